@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, f"{name}.npz"))
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def golden_inputs(g):
+    """BA inputs of a fixture that stores them (C1, C2), without batch dimension."""
+    return dict(xyz=g["in_landmarks_xyz"][0], uv=g["in_landmarks"][0], ii=g["in_ii"], time_idx=g["in_time_idx"],
+                K=g["in_intrinsics"][0], conf=g["in_confidences"], cumrot=g["in_cumrot_last"])
+
+
+@pytest.fixture(scope="session")
+def c1():
+    return load_golden("c1")
+
+
+@pytest.fixture(scope="session")
+def c2():
+    return load_golden("c2")

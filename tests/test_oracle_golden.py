@@ -1,0 +1,81 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz were
+captured from estimation/BA/BA_filtering.py:BA by tools/gen_golden.py)."""
+import numpy as np
+import pytest
+
+from conftest import golden_inputs, load_golden, rel_err
+from oracle import ba_oracle as O
+
+
+def _run(g, k, solver="dense", debug=None):
+    inp = golden_inputs(g)
+    st = g[f"states_in_{k}"][0] if f"states_in_{k}" in g else (g["states0"][0] if k == 0 else g[f"states_out_{k-1}"][0])
+    return O.ba_iteration(int(g["iters"][k]), st, inp["cumrot"], inp["uv"], inp["xyz"], inp["ii"], inp["time_idx"],
+                          inp["K"], inp["conf"], float(g["lamda_in"][k]), initialize=bool(g["initialize"][k]),
+                          solver=solver, debug=debug)
+
+
+@pytest.mark.parametrize("k", range(20))
+def test_c1_every_intermediate(c1, k):
+    g = c1
+    dbg = {}
+    states, lam, last_h, ntr = _run(g, k, debug=dbg)
+    n = states.shape[0]
+    assert rel_err(dbg["est"], g[f"landmark_est_{k}"][0]) < 1e-14
+    assert rel_err(dbg["Jg"], g[f"Jg_{k}"][:, :, :6]) < 1e-13
+    assert np.abs(g[f"Jg_{k}"][:, :, 6:]).max() == 0.0
+    assert g[f"A_offband_{k}"].max() == 0.0          # the reference system is exactly block tridiagonal
+    assert rel_err(dbg["trials"][0]["A"], g[f"A_bands_{k}"][0]) < 1e-11
+    assert rel_err(dbg["rhs"], g[f"JTr_{k}"][0].reshape(n, 9)) < 1e-9
+    assert rel_err(dbg["trials"][0]["dpose"], g[f"dpose_{k}"][0].reshape(n, 9)) < 1e-7
+    assert rel_err(dbg["trials"][0]["est"], g[f"trial_est_{k}"][0][0]) < 1e-9   # inherits the dpose difference
+    if not g["initialize"][k]:
+        assert g[f"Jf_offband_{k}"] == 0.0 and g[f"Hq_offband_{k}"] == 0.0
+        assert np.abs(dbg["r_pred"] - g[f"r_pred_{k}"][0]).max() < 1e-9
+        assert rel_err(dbg["E"], g[f"Jf_blocks_{k}"][:, 0]) < 1e-13
+        assert rel_err(np.broadcast_to(dbg["F"], (n - 1, 6, 9)), g[f"Jf_blocks_{k}"][:, 1]) == 0.0
+        assert rel_err(dbg["qgrad"], g[f"qgrad_{k}"][0][:, 3:6]) < 1e-10
+        Hq = g[f"Hq_bands_{k}"]
+        assert rel_err(dbg["Hd"], Hq[:, 1, 3:6, 3:6]) < 1e-13
+        assert rel_err(dbg["Hu"], Hq[:-1, 2, 3:6, 3:6]) < 1e-13
+        assert rel_err(dbg["Hl"], Hq[1:, 0, 3:6, 3:6]) < 1e-13
+        mask = np.ones((9, 9), bool)
+        mask[3:6, 3:6] = False
+        assert np.abs(Hq[:, :, mask]).max() == 0.0     # only rot-rot blocks are populated
+    assert rel_err(states, g[f"states_out_{k}"][0]) < 1e-10
+    assert lam == g["lamda_out"][k]
+    assert ntr == g["n_trials"][k]
+    assert rel_err(last_h, g[f"last_hessian_{k}"][0]) < 1e-11
+
+
+@pytest.mark.parametrize("k", [0, 5, 9, 10, 15, 19])
+def test_c2_per_call(c2, k):
+    states, lam, last_h, ntr = _run(c2, k, solver="banded")
+    assert rel_err(states, c2[f"states_out_{k}"][0]) < 1e-9
+    assert lam == c2["lamda_out"][k] and ntr == c2["n_trials"][k]
+    assert rel_err(last_h, c2[f"last_hessian_{k}"][0]) < 1e-10
+
+
+def test_c2_chained_20_iterations(c2):
+    """Feed the oracle its own output for all 20 calls: the BASELINE parity bar (<=1e-6)."""
+    g = c2
+    inp = golden_inputs(g)
+    st, lam = g["states0"][0], 1e-4
+    for k in range(20):
+        st, lam, _, ntr = O.ba_iteration(int(g["iters"][k]), st, inp["cumrot"], inp["uv"], inp["xyz"], inp["ii"],
+                                         inp["time_idx"], inp["K"], inp["conf"], lam,
+                                         initialize=bool(g["initialize"][k]), solver="banded")
+        assert ntr == g["n_trials"][k]
+        assert lam == g["lamda_out"][k]
+    ref = g["states_out_19"][0]
+    assert np.abs(st[:, :3] - ref[:, :3]).max() / np.abs(ref[:, :3]).max() < 1e-9
+    assert rel_err(st, ref) < 1e-8
+
+
+def test_solver_variants_agree(c2):
+    k = 10
+    A, b = c2[f"A_bands_{k}"][0], c2[f"JTr_{k}"][0].reshape(-1, 9)
+    xd = O.solve_tridiag(A, b, "dense")
+    xb = O.solve_tridiag(A, b, "banded")
+    assert rel_err(xb, xd) < 1e-7
+    assert rel_err(xd, c2[f"dpose_{k}"][0].reshape(-1, 9)) < 1e-7

@@ -1,0 +1,262 @@
+"""Orbit-determination driver: the host-side counterpart of the reference's
+``estimation/od_pipe.py:streaming_version`` (lines 911-1062) and its helpers.
+
+The driver owns data preparation (frame bookkeeping, ECEF->ECI, ground-truth nadir
+attitude, outlier mask, pose renumbering, IMU pre-integration, initial guess), splits
+the detection stream into batches and calls ``BA`` 20 times per batch.  All the
+heavy arithmetic is inside ``BA`` (HIP); everything here is NumPy fp64 on the host
+and reproduces the reference's integer outputs (``ii``, masks, batch cuts) exactly.
+
+Input formats (reference ``sim/nadir_sim.py:140-149, 236, 256``):
+``detections [M,6] = [frame, lon, lat, u, v, conf]`` and ``orbit [N,12]`` with ECEF
+metres in columns 0:3.  Outputs: ``(errors, first_detection, times)`` as consumed by
+``estimation/errors_eval.py:19-50``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import frames, quat
+from .synth import INTRINSICS, project
+
+NUM_ITERS = 20          # od_pipe.py:918
+KNOT_PERIOD = 1000      # od_pipe.py:216-225
+
+
+@dataclass
+class Window:
+    """Everything ``BA`` needs for one sequence, without batch dimension."""
+    time_idx: np.ndarray          # [T] int64, seconds
+    ii: np.ndarray                # [M] int64 pose index of every observation
+    landmarks_uv: np.ndarray      # [M,2]
+    landmarks_xyz: np.ndarray     # [M,3] ECI km
+    confidences: np.ndarray       # [M]
+    intrinsics: np.ndarray        # [T,4]
+    poses_gt: np.ndarray          # [T,7]
+    vel_gt_full: np.ndarray       # [N,3] per-second finite-difference velocity
+    quat_gt_full: np.ndarray      # [N,4]
+    omega_gt: np.ndarray          # [N,3]
+    cumrot_last: np.ndarray       # [T,4] attitude increment over the gap after each pose
+    max_gap: int
+    mask: np.ndarray              # [M_raw] bool, observations kept
+    extras: dict = field(default_factory=dict)
+
+    @property
+    def velocities(self):
+        return self.vel_gt_full[self.time_idx]
+
+    @property
+    def states_gt(self):
+        return np.concatenate([self.poses_gt, self.velocities], -1)
+
+
+def read_detections(detections, orbit, intrinsics=None):
+    """Frame bookkeeping + ECEF->ECI (reference ``read_detections`` od_pipe.py:185-251).
+
+    ``orbit`` is converted in place like the reference does (pass a copy).  Returns
+    ``orbit, fields, intrinsics, time_idx, ii`` where time_idx holds every frame with a
+    detection plus one "knot" every 1000 s.
+    """
+    det = np.asarray(detections)
+    fields = dict(frame=det[:, 0], uv=det[:, 3:5], lonlat=det[:, 1:3], confidence=det[:, 5])
+    uniq, counts = np.unique(det[:, 0], return_counts=True)
+    uniq = uniq.astype(np.int64)
+    filler = uniq.min() // KNOT_PERIOD + 1
+    offset = 0
+    time_new = []
+    ii = []
+    for i, (t, c) in enumerate(zip(uniq, counts)):
+        if t == filler * KNOT_PERIOD:
+            filler += 1
+        while t > filler * KNOT_PERIOD:
+            time_new.append(filler * KNOT_PERIOD)
+            filler += 1
+            offset += 1
+        time_new.append(t)
+        ii.append(np.full(c, i + offset, dtype=np.int64))
+    n_sec = orbit.shape[0]
+    orbit[:, 0], orbit[:, 1], orbit[:, 2] = frames.ecef_to_eci(
+        orbit[:, 0] / 1000, orbit[:, 1] / 1000, orbit[:, 2] / 1000, times=np.arange(n_sec))
+    if uniq[-1] < n_sec:
+        while filler * KNOT_PERIOD < (n_sec // KNOT_PERIOD) * KNOT_PERIOD + 1:
+            time_new.append(filler * KNOT_PERIOD)
+            filler += 1
+    if intrinsics is None:
+        intrinsics = INTRINSICS
+    return orbit, fields, np.asarray(intrinsics, dtype=np.float64), np.array(time_new, dtype=np.int64), np.concatenate(ii)
+
+
+def prepare_window(detections, orbit_np, intrinsics=None, dt=1.0) -> Window:
+    """Reference od_pipe.py:924-961 (read, ground truth, outlier mask, renumber, IMU)."""
+    orbit, f, intr, time_idx, ii = read_detections(detections, np.array(orbit_np, dtype=np.float64), intrinsics)
+    # process_ground_truths (od_pipe.py:94-123)
+    pos_full = orbit[:, :3]
+    pos_gt = pos_full[time_idx]
+    vel_full = frames.finite_difference(pos_full, dt)
+    quat_gt = frames.nadir_quaternion(pos_gt)
+    quat_full = frames.nadir_quaternion(pos_full)
+    xyz = frames.latlon_to_eci(f["lonlat"][:, 1], f["lonlat"][:, 0], f["frame"])
+    uv = np.asarray(f["uv"], dtype=np.float64)
+    conf = np.asarray(f["confidence"], dtype=np.float64)
+    intr_rows = np.repeat(intr[None], len(pos_gt), axis=0)
+    # outlier mask from the reprojection at ground truth (od_pipe.py:928-930)
+    proj = project(pos_gt[ii], quat_gt[ii], xyz, intr)
+    mask = ((proj[:, 0] > 0) & (proj[:, 1] > 0) & (proj[:, 0] < 4700) & (proj[:, 1] < 2600)
+            & (np.linalg.norm(proj - uv, axis=-1) < 1000) & (conf > 0.8))
+    # remove_elems (od_pipe.py:253-288): keep poses that still own an observation, and knots
+    keep = np.zeros(time_idx.shape[0], dtype=bool)
+    keep[np.unique(ii[mask])] = True
+    keep |= (time_idx % KNOT_PERIOD == 0)
+    new_index = np.cumsum(keep) - 1
+    ii_new = new_index[ii[mask]]
+    time_idx = time_idx[keep]
+    pos_gt, quat_gt = pos_gt[keep], quat_gt[keep]
+    # IMU pre-integration (od_pipe.py:945-961): only the rotation accumulated over each gap is
+    # consumed downstream (BA_utils.py:295), zero-rate padding being the identity.
+    T = len(pos_gt)
+    gaps = np.diff(time_idx)
+    max_gap = int(gaps.max()) if T > 1 else 1
+    omega = quat.omega_from_quats(quat_full, dt)
+    cum = np.zeros((T, 4))
+    cum[:, 3] = 1.0
+    for j in range(max_gap):
+        act = np.nonzero(gaps > j)[0]
+        step = quat.qexp(dt * omega[time_idx[act] + j])
+        cum[act] = step if j == 0 else quat.qmul(cum[act], step)
+    return Window(time_idx=time_idx, ii=ii_new, landmarks_uv=uv[mask], landmarks_xyz=xyz[mask],
+                  confidences=conf[mask], intrinsics=intr_rows, poses_gt=np.concatenate([pos_gt, quat_gt], 1),
+                  vel_gt_full=vel_full, quat_gt_full=quat_full, omega_gt=omega, cumrot_last=cum,
+                  max_gap=max_gap, mask=mask, extras=dict(proj_gt=proj[mask]))
+
+
+def initial_guess(win: Window, seed=0):
+    """Ground truth + Gaussian perturbation (100 km, 0.2 rad, 10 % |v|), od_pipe.py:962-969.
+
+    Uses torch's CPU generator so the draw is the one the reference makes after
+    ``torch.manual_seed(seed)``.
+    """
+    import torch
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    T = win.poses_gt.shape[0]
+    vel = win.velocities
+    pos_off = (torch.randn((T, 3)) * 100).double().numpy()
+    ori_off = (torch.randn([T, 3]) * 0.2).double().numpy()
+    vmean = torch.tensor(vel).abs().mean()
+    vel_off = (torch.randn([T, 3]) * vmean * 0.1).numpy()
+    position = win.poses_gt[:, :3] + pos_off
+    orientation = quat.qexp(quat.qlog(win.poses_gt[:, 3:]) + ori_off)
+    return np.concatenate([position, orientation, vel + vel_off], -1)
+
+
+def next_batch(ii, time_idx, i):
+    """Cut where the frame gap exceeds 200 s after >4 near-contiguous observations.
+
+    Reference ``identify_next_batch_new`` od_pipe.py:898-905.  Returns
+    ``(t_final, i_final, seq_end)``.
+    """
+    t_obs = time_idx[ii]
+    contiguous = 0
+    for j in range(i + 1, len(ii)):
+        gap = t_obs[j] - t_obs[j - 1]
+        if gap < 100:
+            contiguous += 1
+        if gap > 200 and contiguous > 4:
+            return int(ii[j - 1]) + 1, j, False
+    return int(ii[-1]) + 1, len(ii), True
+
+
+def propagate_between_batches(state, omega, tdiff, duration, rk4_step):
+    """Dead-reckon the last estimate across a gap (reference ``propagate_dynamics_init``
+    BA_utils.py:114-129): ``tdiff`` steps to reach the first new frame, then ``duration``
+    more, returning the per-second states from the first new frame on, [duration+1, 10].
+    """
+    x = np.concatenate([state[:3], state[7:10]])
+    q = state[3:7].copy()
+    out = []
+    for k in range(tdiff + duration):
+        x = rk4_step(x)
+        q = quat.qmul(q, quat.qexp(1.0 * omega[k]))
+        if k >= tdiff - 1:
+            out.append(np.concatenate([x[:3], q, x[3:]]))
+    return np.stack(out)
+
+
+def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, detections_file_name=None,
+                      ba=None, num_iters=NUM_ITERS, record=None):
+    """Drop-in for the reference's ``streaming_version`` (od_pipe.py:911-1062).
+
+    ``ba`` defaults to the HIP-backed :func:`vinsat_amd.ba.BA`; tests may inject another
+    callable with the reference signature.
+    """
+    import torch
+    from .synth import rk4_step
+    if ba is None:
+        from .ba import BA as ba
+    if detections is None:
+        detections = np.load(detections_file_name, allow_pickle=True)
+    if orbit_np is None:
+        orbit_np = np.load(orbit_file_name, allow_pickle=True)
+    win = prepare_window(detections, orbit_np)
+    states = initial_guess(win, seed=0)
+    time_idx, ii = win.time_idx, win.ii
+    T = len(time_idx)
+    # the reference hands BA an imu tensor [1,T,N,10] of which only [..., -1, 6:10] is read
+    imu = torch.zeros((1, T, 1, 10), dtype=torch.float64)
+    imu[0, :, 0, 6:10] = torch.from_numpy(win.cumrot_last)
+    uv = torch.from_numpy(win.landmarks_uv)[None]
+    xyz = torch.from_numpy(win.landmarks_xyz)[None]
+    intr = torch.from_numpy(win.intrinsics)[None]
+    conf = torch.from_numpy(win.confidences)
+    poses_gt = torch.from_numpy(win.poses_gt)
+    vel_all = torch.from_numpy(win.velocities)[None]
+    states_all = torch.from_numpy(states)[None]
+
+    t = i = 0
+    seq_end = False
+    patch = 0
+    errors, times = [], []
+    first_detection = None
+    states_t = vel_t = None
+    while not seq_end:
+        t_init = t
+        t, i, seq_end = next_batch(ii, time_idx, i)
+        if patch == 0:
+            states_t = states_all[:, :t]
+            vel_t = vel_all[:, :t]
+            first_detection = time_idx[:t][-1]
+        else:
+            omega = win.omega_gt[time_idx[t_init - 1]:time_idx[t - 1]]
+            tdiff = int(time_idx[t_init] - time_idx[t_init - 1])
+            duration = int(time_idx[t - 1] - time_idx[t_init])
+            prop = propagate_between_batches(states_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
+            sel = time_idx[t_init:t] - time_idx[t_init]
+            prop = torch.from_numpy(prop[sel])[None]
+            states_t = torch.cat([states_t, prop], dim=1)
+            vel_t = torch.cat([vel_t, prop[..., 7:]], dim=1)
+            err_prop = (prop[0, :, :3] - poses_gt[t - prop.shape[1]:t, :3]).norm(dim=-1)[:-1]
+            times.append(time_idx[t - prop.shape[1]:t][:-1])
+            errors.append(err_prop)
+        lam = 1e-4
+        for it in range(num_iters):
+            init = (it < 10) if patch == 0 else False
+            states_t, vel_t, lam, last_h = ba(it, states_t, vel_t, imu[:, :t], uv[:, :i], xyz[:, :i], ii[:i],
+                                              time_idx[:t], intr[:, :t], conf[:i], 1e-3, 1e-3, lam,
+                                              poses_gt[:t], initialize=init)
+            if record is not None:
+                record.append(dict(patch=patch, iter=it, states=states_t.clone(), lamda=lam))
+        patch += 1
+        errors.append((states_t[0, -1:, :3] - poses_gt[t - 1:t, :3]).norm(dim=-1))
+        times.append(time_idx[t - 1:t])
+        if seq_end and t < T:
+            t_init, t = t, T
+            omega = win.omega_gt[time_idx[t_init - 1]:time_idx[t - 1]]
+            tdiff = int(time_idx[t_init] - time_idx[t_init - 1])
+            duration = int(time_idx[t - 1] - time_idx[t_init])
+            prop = propagate_between_batches(states_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
+            prop = torch.from_numpy(prop[time_idx[t_init:t] - time_idx[t_init]])
+            errors.append((prop[:, :3] - poses_gt[t_init:t, :3]).norm(dim=-1))
+            times.append(time_idx[-prop.shape[0]:])
+    return torch.cat(errors), first_detection, times
