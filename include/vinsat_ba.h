@@ -1,0 +1,136 @@
+/*
+ * vinsat_ba.h -- C ABI of libvinsat_ba.so: the VINSat bundle-adjustment iteration on MI355X.
+ *
+ * The reference exposes this path as ONE Python function (there is no FFI layer in it):
+ *
+ *   BA(iter, states, velocities, imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics,
+ *      confidences, Sigma, V, lamda_init, poses_gt_eci, initialize=False)
+ *        -> (states_new, velocities, lamda_init, last_hessian)
+ *   reference: estimation/BA/BA_filtering.py:4-98, called from estimation/od_pipe.py:1038,1040.
+ *
+ * The entry points below are what a binding for that function needs: the arguments that stay constant
+ * over the 20 iterations of a window are uploaded once (observations, per-pose constants), and
+ * vba_iterate() is one call of BA().  Plain pointers and sizes only; all host buffers are caller
+ * owned, row-major, fp64 unless stated; every call returns 0 on success or a VBA_E* code.
+ *
+ * A handle owns its device memory and (unless vba_set_stream is used) its HIP stream.  Calls are
+ * synchronous on return unless documented otherwise.  One handle per host thread.
+ *
+ * A handle can hold W independent windows ("batched windows": the reference's outer loop over
+ * sequences, estimation/od_pipe.py:1069-1077); every kernel launch then covers all of them.
+ */
+#ifndef VINSAT_BA_H
+#define VINSAT_BA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vba_context* vba_handle;
+
+enum {
+    VBA_OK = 0,
+    VBA_EINVAL = 1,     /* bad argument (null pointer, size out of range, unsorted input ...) */
+    VBA_ENODEV = 2,     /* no usable HIP device */
+    VBA_EHIP = 3,       /* a HIP runtime call failed; see vba_last_error() */
+    VBA_ESTATE = 4,     /* call order violated (e.g. iterate before upload) */
+    VBA_ENOMEM = 5
+};
+
+/* bits of the `flags` word returned by vba_iterate (reference behaviour is unchanged by them) */
+enum {
+    VBA_FLAG_LAMBDA_EXHAUSTED = 1u, /* "lamda too large": no trial improved, last trial kept (BA_filtering.py:75-77) */
+    VBA_FLAG_NONFINITE = 2u,        /* NaN/Inf met in the solve or the residuals */
+    VBA_FLAG_ZERO_PIVOT = 4u        /* a diagonal block was numerically singular */
+};
+
+/* selectors for vba_debug_fetch: intermediates of the LAST vba_iterate call, window 0 unless stated */
+enum {
+    VBA_DBG_EST = 0,        /* [m,2]   reprojection at the input states (BA_utils.py:30-43), input order */
+    VBA_DBG_WEIGHT = 1,     /* [m]     final robust weight w_k (BA_filtering.py:24-25), input order */
+    VBA_DBG_H = 2,          /* [n,6,6] per-pose sum of w J^T J, scaled as the reference (BA_filtering.py:32-36) */
+    VBA_DBG_B = 3,          /* [n,6]   per-pose sum of w J^T r (BA_filtering.py:44) */
+    VBA_DBG_PHI = 4,        /* [n,6,6] d x_hat_i / d x_i of the orbit propagation (BA_utils.py:73-87) */
+    VBA_DBG_RPRED = 5,      /* [n-1,7] dynamics residuals (BA_utils.py:476) */
+    VBA_DBG_QGRAD = 6,      /* [n,3]   attitude gradient, rotation slots (BA_utils.py:520) */
+    VBA_DBG_HQ = 7,         /* [n,3,3,3] attitude Newton blocks (sub, diag, super) rot-rot (BA_utils.py:521-523) */
+    VBA_DBG_BANDS = 8,      /* [n,3,9,9] undamped block-tridiagonal system (sub, diag, super) (BA_filtering.py:54) */
+    VBA_DBG_RHS = 9,        /* [n,9]   JTr (BA_filtering.py:48) */
+    VBA_DBG_DPOSE = 10,     /* [n,9]   solution of the last LM trial (BA_filtering.py:55) */
+    VBA_DBG_SCALARS = 11,   /* [8]     c_obs, w_max, init_residual, last trial residual, lamda32 of last trial, sigma, alpha, n_trials */
+    VBA_DBG_JG = 12         /* [m,2,6] reprojection Jacobian (BA_utils.py:44-48), input order */
+};
+
+/* library / device */
+int vba_version(void);
+const char* vba_last_error(void);
+int vba_device_count(int* count);
+
+/* Create a context on HIP device `device` able to hold `windows` windows of at most n_max poses and
+ * m_max observations each.  Replaces nothing in the reference (it allocates per call). */
+int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* out);
+int vba_destroy(vba_handle h);
+
+/* Run all work of this handle on an existing HIP stream (e.g. the one RCCL collectives are issued on).
+ * `hip_stream` is a hipStream_t; 0 restores the handle's own stream. */
+int vba_set_stream(vba_handle h, void* hip_stream);
+
+/* Observation rows of window `window`: landmarks_xyz [m,3] (ECI km), landmarks (uv) [m,2] px,
+ * confidences [m], ii [m] pose index of each row (BA arguments landmarks_xyz, landmarks, confidences, ii:
+ * BA_filtering.py:4; ii is int64 as at BA_filtering.py:35).  n is the number of poses the indices refer to. */
+int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const double* landmarks_xyz,
+                            const double* landmarks_uv, const double* confidences, const int64_t* ii);
+
+/* Per-pose constants of window `window`: intrinsics [n,4] = fx,fy,cx,cy; cumrot_last [n,4] =
+ * imu_meas[0,:,-1,6:10], the attitude increment over the gap that follows each pose (the only part of
+ * imu_meas the reference's CPU path reads, BA_utils.py:295); time_idx [n] seconds, strictly increasing. */
+int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics, const double* cumrot_last,
+                      const int64_t* time_idx);
+
+/* Device-resident state of a window: [n,10] = p(3) q(4, scalar last) v(3); lamda is the LM damping. */
+int vba_set_states(vba_handle h, int window, const double* states, double lamda);
+int vba_get_states(vba_handle h, int window, double* states, double* lamda, double* last_hessian /*[81] or NULL*/,
+                   int* n_trials /*or NULL*/, unsigned* flags /*or NULL*/);
+
+/* One BA() call (BA_filtering.py:4-98) on EVERY window of the handle, states and lamda device resident:
+ * states <- states_new, lamda <- lamda_out.  `iter` selects alpha and Sigma (BA_filtering.py:22,26);
+ * `initialize` != 0 is the landmark-only phase (BA_utils.py:463-466).  Synchronous. */
+int vba_step(vba_handle h, int iter, int initialize);
+
+/* Convenience: set_states(window 0) + step + get_states(window 0); the exact shape of one BA() call. */
+int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in,
+                double* states_out, double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags);
+
+/* Copy an intermediate of the last step of `window` to host memory; *count receives the number of
+ * doubles written (capacity is checked). */
+int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t capacity, int64_t* count);
+
+/* Timing of the last vba_step measured with HIP events on the handle's stream, milliseconds. */
+int vba_last_step_ms(vba_handle h, float* ms);
+
+/* ---- observation-sharded multi-GPU operation (one rank per GPU, window 0 only) -------------------------
+ * Each rank uploads its slice of the observation rows and the full per-pose constants.  One BA() call is
+ * the sequence   stage1 -> all-gather -> stage2 -> all-gather -> stage3 -> all-gather -> stage4 [-> stage3 ...]
+ * where the exchanges are done by the caller (RCCL through torch.distributed) on DEVICE buffers; all
+ * stage calls are asynchronous on the handle's stream except stage4.
+ */
+/* number of doubles each rank contributes to the second exchange: per-pose blocks + gradient + scalars */
+int64_t vba_sh_partial_count(int n);
+/* stage 1: residuals of the local rows at the resident states; writes 2*m_local |r| values to d_abs_local. */
+int vba_sh_stage1(vba_handle h, int iter, int initialize, double* d_abs_local);
+/* stage 2: exact lower median over the gathered |r| of all ranks (count_all values), robust weights and the
+ * local per-pose accumulation; writes vba_sh_partial_count(n) doubles to d_partial_local. */
+int vba_sh_stage2(vba_handle h, const double* d_abs_all, int64_t count_all, double* d_partial_local);
+/* stage 3: reduce the R gathered partials in rank order, build + solve the system (every rank redundantly),
+ * retract, and evaluate the local part of the trial residual into d_trial_local[0..1]. */
+int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, int64_t m_total, double* d_trial_local);
+/* stage 4: accept test on the gathered trial sums (2 doubles per rank); *done = 1 when the LM loop ended
+ * (states/lamda updated).  Synchronous. */
+int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VINSAT_BA_H */

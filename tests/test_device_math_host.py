@@ -1,0 +1,140 @@
+"""The formulas the HIP kernels use (vinsat_amd/csrc/vba_math.h), compiled for the host and compared with
+the oracle.  This checks the device arithmetic on a machine without a GPU; it is not a product path."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_inputs, rel_err
+from oracle import ba_oracle as O
+
+SRC = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")
+LIB = os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so")
+P = ctypes.POINTER(ctypes.c_double)
+PI = ctypes.POINTER(ctypes.c_int64)
+
+
+def _p(a):
+    return a.ctypes.data_as(P)
+
+
+def _pi(a):
+    return a.ctypes.data_as(PI)
+
+
+@pytest.fixture(scope="module")
+def hc():
+    hdr = os.path.join(ROOT, "vinsat_amd", "csrc", "vba_math.h")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", LIB, SRC])
+    return ctypes.CDLL(LIB)
+
+
+@pytest.mark.parametrize("k", [0, 10, 19])
+def test_projection_and_jacobian(hc, c2, k):
+    inp = golden_inputs(c2)
+    st = np.ascontiguousarray(c2[f"states_in_{k}"][0])
+    m = inp["xyz"].shape[0]
+    est = np.zeros((m, 2))
+    J = np.zeros((m, 2, 6))
+    hc.hc_project(ctypes.c_int64(m), _p(st), _p(inp["K"]), _p(inp["xyz"]), _pi(inp["ii"]), _p(est), _p(J))
+    assert rel_err(est, c2[f"landmark_est_{k}"][0]) < 1e-14
+    assert rel_err(J, c2[f"Jg_{k}"][:, :, :6]) < 1e-13
+
+
+@pytest.mark.parametrize("it", [0, 1, 2, 3, 7])
+def test_robust_weights(hc, c2, it):
+    inp = golden_inputs(c2)
+    rng = np.random.default_rng(it)
+    r = rng.normal(0, 3.0, size=(500, 2))
+    r[0] = 0.0
+    w_ref, c, wmax = O.robust_weights(r, it, np.ones(500))
+    alpha, _ = O.lm_schedule(it)
+    w = np.zeros(500)
+    hc.hc_weights(ctypes.c_int64(500), _p(r), ctypes.c_double(c), ctypes.c_double(alpha), _p(w))
+    assert rel_err(w / w.max(), w_ref) < 1e-14
+
+
+@pytest.mark.parametrize("k", [10, 19])
+def test_orbit_and_attitude_factors(hc, c2, k):
+    inp = golden_inputs(c2)
+    st = np.ascontiguousarray(c2[f"states_in_{k}"][0])
+    n = st.shape[0]
+    steps = O.step_counts(inp["time_idx"])
+    xhat = np.zeros((n, 6))
+    Phi = np.zeros((n, 6, 6))
+    hc.hc_orbit(n, _p(st), _pi(steps), _p(xhat), _p(Phi))
+    x = np.concatenate([st[:, :3], st[:, 7:]], 1)
+    D = np.array([1, 1, 1, 100.0, 100, 100])
+    r_orb = (xhat[:-1] - x[1:]) * D
+    assert np.abs(r_orb - c2[f"r_pred_{k}"][0][:, :6]).max() < 1e-9
+    E = np.zeros((n - 1, 6, 9))
+    E[:, :, :3] = (D[None, :, None] * Phi[:-1])[:, :, :3]
+    E[:, :, 6:] = (D[None, :, None] * Phi[:-1])[:, :, 3:]
+    assert rel_err(E, c2[f"Jf_blocks_{k}"][:, 0]) < 1e-13
+    xf = np.zeros((n, 6))
+    hc.hc_orbit_fwd(n, _p(st), _pi(steps), _p(xf))
+    assert np.array_equal(xf, xhat)
+    f = np.zeros(n)
+    qgrad = np.zeros((n, 3))
+    Hd, Hu, Hl = np.zeros((n, 3, 3)), np.zeros((n, 3, 3)), np.zeros((n, 3, 3))
+    hc.hc_attitude(n, _p(st), _p(inp["cumrot"]), _p(f), _p(qgrad), _p(Hd), _p(Hu), _p(Hl))
+    Hq = c2[f"Hq_bands_{k}"]
+    assert np.abs(f[:-1] - c2[f"r_pred_{k}"][0][:, 6]).max() < 1e-10
+    assert rel_err(qgrad, c2[f"qgrad_{k}"][0][:, 3:6]) < 1e-10
+    assert rel_err(Hd, Hq[:, 1, 3:6, 3:6]) < 1e-13
+    assert rel_err(Hu[:-1], Hq[:-1, 2, 3:6, 3:6]) < 1e-13
+    assert rel_err(Hl[1:], Hq[1:, 0, 3:6, 3:6]) < 1e-13
+
+
+@pytest.mark.parametrize("k", [0, 9, 10, 19])
+def test_assembly_matches_reference_system(hc, c2, k):
+    """Feed the oracle's per-pose pieces through the device assembly and compare with the matrix the
+    reference handed to torch.linalg.solve."""
+    inp = golden_inputs(c2)
+    g = c2
+    st = g[f"states_in_{k}"][0]
+    n = st.shape[0]
+    init = bool(g["initialize"][k])
+    dbg = {}
+    O.ba_iteration(int(g["iters"][k]), st, inp["cumrot"], inp["uv"], inp["xyz"], inp["ii"], inp["time_idx"], inp["K"],
+                   inp["conf"], float(g["lamda_in"][k]), initialize=init, debug=dbg)
+    _, sigma = O.lm_schedule(int(g["iters"][k]))
+    iu = np.triu_indices(6)
+    Hraw = np.ascontiguousarray((dbg["H"] * dbg["wmax"])[:, iu[0], iu[1]])
+    braw = np.ascontiguousarray(dbg["b"] * dbg["wmax"])
+    z = lambda *s: np.zeros(s)
+    if init:
+        Phi, rorb, qgrad, Hd, Hu, Hl = z(n, 36), z(n, 6), z(n, 3), z(n, 9), z(n, 9), z(n, 9)
+        sig = 0.0
+    else:
+        steps = O.step_counts(inp["time_idx"])
+        xhat, Phi = np.zeros((n, 6)), np.zeros((n, 6, 6))
+        hc.hc_orbit(n, _p(np.ascontiguousarray(st)), _pi(steps), _p(xhat), _p(Phi))
+        rorb = np.zeros((n, 6))
+        rorb[:-1] = dbg["r_pred"][:, :6]
+        qgrad = np.ascontiguousarray(dbg["qgrad"])
+        Hd = np.ascontiguousarray(dbg["Hd"])
+        Hu, Hl = z(n, 3, 3), z(n, 3, 3)
+        Hu[:-1], Hl[1:] = dbg["Hu"], dbg["Hl"]
+        sig = float(sigma)
+    bands, rhs = np.zeros((n, 3, 9, 9)), np.zeros((n, 9))
+    hc.hc_assemble(n, _p(Hraw), _p(braw), ctypes.c_double(1.0 / dbg["wmax"]), ctypes.c_double(sig), _p(Phi), _p(rorb),
+                   _p(qgrad), _p(Hd), _p(Hu), _p(Hl), _p(bands), _p(rhs))
+    lam32 = float(np.float32(g["lamda_in"][k]))
+    A = bands.copy()
+    A[:, 1] += lam32 * np.eye(9)
+    assert rel_err(A, g[f"A_bands_{k}"][0]) < 1e-11
+    assert rel_err(rhs, g[f"JTr_{k}"][0].reshape(n, 9)) < 1e-9
+
+
+def test_retraction(hc, c2):
+    k = 10
+    st = np.ascontiguousarray(c2[f"states_in_{k}"][0])
+    dp = np.ascontiguousarray(c2[f"dpose_{k}"][0].reshape(-1, 9))
+    dp[3, 3:6] = 0.0     # exercises the identity branch of the exponential
+    out = np.zeros_like(st)
+    hc.hc_retract(st.shape[0], _p(st), _p(dp), _p(out))
+    assert rel_err(out, O.retract(st, dp)) < 1e-15

@@ -1,0 +1,69 @@
+"""ctypes binding of libvinsat_ba.so (C ABI declared in include/vinsat_ba.h).
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible the
+loader / the first call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvinsat_ba.so")
+
+PD = POINTER(c_double)
+PI64 = POINTER(c_int64)
+
+# name -> (restype, argtypes); mirrors include/vinsat_ba.h one to one
+SIGNATURES = {
+    "vba_version": (c_int, []),
+    "vba_last_error": (c_char_p, []),
+    "vba_device_count": (c_int, [POINTER(c_int)]),
+    "vba_create": (c_int, [c_int, c_int, c_int, c_int64, POINTER(c_void_p)]),
+    "vba_destroy": (c_int, [c_void_p]),
+    "vba_set_stream": (c_int, [c_void_p, c_void_p]),
+    "vba_upload_observations": (c_int, [c_void_p, c_int, c_int, c_int64, PD, PD, PD, PI64]),
+    "vba_upload_window": (c_int, [c_void_p, c_int, c_int, PD, PD, PI64]),
+    "vba_set_states": (c_int, [c_void_p, c_int, PD, c_double]),
+    "vba_get_states": (c_int, [c_void_p, c_int, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
+    "vba_step": (c_int, [c_void_p, c_int, c_int]),
+    "vba_iterate": (c_int, [c_void_p, c_int, c_int, c_double, PD, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
+    "vba_debug_fetch": (c_int, [c_void_p, c_int, c_int, PD, c_int64, PI64]),
+    "vba_last_step_ms": (c_int, [c_void_p, POINTER(c_float)]),
+    "vba_sh_partial_count": (c_int64, [c_int]),
+    "vba_sh_stage1": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "vba_sh_stage2": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "vba_sh_stage3": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "vba_sh_stage4": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int)]),
+}
+
+_lib = None
+
+
+class VbaError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and set the prototypes (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VbaError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C vinsat_amd/csrc` (there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        lib = lib or load()
+        msg = lib.vba_last_error()
+        raise VbaError(f"libvinsat_ba error {rc}: {msg.decode() if msg else ''}")

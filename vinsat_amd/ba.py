@@ -1,0 +1,88 @@
+"""``BA``: the reference's bundle-adjustment call surface, executed by the HIP kernels.
+
+Same positional signature and 4-tuple return as the reference's
+``estimation/BA/BA_filtering.py:4, 98``::
+
+    states_new, velocities, lamda_init, last_hessian = BA(iter, states, velocities, imu_meas, landmarks,
+        landmarks_xyz, ii, time_idx, intrinsics, confidences, Sigma, V, lamda_init, poses_gt_eci, initialize=False)
+
+Behaviour kept from the reference: ``Sigma``/``V`` are ignored (overwritten at :26-27),
+``velocities`` is returned untouched, only ``imu_meas[0, :, -1, 6:10]`` is read
+(``BA_utils.py:295``), a "lamda too large" outcome keeps the last trial (:75-77).
+Inputs may be torch tensors or NumPy arrays; outputs are fp64 torch tensors shaped like
+the reference's (``[1,n,10]``, ``[1,9,9]``).
+
+The observation arrays are constant over the 20 calls of a window, so the engine is cached
+and re-uploaded only when they change (cheap fingerprint).  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import BAEngine
+
+_cache = {}
+
+
+def _np(x):
+    try:
+        import torch
+        if isinstance(x, torch.Tensor):
+            return x.detach().cpu().double().numpy()
+    except ImportError:
+        pass
+    return np.asarray(x, dtype=np.float64)
+
+
+def _fingerprint(*arrays):
+    parts = []
+    for a in arrays:
+        parts.append((a.shape, a.dtype.str, a.ctypes.data, float(a.reshape(-1)[:: max(1, a.size // 64)].sum())))
+    return tuple(parts)
+
+
+def _engine_for(xyz, uv, conf, ii, K, cum, t, device):
+    n, m = K.shape[0], xyz.shape[0]
+    eng = _cache.get("eng")
+    if eng is None or eng.n_max < n or eng.m_max < m or eng.device != device:
+        if eng is not None:
+            eng.close()
+        eng = BAEngine(max(n, 16), max(m, 256), windows=1, device=device)
+        eng.n_max, eng.m_max, eng.device = max(n, 16), max(m, 256), device
+        _cache["eng"] = eng
+        _cache["fp"] = None
+    fp = (n, m, ii.tobytes() if m <= 4096 else (int(ii.sum()), int(ii[0]), int(ii[-1])),
+          t.tobytes(), float(xyz.sum()), float(uv.sum()), float(conf.sum()), float(K.sum()), float(cum.sum()))
+    if _cache.get("fp") != fp:
+        eng.upload_observations(xyz, uv, conf, ii, n)
+        eng.upload_window(K, cum, t)
+        _cache["fp"] = fp
+    return eng
+
+
+def BA(iter, states, velocities, imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences, Sigma, V,
+       lamda_init, poses_gt_eci, initialize=False, device=0):
+    import torch
+    st = _np(states)
+    if st.ndim != 3 or st.shape[0] != 1 or st.shape[2] != 10:
+        raise ValueError("states must be [1, n, 10] (the reference hard-codes batch index 0, BA_filtering.py:24,37)")
+    n = st.shape[1]
+    imu = _np(imu_meas)
+    cum = np.ascontiguousarray(imu[0, :, -1, 6:10])
+    uv = _np(landmarks).reshape(-1, 2)
+    xyz = _np(landmarks_xyz).reshape(-1, 3)
+    K = _np(intrinsics).reshape(-1, 4)
+    conf = _np(confidences).reshape(-1)
+    ii = np.ascontiguousarray(np.asarray(ii), dtype=np.int64).reshape(-1)
+    t = np.ascontiguousarray(np.asarray(time_idx), dtype=np.int64).reshape(-1)
+    if not (K.shape[0] == n and cum.shape[0] == n and t.shape[0] == n):
+        raise ValueError("intrinsics / imu_meas / time_idx must have one row per pose")
+    eng = _engine_for(xyz, uv, conf, ii, K, cum, t, device)
+    out, lam, hess, n_trials, flags = eng.iterate(int(iter), bool(initialize), float(lamda_init), st[0])
+    if flags & 1:
+        print("lamda too large")          # reference BA_filtering.py:76
+    BA.last = dict(n_trials=n_trials, flags=flags, ms=eng.last_step_ms())
+    return (torch.from_numpy(out)[None], velocities, lam, torch.from_numpy(hess)[None])
+
+
+BA.last = {}

@@ -1,0 +1,557 @@
+// vba_api.hip -- C ABI of libvinsat_ba.so (see include/vinsat_ba.h): context, uploads, one BA() step.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/vinsat_ba.h"
+#include "vba_device.h"
+#include "vba_launch.h"
+
+using namespace vba;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(VBA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+struct Arena {
+    char* base = nullptr;
+    size_t size = 0, used = 0;
+    template <class T>
+    T* take(size_t count) {
+        used = (used + 255) & ~size_t(255);
+        T* p = reinterpret_cast<T*>(base + used);
+        used += count * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace
+
+struct vba_context {
+    int device = 0;
+    int W = 0, n_max = 0;
+    int64_t m_max = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Arena arena;
+    DevView V{};
+    // mutable device pointers (DevView holds const views of some)
+    int *d_n = nullptr, *d_m = nullptr, *d_opose = nullptr, *d_pose_ptr = nullptr, *d_steps = nullptr;
+    double *d_ox = nullptr, *d_oy = nullptr, *d_oz = nullptr, *d_ou = nullptr, *d_ov = nullptr, *d_oconf = nullptr;
+    double *d_intr = nullptr, *d_cumrot = nullptr;
+    StepParams* d_prm = nullptr;
+    StepParams* h_prm = nullptr;            // pinned
+    char* h_head = nullptr;                 // pinned, W * kHead bytes
+    std::vector<int> n, m;
+    std::vector<char> have_obs, have_win, have_state;
+    std::vector<std::vector<int64_t>> perm; // sorted position -> input row
+    float last_ms = 0.f;
+    bool stepped = false;
+    int last_iter = 0, last_init = 0;
+    double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
+    size_t dbg_cap = 0;
+};
+
+namespace {
+
+constexpr size_t kHead = offsetof(WinScalars, sel_prefix);
+
+void fill_params(StepParams& p, int iter, int initialize) {
+    // BA_filtering.py:22: alpha = min(max(1 - (2*(iter/5) - 1), 1), 2);  :26: Sigma = min(10000*(iter+1)**2, 1000000)
+    double alpha = 1.0 - (2.0 * ((double)iter / 5.0) - 1.0);
+    alpha = std::min(std::max(alpha, 1.0), 2.0);
+    const double it1 = (double)iter + 1.0;
+    const double sigma = std::min(10000.0 * it1 * it1, 1000000.0);
+    p.alpha = alpha;
+    p.am2 = std::fabs(alpha - 2.0);
+    p.expo = alpha / 2.0 - 1.0;
+    p.alpha_is_2 = alpha == 2.0;
+    p.sigma = sigma;
+    p.sqrt_sigma = std::sqrt(sigma);
+    p.initialize = initialize ? 1 : 0;
+    p.iter = iter;
+    p.pad = 0;
+}
+
+int check_window(vba_handle h, int window) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (window < 0 || window >= h->W) return fail(VBA_EINVAL, "window index out of range");
+    return VBA_OK;
+}
+
+int read_heads(vba_handle h) {
+    HIPCHK(hipMemcpy2DAsync(h->h_head, kHead, h->V.sc, sizeof(WinScalars), kHead, h->W, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return VBA_OK;
+}
+
+const WinScalars* head(vba_handle h, int w) { return reinterpret_cast<const WinScalars*>(h->h_head + (size_t)w * kHead); }
+
+int ready(vba_handle h) {
+    for (int w = 0; w < h->W; ++w)
+        if (!h->have_obs[w] || !h->have_win[w] || !h->have_state[w])
+            return fail(VBA_ESTATE, "window " + std::to_string(w) + " is missing observations, pose constants or states");
+    return VBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vba_version(void) { return 100; }
+
+const char* vba_last_error(void) { return g_err.c_str(); }
+
+int vba_device_count(int* count) {
+    if (!count) return fail(VBA_EINVAL, "null count");
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *count = c;
+    return VBA_OK;
+}
+
+int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* out) {
+    if (!out) return fail(VBA_EINVAL, "null out");
+    *out = nullptr;
+    if (windows < 1 || n_max < 2 || m_max < 1) return fail(VBA_EINVAL, "need windows >= 1, n_max >= 2, m_max >= 1");
+    if (m_max > (int64_t)1 << 30) return fail(VBA_EINVAL, "m_max too large");
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) return fail(VBA_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= cnt) return fail(VBA_EINVAL, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    vba_context* h = new (std::nothrow) vba_context();
+    if (!h) return fail(VBA_ENOMEM, "host allocation failed");
+    h->device = device;
+    h->W = windows;
+    h->n_max = n_max;
+    h->m_max = m_max;
+    const size_t W = windows, N = n_max, M = (size_t)m_max;
+    const int nblk_obs = (int)((M + kObsBlock - 1) / kObsBlock);
+    const int nblk_dyn = (int)((N + kObsBlock - 1) / kObsBlock);
+    size_t bytes = 0;
+    auto need = [&](size_t b) { bytes += ((b + 255) & ~size_t(255)) + 256; };
+    need(W * 4); need(W * 4); need(sizeof(StepParams)); need(W * sizeof(WinScalars));
+    for (int k = 0; k < 6; ++k) need(W * M * 8);
+    need(W * M * 4); need(W * (N + 1) * 4);
+    need(W * N * 10 * 8); need(W * N * 10 * 8); need(W * N * 10 * 8);
+    need(W * N * 4 * 8); need(W * N * 4 * 8); need(W * N * 4);
+    need(W * 2 * M * 8); need(W * M * 8); need(W * nblk_obs * 8); need(W * (nblk_obs + nblk_dyn) * 8);
+    need(W * kSelPasses * kSelBins * 4);
+    const size_t per_pose = 21 + 6 + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
+    need(W * N * per_pose * 8 + 16 * 256);
+    bytes += 1 << 16;
+    if (hipMalloc(&h->arena.base, bytes) != hipSuccess) {
+        delete h;
+        return fail(VBA_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    }
+    h->arena.size = bytes;
+    hipMemset(h->arena.base, 0, bytes);
+    Arena& A = h->arena;
+    DevView& V = h->V;
+    V.W = windows; V.n_max = n_max; V.m_max = m_max; V.nblk_obs = nblk_obs; V.nblk_dyn = nblk_dyn;
+    V.n = h->d_n = A.take<int>(W);
+    V.m = h->d_m = A.take<int>(W);
+    V.prm = h->d_prm = A.take<StepParams>(1);
+    V.sc = A.take<WinScalars>(W);
+    V.ox = h->d_ox = A.take<double>(W * M); V.oy = h->d_oy = A.take<double>(W * M); V.oz = h->d_oz = A.take<double>(W * M);
+    V.ou = h->d_ou = A.take<double>(W * M); V.ov = h->d_ov = A.take<double>(W * M); V.oconf = h->d_oconf = A.take<double>(W * M);
+    V.opose = h->d_opose = A.take<int>(W * M);
+    V.pose_ptr = h->d_pose_ptr = A.take<int>(W * (N + 1));
+    V.states = A.take<double>(W * N * 10); V.states_new = A.take<double>(W * N * 10); V.states_prev = A.take<double>(W * N * 10);
+    V.intr = h->d_intr = A.take<double>(W * N * 4);
+    V.cumrot = h->d_cumrot = A.take<double>(W * N * 4);
+    V.steps = h->d_steps = A.take<int>(W * N);
+    V.absr = A.take<double>(W * 2 * M); V.wraw = A.take<double>(W * M);
+    V.part_init = A.take<double>(W * nblk_obs); V.part_trial = A.take<double>(W * (nblk_obs + nblk_dyn));
+    V.hist = A.take<unsigned>(W * kSelPasses * kSelBins);
+    V.Hraw = A.take<double>(W * N * 21); V.braw = A.take<double>(W * N * 6);
+    V.xhat = A.take<double>(W * N * 6); V.Phi = A.take<double>(W * N * 36); V.rorb = A.take<double>(W * N * 6);
+    V.fatt = A.take<double>(W * N); V.qgrad = A.take<double>(W * N * 3);
+    V.Hd = A.take<double>(W * N * 9); V.Hu = A.take<double>(W * N * 9); V.Hl = A.take<double>(W * N * 9);
+    V.bands = A.take<double>(W * N * 243); V.rhs = A.take<double>(W * N * 9);
+    V.Xs = A.take<double>(W * N * 81); V.zs = A.take<double>(W * N * 9); V.dpose = A.take<double>(W * N * 9);
+    V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
+    if (A.used > A.size) {
+        hipFree(A.base);
+        delete h;
+        return fail(VBA_ENOMEM, "internal: arena under-sized");
+    }
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_prm, sizeof(StepParams)) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_head, W * kHead) != hipSuccess) {
+        vba_destroy(h);
+        return fail(VBA_EHIP, "stream/event/pinned allocation failed");
+    }
+    h->stream = h->own_stream;
+    h->n.assign(W, 0); h->m.assign(W, 0);
+    h->have_obs.assign(W, 0); h->have_win.assign(W, 0); h->have_state.assign(W, 0);
+    h->perm.resize(W);
+    *out = h;
+    return VBA_OK;
+}
+
+int vba_destroy(vba_handle h) {
+    if (!h) return VBA_OK;
+    hipSetDevice(h->device);
+    if (h->own_stream) { hipStreamSynchronize(h->own_stream); hipStreamDestroy(h->own_stream); }
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->h_prm) hipHostFree(h->h_prm);
+    if (h->h_head) hipHostFree(h->h_head);
+    if (h->d_dbg) hipFree(h->d_dbg);
+    if (h->arena.base) hipFree(h->arena.base);
+    delete h;
+    return VBA_OK;
+}
+
+int vba_set_stream(vba_handle h, void* hip_stream) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    hipStreamSynchronize(h->stream);
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return VBA_OK;
+}
+
+int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const double* xyz, const double* uv,
+                            const double* conf, const int64_t* ii) {
+    if (int rc = check_window(h, window)) return rc;
+    if (!xyz || !uv || !conf || !ii) return fail(VBA_EINVAL, "null observation array");
+    if (n < 2 || n > h->n_max) return fail(VBA_EINVAL, "n out of range (need 2 <= n <= n_max)");
+    if (m < 1 || m > h->m_max) return fail(VBA_EINVAL, "m out of range (need 1 <= m <= m_max)");
+    if (h->have_win[window] && h->n[window] != n) return fail(VBA_EINVAL, "n differs from the uploaded pose constants");
+    HIPCHK(hipSetDevice(h->device));
+    // stable counting sort by pose: the reference's segment sums run in input order inside a pose
+    std::vector<int> ptr(n + 1, 0);
+    for (int64_t k = 0; k < m; ++k) {
+        if (ii[k] < 0 || ii[k] >= n) return fail(VBA_EINVAL, "ii[" + std::to_string(k) + "] outside [0, n)");
+        ptr[ii[k] + 1]++;
+    }
+    for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+    std::vector<int64_t>& perm = h->perm[window];
+    perm.assign(m, 0);
+    {
+        std::vector<int> cur(ptr.begin(), ptr.end() - 1);
+        for (int64_t k = 0; k < m; ++k) perm[cur[ii[k]]++] = k;
+    }
+    std::vector<double> buf(6 * (size_t)m);
+    std::vector<int> pose(m);
+    double *x = buf.data(), *y = x + m, *z = y + m, *u = z + m, *v = u + m, *c = v + m;
+    for (int64_t s = 0; s < m; ++s) {
+        const int64_t k = perm[s];
+        x[s] = xyz[3 * k]; y[s] = xyz[3 * k + 1]; z[s] = xyz[3 * k + 2];
+        u[s] = uv[2 * k]; v[s] = uv[2 * k + 1];
+        c[s] = conf[k];
+        pose[s] = (int)ii[k];
+    }
+    const size_t ob = (size_t)window * h->m_max;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_ox + ob, x, m * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_oy + ob, y, m * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_oz + ob, z, m * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_ou + ob, u, m * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_ov + ob, v, m * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_oconf + ob, c, m * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_opose + ob, pose.data(), m * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_pose_ptr + (size_t)window * (h->n_max + 1), ptr.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    const int mi = (int)m;
+    HIPCHK(hipMemcpy(h->d_m + window, &mi, 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_n + window, &n, 4, hipMemcpyHostToDevice));
+    h->n[window] = n;
+    h->m[window] = mi;
+    h->have_obs[window] = 1;
+    return VBA_OK;
+}
+
+int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics, const double* cumrot_last,
+                      const int64_t* time_idx) {
+    if (int rc = check_window(h, window)) return rc;
+    if (!intrinsics || !cumrot_last || !time_idx) return fail(VBA_EINVAL, "null pose-constant array");
+    if (n < 2 || n > h->n_max) return fail(VBA_EINVAL, "n out of range (need 2 <= n <= n_max)");
+    if (h->have_obs[window] && h->n[window] != n) return fail(VBA_EINVAL, "n differs from the uploaded observations");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<int> steps(n);
+    for (int i = 0; i + 1 < n; ++i) {
+        const int64_t d = time_idx[i + 1] - time_idx[i];
+        if (d < 1 || d > 100000000) return fail(VBA_EINVAL, "time_idx must be strictly increasing");
+        steps[i] = (int)d;
+    }
+    steps[n - 1] = 1;   // BA_utils.py:75
+    const size_t pb = (size_t)window * h->n_max;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->d_intr + pb * 4, intrinsics, (size_t)n * 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_cumrot + pb * 4, cumrot_last, (size_t)n * 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_steps + pb, steps.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_n + window, &n, 4, hipMemcpyHostToDevice));
+    h->n[window] = n;
+    h->have_win[window] = 1;
+    return VBA_OK;
+}
+
+int vba_set_states(vba_handle h, int window, const double* states, double lamda) {
+    if (int rc = check_window(h, window)) return rc;
+    if (!states) return fail(VBA_EINVAL, "null states");
+    if (!h->have_obs[window] && !h->have_win[window]) return fail(VBA_ESTATE, "upload the window before its states");
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->n[window];
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->V.states + (size_t)window * h->n_max * 10, states, (size_t)n * 80, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(&h->V.sc[window].lamda, &lamda, 8, hipMemcpyHostToDevice));
+    h->have_state[window] = 1;
+    return VBA_OK;
+}
+
+int vba_get_states(vba_handle h, int window, double* states, double* lamda, double* last_hessian, int* n_trials,
+                   unsigned* flags) {
+    if (int rc = check_window(h, window)) return rc;
+    if (!h->have_state[window]) return fail(VBA_ESTATE, "no states uploaded");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int n = h->n[window];
+    if (states) HIPCHK(hipMemcpy(states, h->V.states + (size_t)window * h->n_max * 10, (size_t)n * 80, hipMemcpyDeviceToHost));
+    WinScalars sc;
+    HIPCHK(hipMemcpy(&sc, h->V.sc + window, sizeof(sc), hipMemcpyDeviceToHost));
+    if (lamda) *lamda = sc.lamda;
+    if (last_hessian) std::memcpy(last_hessian, sc.last_hessian, 81 * 8);
+    if (n_trials) *n_trials = sc.n_trials;
+    if (flags) *flags = sc.flags;
+    return VBA_OK;
+}
+
+int vba_step(vba_handle h, int iter, int initialize) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc = ready(h)) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    DevView V = h->V;
+    V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
+    fill_params(*h->h_prm, iter, initialize);
+    HIPCHK(hipEventRecord(h->ev0, s));
+    HIPCHK(hipMemcpyAsync(h->d_prm, h->h_prm, sizeof(StepParams), hipMemcpyHostToDevice, s));
+    launch_step_begin(V, s);
+    launch_obs_residual(V, nullptr, s);
+    launch_select(V, s);
+    launch_obs_accumulate(V, s);
+    if (!initialize) launch_dynamics(V, s);
+    launch_assemble(V, s);
+    // LM loop (BA_filtering.py:52-77): lamda 1e-4 .. 1e4 in decades, at most 9 trials
+    for (int trial = 0; trial < 12; ++trial) {
+        launch_solve(V, s);
+        launch_trial(V, s);
+        launch_decide(V, nullptr, 0, s);
+        if (trial == 0) HIPCHK(hipEventRecord(h->ev1, s));
+        HIPCHK(hipGetLastError());
+        if (int rc = read_heads(h)) return rc;
+        bool all = true;
+        for (int w = 0; w < h->W; ++w) all = all && head(h, w)->done;
+        if (all) break;
+    }
+    HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    h->stepped = true;
+    h->last_iter = iter;
+    h->last_init = initialize;
+    return VBA_OK;
+}
+
+int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in, double* states_out,
+                double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags) {
+    if (int rc = vba_set_states(h, 0, states_in, lamda_in)) return rc;
+    if (int rc = vba_step(h, iter, initialize)) return rc;
+    return vba_get_states(h, 0, states_out, lamda_out, last_hessian, n_trials, flags);
+}
+
+int vba_last_step_ms(vba_handle h, float* ms) {
+    if (!h || !ms) return fail(VBA_EINVAL, "null argument");
+    if (!h->stepped) return fail(VBA_ESTATE, "no step has run");
+    *ms = h->last_ms;
+    return VBA_OK;
+}
+
+int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t capacity, int64_t* count) {
+    if (int rc = check_window(h, window)) return rc;
+    if (!out || !count) return fail(VBA_EINVAL, "null output");
+    if (!h->stepped) return fail(VBA_ESTATE, "no step has run");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int n = h->n[window];
+    const int64_t m = h->m[window];
+    const size_t pb = (size_t)window * h->n_max;
+    const DevView& V = h->V;
+    auto copy = [&](const double* src, int64_t cnt) -> int {
+        if (cnt > capacity) return fail(VBA_EINVAL, "debug buffer too small");
+        HIPCHK(hipMemcpy(out, src, cnt * 8, hipMemcpyDeviceToHost));
+        *count = cnt;
+        return VBA_OK;
+    };
+    WinScalars sc;
+    HIPCHK(hipMemcpy(&sc, V.sc + window, sizeof(sc), hipMemcpyDeviceToHost));
+    double wmax;
+    std::memcpy(&wmax, &sc.wmax_bits, 8);
+    switch (what) {
+        case VBA_DBG_EST:
+        case VBA_DBG_WEIGHT:
+        case VBA_DBG_JG: {
+            const int64_t per = what == VBA_DBG_EST ? 2 : (what == VBA_DBG_JG ? 12 : 1);
+            if (m * per > capacity) return fail(VBA_EINVAL, "debug buffer too small");
+            const size_t need = (size_t)m * 15 * 8;
+            if (h->dbg_cap < need) {
+                if (h->d_dbg) hipFree(h->d_dbg);
+                h->d_dbg = nullptr;
+                h->dbg_cap = 0;
+                HIPCHK(hipMalloc(&h->d_dbg, need));
+                h->dbg_cap = need;
+            }
+            double* est = h->d_dbg;
+            double* J = est + 2 * m;
+            double* wt = J + 12 * m;
+            launch_debug_project(V, window, (int)m, est, J, wt, h->stream);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->stream));
+            std::vector<double> tmp((size_t)m * per);
+            const double* src = what == VBA_DBG_EST ? est : (what == VBA_DBG_JG ? J : wt);
+            HIPCHK(hipMemcpy(tmp.data(), src, (size_t)m * per * 8, hipMemcpyDeviceToHost));
+            const std::vector<int64_t>& perm = h->perm[window];
+            for (int64_t s = 0; s < m; ++s) std::memcpy(out + perm[s] * per, tmp.data() + s * per, per * 8);
+            *count = m * per;
+            return VBA_OK;
+        }
+        case VBA_DBG_H: {
+            if ((int64_t)n * 36 > capacity) return fail(VBA_EINVAL, "debug buffer too small");
+            std::vector<double> tmp((size_t)n * 21);
+            HIPCHK(hipMemcpy(tmp.data(), V.Hraw + pb * 21, (size_t)n * 21 * 8, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i)
+                for (int a = 0; a < 6; ++a)
+                    for (int b = 0; b < 6; ++b) out[(size_t)i * 36 + a * 6 + b] = tmp[(size_t)i * 21 + sym6(a, b)] / wmax;
+            *count = (int64_t)n * 36;
+            return VBA_OK;
+        }
+        case VBA_DBG_B: {
+            if (int rc = copy(V.braw + pb * 6, (int64_t)n * 6)) return rc;
+            for (int64_t k = 0; k < (int64_t)n * 6; ++k) out[k] /= wmax;
+            return VBA_OK;
+        }
+        case VBA_DBG_PHI: return copy(V.Phi + pb * 36, (int64_t)n * 36);
+        case VBA_DBG_RPRED: {
+            if ((int64_t)(n - 1) * 7 > capacity) return fail(VBA_EINVAL, "debug buffer too small");
+            std::vector<double> ro((size_t)n * 6), fa(n);
+            HIPCHK(hipMemcpy(ro.data(), V.rorb + pb * 6, (size_t)n * 48, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(fa.data(), V.fatt + pb, (size_t)n * 8, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n - 1; ++i) {
+                for (int r = 0; r < 6; ++r) out[(size_t)i * 7 + r] = ro[(size_t)i * 6 + r];
+                out[(size_t)i * 7 + 6] = fa[i];
+            }
+            *count = (int64_t)(n - 1) * 7;
+            return VBA_OK;
+        }
+        case VBA_DBG_QGRAD: return copy(V.qgrad + pb * 3, (int64_t)n * 3);
+        case VBA_DBG_HQ: {
+            if ((int64_t)n * 27 > capacity) return fail(VBA_EINVAL, "debug buffer too small");
+            std::vector<double> d((size_t)n * 9), u((size_t)n * 9), l((size_t)n * 9);
+            HIPCHK(hipMemcpy(d.data(), V.Hd + pb * 9, (size_t)n * 72, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(u.data(), V.Hu + pb * 9, (size_t)n * 72, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(l.data(), V.Hl + pb * 9, (size_t)n * 72, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i)
+                for (int k = 0; k < 9; ++k) {
+                    out[(size_t)i * 27 + k] = l[(size_t)i * 9 + k];
+                    out[(size_t)i * 27 + 9 + k] = d[(size_t)i * 9 + k];
+                    out[(size_t)i * 27 + 18 + k] = u[(size_t)i * 9 + k];
+                }
+            *count = (int64_t)n * 27;
+            return VBA_OK;
+        }
+        case VBA_DBG_BANDS: return copy(V.bands + pb * 243, (int64_t)n * 243);
+        case VBA_DBG_RHS: return copy(V.rhs + pb * 9, (int64_t)n * 9);
+        case VBA_DBG_DPOSE: return copy(V.dpose + pb * 9, (int64_t)n * 9);
+        case VBA_DBG_SCALARS: {
+            if (capacity < 8) return fail(VBA_EINVAL, "debug buffer too small");
+            StepParams p;
+            fill_params(p, h->last_iter, h->last_init);
+            out[0] = sc.c_obs; out[1] = wmax; out[2] = sc.init_residual; out[3] = sc.trial_residual;
+            out[4] = sc.lam32; out[5] = p.sigma; out[6] = p.alpha; out[7] = (double)sc.n_trials;
+            *count = 8;
+            return VBA_OK;
+        }
+        default: return fail(VBA_EINVAL, "unknown debug selector");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sharded mode
+int64_t vba_sh_partial_count(int n) { return 27 * (int64_t)n + 2; }
+
+int vba_sh_stage1(vba_handle h, int iter, int initialize, double* d_abs_local) {
+    if (!h || !d_abs_local) return fail(VBA_EINVAL, "null argument");
+    if (h->W != 1) return fail(VBA_EINVAL, "sharded mode uses a single window per handle");
+    if (int rc = ready(h)) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    fill_params(*h->h_prm, iter, initialize);
+    HIPCHK(hipMemcpyAsync(h->d_prm, h->h_prm, sizeof(StepParams), hipMemcpyHostToDevice, s));
+    launch_step_begin(h->V, s);
+    launch_obs_residual(h->V, d_abs_local, s);
+    HIPCHK(hipGetLastError());
+    h->last_iter = iter;
+    h->last_init = initialize;
+    return VBA_OK;
+}
+
+int vba_sh_stage2(vba_handle h, const double* d_abs_all, int64_t count_all, double* d_partial_local) {
+    if (!h || !d_abs_all || !d_partial_local || count_all < 1) return fail(VBA_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    DevView V = h->V;
+    V.abs_all = d_abs_all;
+    V.abs_all_count = count_all;
+    launch_select(V, s);
+    launch_obs_accumulate(V, s);
+    launch_shard_pack(V, d_partial_local, s);
+    HIPCHK(hipGetLastError());
+    return VBA_OK;
+}
+
+int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, int64_t m_total, double* d_trial_local) {
+    if (!h || !d_trial_local || m_total < 1) return fail(VBA_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    h->V.m_total = m_total;
+    DevView V = h->V;
+    if (d_partial_all) {    // first trial of this call; NULL = another LM trial on the same system
+        if (ranks < 1) return fail(VBA_EINVAL, "ranks must be >= 1");
+        launch_shard_reduce(V, d_partial_all, ranks, s);
+        if (!h->last_init) launch_dynamics(V, s);
+        launch_assemble(V, s);
+    }
+    launch_solve(V, s);
+    launch_trial(V, s);
+    launch_shard_trial_sum(V, d_trial_local, s);
+    HIPCHK(hipGetLastError());
+    return VBA_OK;
+}
+
+int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done) {
+    if (!h || !d_trial_all || !done || ranks < 1) return fail(VBA_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    DevView V = h->V;
+    launch_decide(V, d_trial_all, ranks, h->stream);
+    HIPCHK(hipGetLastError());
+    if (int rc = read_heads(h)) return rc;
+    *done = head(h, 0)->done;
+    if (*done) { h->stepped = true; h->V.m_total = 0; }
+    return VBA_OK;
+}
+
+}  // extern "C"

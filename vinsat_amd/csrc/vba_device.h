@@ -1,0 +1,178 @@
+// vba_device.h -- device memory layout of a BA context and small wave/block primitives (gfx950, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vba_math.h"
+
+namespace vba {
+
+constexpr int kWave = 64;
+constexpr int kObsBlock = 256;          // threads per block of the per-observation kernels
+constexpr int kSelItems = 8;            // keys per thread per radix-select pass
+constexpr int kSelPasses = 6;           // 63 key bits = 10 + 11 + 11 + 11 + 11 + 9
+constexpr int kSelBins = 2048;
+constexpr int kPosesPerAccBlock = 4;    // one wave per pose in the accumulation kernel
+constexpr int kDynLanes = 8;            // lanes per pose in the dynamics kernel (6 tangents + attitude + spare)
+
+__host__ __device__ constexpr int sel_shift(int p) { return p == 0 ? 53 : p == 1 ? 42 : p == 2 ? 31 : p == 3 ? 20 : p == 4 ? 9 : 0; }
+__host__ __device__ constexpr int sel_width(int p) { return p == 0 ? 10 : p == 5 ? 9 : 11; }
+
+// Per-call constants (BA_filtering.py:22, 26); rewritten by the host before every step.
+struct StepParams {
+    double alpha, am2, expo;
+    double sigma, sqrt_sigma;
+    int alpha_is_2;
+    int initialize;
+    int iter;
+    int pad;
+};
+
+// Per-window scalars living in device memory.
+struct WinScalars {
+    double lamda;                   // LM damping carried between calls
+    double lam32;                   // float32-rounded damping of the last trial (BA_filtering.py:54)
+    double c_obs;                   // lower median of |r_obs|
+    unsigned long long wmax_bits;   // max raw weight, as ordered bits
+    double init_residual;
+    double trial_residual;
+    double sum_abs_robs;            // sum |r_obs| at the input states (sharded mode: local part)
+    double sum_abs_rpred;           // sqrt(sigma) * sum |r_pred|
+    int done;
+    int n_trials;
+    unsigned flags;
+    int pad;
+    unsigned long long sel_prefix[kSelPasses + 1];
+    long long sel_rank[kSelPasses + 1];
+    double last_hessian[81];
+};
+
+// Everything a kernel needs; passed by value.  Arrays of W windows use the *_max strides.
+struct DevView {
+    int W, n_max;
+    int64_t m_max;
+    int nblk_obs;                   // ceil(m_max / kObsBlock)
+    const int* n;                   // [W]
+    const int* m;                   // [W]
+    const StepParams* prm;
+    WinScalars* sc;                 // [W]
+    // observations, pose sorted, SoA [W][m_max]
+    const double *ox, *oy, *oz, *ou, *ov, *oconf;
+    const int* opose;
+    const int* pose_ptr;            // [W][n_max+1] CSR
+    // per pose [W][n_max][...]
+    double* states;                 // [10] current estimate (input of the step)
+    double* states_new;             // [10] last trial
+    double* states_prev;            // [10] copy of the step's input (debug)
+    const double* intr;             // [4]
+    const double* cumrot;           // [4]
+    const int* steps;               // RK4 steps to the next pose (last = 1)
+    // work
+    double* absr;                   // [W][2 m_max]  |r| components
+    double* wraw;                   // [W][m_max]    raw robust weight
+    double* part_init;              // [W][nblk_obs] block sums of |r_obs|
+    double* part_trial;             // [W][nblk_obs + nblk_dyn]
+    unsigned* hist;                 // [W][kSelPasses][kSelBins]
+    double* Hraw;                   // [21]
+    double* braw;                   // [6]
+    double* xhat;                   // [6]
+    double* Phi;                    // [36]
+    double* rorb;                   // [6]
+    double* fatt;                   // [1]
+    double* qgrad;                  // [3]
+    double* Hd;                     // [9]
+    double* Hu;                     // [9]
+    double* Hl;                     // [9]
+    double* bands;                  // [3][81]
+    double* rhs;                    // [9]
+    double* Xs;                     // [81]  D'^-1 U of the forward sweep
+    double* zs;                     // [9]
+    double* dpose;                  // [9]
+    int nblk_dyn;                   // ceil(n_max / kObsBlock)
+    // sharded mode: number of observation rows over all ranks (0 = not sharded) and external key buffer
+    int64_t m_total;
+    const double* abs_all;          // gathered |r| of all ranks or nullptr
+    int64_t abs_all_count;
+};
+
+// ------------------------------------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, kWave); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += shfl_xor_f64(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, shfl_xor_f64(v, o));
+    return v;
+}
+
+// fixed-order block sum (result valid in thread 0); BLOCK a multiple of 64, <= 1024
+template <int BLOCK>
+__device__ __forceinline__ double block_sum(double v, double* lds /*[BLOCK/64]*/) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) lds[wv] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < BLOCK / 64; ++i) t += lds[i];
+    }
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ unsigned long long f64_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ double bits_f64(unsigned long long b) { return __longlong_as_double((long long)b); }
+
+// Resolve one radix-select digit: given the histogram of digit p among keys matching the prefix and the
+// rank wanted inside that set, every thread of the block gets (new prefix, new rank).  256 threads.
+__device__ __forceinline__ void select_resolve(const unsigned* hist, int nbins, int width, unsigned long long prefix,
+                                               long long rank, unsigned long long& prefix_out, long long& rank_out,
+                                               unsigned* lds_u /*[260]*/) {
+    const int t = threadIdx.x;
+    const int per = nbins / 256 > 0 ? nbins / 256 : 1;      // bins per thread (8, 4 or 2)
+    unsigned loc[8];
+    unsigned s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned h = 0;
+        if (j < per && t * per + j < nbins) h = hist[t * per + j];
+        loc[j] = h;
+        s += h;
+    }
+    // inclusive scan over 256 threads: wave scan + 4 wave totals
+    unsigned inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned v = __shfl_up(inc, o, kWave);
+        if ((t & 63) >= o) inc += v;
+    }
+    if ((t & 63) == 63) lds_u[t >> 6] = inc;
+    if (t == 0) { lds_u[8] = 0; lds_u[9] = 0; }
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += lds_u[w];
+    const long long excl = (long long)base + inc - s;
+    if (rank >= excl && rank < excl + (long long)s) {
+        long long cum = excl;
+        int bin = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < per) {
+                if (rank >= cum && rank < cum + (long long)loc[j]) bin = t * per + j, lds_u[8] = (unsigned)(rank - cum), lds_u[9] = (unsigned)bin;
+                cum += loc[j];
+            }
+        }
+    }
+    __syncthreads();
+    rank_out = (long long)lds_u[8];
+    prefix_out = (prefix << width) | (unsigned long long)lds_u[9];
+    __syncthreads();
+}
+
+}  // namespace vba

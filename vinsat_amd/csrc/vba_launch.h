@@ -1,0 +1,30 @@
+// vba_launch.h -- host-side launchers of the kernels (one per .hip file), all asynchronous on `s`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vba_device.h"
+
+namespace vba {
+
+// vba_obs.hip
+void launch_step_begin(const DevView& V, hipStream_t s);
+void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s);
+void launch_select(const DevView& V, hipStream_t s);
+void launch_obs_accumulate(const DevView& V, hipStream_t s);
+void launch_trial(const DevView& V, hipStream_t s);
+void launch_debug_project(const DevView& V, int w, int m, double* est, double* J, double* wt, hipStream_t s);
+
+// vba_dyn.hip
+void launch_dynamics(const DevView& V, hipStream_t s);
+void launch_assemble(const DevView& V, hipStream_t s);
+
+// vba_solve.hip
+void launch_solve(const DevView& V, hipStream_t s);
+void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStream_t s);
+
+// vba_shard.hip
+void launch_shard_pack(const DevView& V, double* partial_out, hipStream_t s);
+void launch_shard_reduce(const DevView& V, const double* partial_all, int ranks, hipStream_t s);
+void launch_shard_trial_sum(const DevView& V, double* trial_local, hipStream_t s);
+
+}  // namespace vba

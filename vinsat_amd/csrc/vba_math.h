@@ -1,0 +1,340 @@
+// vba_math.h -- per-observation / per-pose arithmetic of the BA iteration, fp64.
+//
+// Pure functions shared by the HIP kernels.  They compile for the host as well (plain C++), which the
+// test-suite uses to check the formulas on a machine without a GPU; the product never runs them there.
+//
+// Reference formulas: estimation/BA/BA_utils.py (cited per function).  The reference differentiates with
+// autograd; the closed forms here were checked against its output.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define VBA_HD __host__ __device__ __forceinline__
+#else
+#define VBA_HD inline
+#endif
+
+namespace vba {
+
+constexpr double kMu = 398600.4418;    // BA_utils.py:883
+constexpr double kJ2c = 1.75553e10;    // BA_utils.py:883
+constexpr double kZMin = 0.1;          // BA_utils.py:13
+constexpr double kQuatCoeff = 100.0;   // BA_filtering.py:11
+constexpr double kVelCoeff = 100.0;    // BA_filtering.py:12
+
+// index of (a,b), a<=b, in the packed upper triangle of a symmetric 6x6
+VBA_HD int sym6(int a, int b) {
+    if (a > b) { int t = a; a = b; b = t; }
+    return a * 6 - (a * (a - 1)) / 2 + (b - a);
+}
+
+// ------------------------------------------------------------------------------------------------ pose
+struct PoseCam {
+    double t[3];    // position
+    double R[9];    // camera->ECI rotation of the normalised quaternion, row major
+    double fx, fy, cx, cy;
+};
+
+// R(q/|q|); BA_utils.py:1058 normalises before rotating.
+VBA_HD void pose_camera(const double* s /*[10]*/, const double* K /*[4]*/, PoseCam& pc) {
+    pc.t[0] = s[0]; pc.t[1] = s[1]; pc.t[2] = s[2];
+    double x = s[3], y = s[4], z = s[5], w = s[6];
+    const double nrm = sqrt(x * x + y * y + z * z + w * w);
+    x /= nrm; y /= nrm; z /= nrm; w /= nrm;
+    pc.R[0] = 1 - 2 * (y * y + z * z); pc.R[1] = 2 * (x * y - z * w);     pc.R[2] = 2 * (x * z + y * w);
+    pc.R[3] = 2 * (x * y + z * w);     pc.R[4] = 1 - 2 * (x * x + z * z); pc.R[5] = 2 * (y * z - x * w);
+    pc.R[6] = 2 * (x * z - y * w);     pc.R[7] = 2 * (y * z + x * w);     pc.R[8] = 1 - 2 * (x * x + y * y);
+    pc.fx = K[0]; pc.fy = K[1]; pc.cx = K[2]; pc.cy = K[3];
+}
+
+// Reprojection (BA_utils.py:30-43, 1052-1069, 7-17): p_c = R^T (X - t), u = fx x/z + cx, z clamped at 0.1.
+VBA_HD void project(const PoseCam& pc, double X, double Y, double Z, double& u, double& v, double* cam /*[3]*/,
+                    double& d) {
+    const double dx = X - pc.t[0], dy = Y - pc.t[1], dz = Z - pc.t[2];
+    cam[0] = pc.R[0] * dx + pc.R[3] * dy + pc.R[6] * dz;
+    cam[1] = pc.R[1] * dx + pc.R[4] * dy + pc.R[7] * dz;
+    cam[2] = pc.R[2] * dx + pc.R[5] * dy + pc.R[8] * dz;
+    const double zc = cam[2] > kZMin ? cam[2] : kZMin;
+    d = 1.0 / zc;
+    u = pc.fx * (d * cam[0]) + pc.cx;
+    v = pc.fy * (d * cam[1]) + pc.cy;
+}
+
+// 2x6 Jacobian of (u,v) w.r.t. [dp, dtheta] (BA_utils.py:44-48): [-Jpi R^T | 2 Jpi hat(p_c)], with the
+// z-derivative switched off below the clamp.  J row major [2][6].
+VBA_HD void project_jacobian(const PoseCam& pc, const double* cam, double d, double* J) {
+    const double live = cam[2] > kZMin ? 1.0 : 0.0;
+    const double a00 = pc.fx * d, a02 = -pc.fx * cam[0] * d * d * live;
+    const double a11 = pc.fy * d, a12 = -pc.fy * cam[1] * d * d * live;
+    for (int c = 0; c < 3; ++c) {   // -Jpi R^T : column c uses row c of R
+        J[c] = -(a00 * pc.R[3 * c + 0] + a02 * pc.R[3 * c + 2]);
+        J[6 + c] = -(a11 * pc.R[3 * c + 1] + a12 * pc.R[3 * c + 2]);
+    }
+    const double x = cam[0], y = cam[1], z = cam[2];
+    J[3] = 2.0 * (-a02 * y);
+    J[4] = 2.0 * (-a00 * z + a02 * x);
+    J[5] = 2.0 * (a00 * y);
+    J[9] = 2.0 * (a11 * z - a12 * y);
+    J[10] = 2.0 * (a12 * x);
+    J[11] = 2.0 * (-a11 * x);
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+struct RobustParams {
+    double c;           // lower median of |r| (BA_filtering.py:23)
+    double inv_c2;      // 1/c^2
+    double am2;         // |alpha-2|
+    double expo;        // alpha/2 - 1
+    int alpha_is_2;     // alpha == 2: ((r/c)^2/0 + 1)^0 == 1 by IEEE inf**0 / nan**0 (BA_filtering.py:24)
+};
+
+// mean over the two pixel components of the Barron-style weight (BA_filtering.py:24), before /max and *conf
+VBA_HD double robust_weight_raw(const RobustParams& rp, double ru, double rv) {
+    if (rp.alpha_is_2) return rp.inv_c2;
+    const double su = ru / rp.c, sv = rv / rp.c;
+    const double wu = pow(su * su / rp.am2 + 1.0, rp.expo) * rp.inv_c2;
+    const double wv = pow(sv * sv / rp.am2 + 1.0, rp.expo) * rp.inv_c2;
+    return (wu + wv) * 0.5;
+}
+
+// ------------------------------------------------------------------------------------------------ orbit
+// J2 two-body acceleration (BA_utils.py:883-899) and its directional derivative along tp.
+VBA_HD void accel_jvp(const double* p, const double* tp, double* a, double* da, bool with_tangent) {
+    const double px2 = p[0] * p[0], py2 = p[1] * p[1], pz2 = p[2] * p[2];
+    const double r2 = px2 + py2 + pz2;
+    const double r = sqrt(r2);
+    const double r3 = r * r * r;
+    const double r7 = r3 * r3 * r;
+    const double k3 = kMu / r3;
+    const double k7 = kJ2c / r7;
+    const double u0 = 6.0 * px2 - 1.5 * py2 - 1.5 * pz2;
+    const double u2 = 3.0 * px2 - 4.5 * py2 - 4.5 * pz2;
+    a[0] = -k3 * p[0] + k7 * u0 * p[0];
+    a[1] = -k3 * p[1] + k7 * u0 * p[1];
+    a[2] = -k3 * p[2] + k7 * u2 * p[2];
+    if (!with_tangent) return;
+    const double pt = p[0] * tp[0] + p[1] * tp[1] + p[2] * tp[2];
+    const double ir2 = 1.0 / r2;
+    const double du0 = 2.0 * (6.0 * p[0] * tp[0] - 1.5 * p[1] * tp[1] - 1.5 * p[2] * tp[2]);
+    const double du2 = 2.0 * (3.0 * p[0] * tp[0] - 4.5 * p[1] * tp[1] - 4.5 * p[2] * tp[2]);
+    const double c3 = 3.0 * k3 * ir2 * pt;      // 3 mu (p.t)/r^5
+    const double c9 = 7.0 * k7 * ir2 * pt;      // 7 J2 (p.t)/r^9
+    da[0] = -k3 * tp[0] + c3 * p[0] - c9 * u0 * p[0] + k7 * (du0 * p[0] + u0 * tp[0]);
+    da[1] = -k3 * tp[1] + c3 * p[1] - c9 * u0 * p[1] + k7 * (du0 * p[1] + u0 * tp[1]);
+    da[2] = -k3 * tp[2] + c3 * p[2] - c9 * u2 * p[2] + k7 * (du2 * p[2] + u2 * tp[2]);
+}
+
+// One RK4 step (h = 1 s) of x = [p, v] and, optionally, of one tangent vector t (forward mode); this is
+// RK4 at BA_utils.py:901-912 and, chained over the gap, propagate_orbit_dynamics :73-87.
+template <bool TANGENT>
+VBA_HD void rk4_step(double* x /*[6]*/, double* t /*[6]*/) {
+    const double h = 1.0;
+    double k1[6], k2[6], k3[6], k4[6], d1[6], d2[6], d3[6], d4[6], xs[6], ts[6];
+    for (int i = 0; i < 3; ++i) { k1[i] = x[3 + i]; if (TANGENT) d1[i] = t[3 + i]; }
+    accel_jvp(x, t, k1 + 3, d1 + 3, TANGENT);
+    for (int i = 0; i < 6; ++i) { xs[i] = x[i] + 0.5 * h * k1[i]; if (TANGENT) ts[i] = t[i] + 0.5 * h * d1[i]; }
+    for (int i = 0; i < 3; ++i) { k2[i] = xs[3 + i]; if (TANGENT) d2[i] = ts[3 + i]; }
+    accel_jvp(xs, ts, k2 + 3, d2 + 3, TANGENT);
+    for (int i = 0; i < 6; ++i) { xs[i] = x[i] + 0.5 * h * k2[i]; if (TANGENT) ts[i] = t[i] + 0.5 * h * d2[i]; }
+    for (int i = 0; i < 3; ++i) { k3[i] = xs[3 + i]; if (TANGENT) d3[i] = ts[3 + i]; }
+    accel_jvp(xs, ts, k3 + 3, d3 + 3, TANGENT);
+    for (int i = 0; i < 6; ++i) { xs[i] = x[i] + h * k3[i]; if (TANGENT) ts[i] = t[i] + h * d3[i]; }
+    for (int i = 0; i < 3; ++i) { k4[i] = xs[3 + i]; if (TANGENT) d4[i] = ts[3 + i]; }
+    accel_jvp(xs, ts, k4 + 3, d4 + 3, TANGENT);
+    for (int i = 0; i < 6; ++i) {
+        x[i] = x[i] + (h / 6.0) * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        if (TANGENT) t[i] = t[i] + (h / 6.0) * (d1[i] + 2 * d2[i] + 2 * d3[i] + d4[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ attitude
+VBA_HD void quat_mul(const double* a, const double* b, double* o) {   // BA_utils.py:992-1000
+    const double x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3];
+    const double x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
+    o[0] = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
+    o[1] = w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2;
+    o[2] = w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2;
+    o[3] = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
+}
+
+// G(q) [4][3] (BA_utils.py:19-28)
+VBA_HD void attitude_jac(const double* q, double* G) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    G[0] = w;  G[1] = -z; G[2] = y;
+    G[3] = z;  G[4] = w;  G[5] = -x;
+    G[6] = -y; G[7] = x;  G[8] = w;
+    G[9] = -x; G[10] = -y; G[11] = -z;
+}
+
+// o = R_m(c) q = q (x) c ;  oT = R_m(c)^T q
+VBA_HD void rm_apply(const double* c, const double* q, double* o) { quat_mul(q, c, o); }
+VBA_HD void rmT_apply(const double* c, const double* q, double* o) {
+    // R_m(c)^T = R_m(conj c) for unit-agnostic bilinear form: q (x) conj(c)
+    const double cc[4] = {-c[0], -c[1], -c[2], c[3]};
+    quat_mul(q, cc, o);
+}
+
+// Attitude dynamics term of pose i (BA_utils.py:481-487, 494-500, 519-523; closed form SURVEY appendix A.3).
+// q_prev/c_prev may be null at i == 0, q_next null at i == n-1.  Outputs:
+//   f      = 100 (1 - |<q_i (x) c_i, q_{i+1}>|)                       (valid when q_next)
+//   qgrad  [3]   = G(q_i)^T grad_{q_i} sum f
+//   Hd [9] = block (i,i); Hu [9] = block (i,i+1) (valid when q_next); Hl [9] = block (i,i-1) (valid when q_prev)
+VBA_HD void attitude_term(const double* q_prev, const double* c_prev, const double* q, const double* c,
+                          const double* q_next, double& f, double* qgrad, double* Hd, double* Hu, double* Hl) {
+    double G[12];
+    attitude_jac(q, G);
+    double g[4] = {0, 0, 0, 0};
+    f = 0.0;
+    for (int k = 0; k < 9; ++k) { Hu[k] = 0.0; Hl[k] = 0.0; }
+    if (q_next) {
+        double qp[4];
+        quat_mul(q, c, qp);
+        const double d = qp[0] * q_next[0] + qp[1] * q_next[1] + qp[2] * q_next[2] + qp[3] * q_next[3];
+        const double s = d > 0 ? 1.0 : (d < 0 ? -1.0 : 0.0);
+        f = kQuatCoeff * (1.0 - fabs(d));
+        double t4[4];
+        rmT_apply(c, q_next, t4);               // R_m(c_i)^T q_{i+1}
+        for (int k = 0; k < 4; ++k) g[k] += -kQuatCoeff * s * t4[k];
+        // Hu = G(q_i)^T (-kappa s R_m(c_i)^T) G(q_{i+1})
+        double Gn[12];
+        attitude_jac(q_next, Gn);
+        for (int b = 0; b < 3; ++b) {
+            const double col[4] = {Gn[b], Gn[3 + b], Gn[6 + b], Gn[9 + b]};
+            double rc[4];
+            rmT_apply(c, col, rc);
+            for (int a = 0; a < 3; ++a)
+                Hu[3 * a + b] = -kQuatCoeff * s * (G[a] * rc[0] + G[3 + a] * rc[1] + G[6 + a] * rc[2] + G[9 + a] * rc[3]);
+        }
+    }
+    if (q_prev) {
+        double qp[4];
+        quat_mul(q_prev, c_prev, qp);           // R_m(c_{i-1}) q_{i-1}
+        const double d = qp[0] * q[0] + qp[1] * q[1] + qp[2] * q[2] + qp[3] * q[3];
+        const double s = d > 0 ? 1.0 : (d < 0 ? -1.0 : 0.0);
+        for (int k = 0; k < 4; ++k) g[k] += -kQuatCoeff * s * qp[k];
+        double Gp[12];
+        attitude_jac(q_prev, Gp);
+        for (int b = 0; b < 3; ++b) {
+            const double col[4] = {Gp[b], Gp[3 + b], Gp[6 + b], Gp[9 + b]};
+            double rc[4];
+            rm_apply(c_prev, col, rc);
+            for (int a = 0; a < 3; ++a)
+                Hl[3 * a + b] = -kQuatCoeff * s * (G[a] * rc[0] + G[3 + a] * rc[1] + G[6 + a] * rc[2] + G[9 + a] * rc[3]);
+        }
+    }
+    for (int a = 0; a < 3; ++a) qgrad[a] = G[a] * g[0] + G[3 + a] * g[1] + G[6 + a] * g[2] + G[9 + a] * g[3];
+    // Hd = B(g) G, B[a][c] = sum_k dG[k][a]/dq[c] g[k]
+    const double B[12] = {-g[3], -g[2], g[1], g[0],
+                          g[2], -g[3], -g[0], g[1],
+                          -g[1], g[0], -g[3], g[2]};
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            Hd[3 * a + b] = B[4 * a + 0] * G[b] + B[4 * a + 1] * G[3 + b] + B[4 * a + 2] * G[6 + b] + B[4 * a + 3] * G[9 + b];
+}
+
+// residual-only variant
+VBA_HD double attitude_residual(const double* q, const double* c, const double* q_next) {
+    double qp[4];
+    quat_mul(q, c, qp);
+    const double d = qp[0] * q_next[0] + qp[1] * q_next[1] + qp[2] * q_next[2] + qp[3] * q_next[3];
+    return kQuatCoeff * (1.0 - fabs(d));
+}
+
+// ------------------------------------------------------------------------------------------------ retraction
+// BA_filtering.py:56-60 with quaternion_exp (BA_utils.py:970-985).
+VBA_HD void retract(const double* s, const double* dp /*[9]*/, double* o /*[10]*/) {
+    o[0] = s[0] + dp[0]; o[1] = s[1] + dp[1]; o[2] = s[2] + dp[2];
+    const double th = sqrt(dp[3] * dp[3] + dp[4] * dp[4] + dp[5] * dp[5]);
+    double e[4];
+    if (th < 1e-16) {
+        e[0] = e[1] = e[2] = 0.0; e[3] = 1.0;
+    } else {
+        const double sc = sin(th / 2) / (th + 1e-16);
+        e[0] = dp[3] * sc; e[1] = dp[4] * sc; e[2] = dp[5] * sc; e[3] = cos(th / 2);
+    }
+    double r[4];
+    quat_mul(s + 3, e, r);
+    const double nrm = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    o[3] = r[0] / nrm; o[4] = r[1] / nrm; o[5] = r[2] / nrm; o[6] = r[3] / nrm;
+    o[7] = s[7] + dp[6]; o[8] = s[8] + dp[7]; o[9] = s[9] + dp[8];
+}
+
+// ------------------------------------------------------------------------------------------------ assembly
+// Inputs of one pose row of the block-tridiagonal system (BA_filtering.py:40-48, 54).
+struct AsmRow {
+    const double* Hraw;       // [21] packed sum (w_raw conf) J^T J of pose i
+    const double* braw;       // [6]
+    double inv_wmax;          // 1 / max raw weight
+    double sigma;             // 0 in the landmark-only phase
+    const double* Phi_i;      // [36] row major, pose i      (null if i == n-1 or sigma == 0)
+    const double* Phi_im1;    // [36] pose i-1               (null if i == 0 or sigma == 0)
+    const double* rorb_i;     // [6]  D (x_hat_i - x_{i+1})  (null if i == n-1)
+    const double* rorb_im1;   // [6]                         (null if i == 0)
+    const double* qgrad;      // [3]
+    const double* Hd;         // [9]
+    const double* Hu;         // [9]
+    const double* Hl;         // [9]
+};
+
+// column c (0..8) of E_i = D Phi_i laid out over [dp, dtheta, dv]: rows r = 0..5; rotation columns are 0.
+VBA_HD double E_entry(const double* Phi, int r, int c) {
+    if (c >= 3 && c < 6) return 0.0;
+    const int pc = c < 3 ? c : c - 3;
+    const double D = r < 3 ? 1.0 : kVelCoeff;
+    return D * Phi[6 * r + pc];
+}
+// F = -D selects position / velocity: column c has a single non-zero at row frow(c)
+VBA_HD int F_row(int c) { return c < 3 ? c : (c >= 6 ? c - 3 : -1); }
+VBA_HD double F_val(int c) { return c < 3 ? -1.0 : -kVelCoeff; }
+
+// entry (a,b) of band `which` (0 sub (i,i-1), 1 diag, 2 super (i,i+1)) of pose row i, no damping.
+VBA_HD double band_entry(const AsmRow& R, int which, int a, int b) {
+    double v = 0.0;
+    const bool rot = (a >= 3 && a < 6 && b >= 3 && b < 6);
+    if (which == 1) {
+        if (a < 6 && b < 6) v = R.Hraw[sym6(a, b)] * R.inv_wmax;
+        if (R.sigma != 0.0) {
+            if (R.Phi_i) {
+                double s = 0.0;
+                for (int r = 0; r < 6; ++r) s += (E_entry(R.Phi_i, r, a) * R.sigma) * E_entry(R.Phi_i, r, b);
+                v += s;
+            }
+            if (R.Phi_im1 && a == b && F_row(a) >= 0) v += (F_val(a) * R.sigma) * F_val(a);
+            if (rot) v += R.sigma * R.Hd[3 * (a - 3) + (b - 3)];
+        }
+    } else if (R.sigma != 0.0) {
+        if (which == 2 && R.Phi_i) {
+            const int r = F_row(b);
+            if (r >= 0) v += (E_entry(R.Phi_i, r, a) * R.sigma) * F_val(b);
+            if (rot) v += R.sigma * R.Hu[3 * (a - 3) + (b - 3)];
+        }
+        if (which == 0 && R.Phi_im1) {
+            const int r = F_row(a);
+            if (r >= 0) v += (F_val(a) * R.sigma) * E_entry(R.Phi_im1, r, b);
+            if (rot) v += R.sigma * R.Hl[3 * (a - 3) + (b - 3)];
+        }
+    }
+    return v;
+}
+
+VBA_HD double rhs_entry(const AsmRow& R, int a) {
+    double v = 0.0;
+    if (a < 6) v = R.braw[a] * R.inv_wmax;
+    if (R.sigma != 0.0) {
+        if (R.Phi_i) {
+            double s = 0.0;
+            for (int r = 0; r < 6; ++r) s += (E_entry(R.Phi_i, r, a) * R.sigma) * R.rorb_i[r];
+            v -= s;
+        }
+        if (R.Phi_im1) {
+            const int r = F_row(a);
+            if (r >= 0) v -= (F_val(a) * R.sigma) * R.rorb_im1[r];
+        }
+        if (a >= 3 && a < 6) v -= R.sigma * R.qgrad[a - 3];
+    }
+    return v;
+}
+
+}  // namespace vba

@@ -1,0 +1,268 @@
+// vba_obs.hip -- observation-indexed kernels of the BA iteration (gfx950).
+//
+//   k_step_begin       reset per-step state
+//   k_obs_residual     A1: reprojection residuals at the input states, |r| keys, sum |r|
+//   k_select_pass<P>   A3a: exact lower median of the 2m keys by most-significant-digit radix select
+//   k_obs_accumulate   A2 + A3a + A3b: Jacobian, robust weight, per-pose 6x6 / 6 accumulation (one wave per pose)
+//   k_trial            A8: weighted trial residuals (observations) and dynamics residuals at the trial states
+//   k_debug_project    recompute est / Jacobian at the step's input states for vba_debug_fetch
+//
+// All of these stream the observation arrays once, coalesced (SoA, 8 B per lane per array); the pose state
+// is gathered through L1/L2 (observations are pose sorted, so a wave touches one or two poses).
+#include "vba_device.h"
+#include "vba_launch.h"
+
+namespace vba {
+
+__global__ __launch_bounds__(256) void k_step_begin(DevView V) {
+    const int w = blockIdx.x;
+    const int n = V.n[w];
+    unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
+    for (int b = threadIdx.x; b < kSelPasses * kSelBins; b += 256) hist[b] = 0u;
+    double* sp = V.states_prev + (size_t)w * V.n_max * 10;
+    const double* s = V.states + (size_t)w * V.n_max * 10;
+    for (int k = threadIdx.x; k < n * 10; k += 256) sp[k] = s[k];
+    if (threadIdx.x == 0) {
+        WinScalars& sc = V.sc[w];
+        sc.done = 0;
+        sc.n_trials = 0;
+        sc.flags = 0u;
+        sc.wmax_bits = 0ull;
+        sc.sum_abs_rpred = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- A1
+__global__ __launch_bounds__(kObsBlock) void k_obs_residual(DevView V, double* abs_out /*null: V.absr*/) {
+    __shared__ double red[kObsBlock / 64];
+    const int w = blockIdx.y;
+    const int m = V.m[w];
+    const size_t ob = (size_t)w * V.m_max;
+    const int k = blockIdx.x * kObsBlock + threadIdx.x;
+    double s = 0.0;
+    if (k < m) {
+        const int pose = V.opose[ob + k];
+        const size_t pb = (size_t)w * V.n_max + pose;
+        PoseCam pc;
+        pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
+        double u, v, cam[3], d;
+        project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
+        const double ru = fabs(V.ou[ob + k] - u), rv = fabs(V.ov[ob + k] - v);
+        double* ab = abs_out ? abs_out : V.absr + 2 * ob;
+        reinterpret_cast<double2*>(ab)[k] = make_double2(ru, rv);
+        s = ru + rv;
+    }
+    const double t = block_sum<kObsBlock>(s, red);
+    if (threadIdx.x == 0) V.part_init[(size_t)w * V.nblk_obs + blockIdx.x] = t;
+}
+
+// ---------------------------------------------------------------------------------------------- A3a: select
+template <int P>
+__global__ __launch_bounds__(256) void k_select_pass(DevView V) {
+    __shared__ unsigned lh[kSelBins];
+    __shared__ unsigned lds_u[260];
+    const int w = blockIdx.y;
+    const double* keys = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
+    const int64_t count = V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w];
+    if ((int64_t)blockIdx.x * 256 * kSelItems >= count) return;
+    unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
+    constexpr int nbins = 1 << sel_width(P);
+    for (int b = threadIdx.x; b < nbins; b += 256) lh[b] = 0u;
+    unsigned long long prefix = 0ull;
+    long long rank = (count - 1) / 2;           // torch.median = lower median (BA_filtering.py:23)
+    if (P > 0) {
+        constexpr int Q = P > 0 ? P - 1 : 0;
+        select_resolve(hist + Q * kSelBins, 1 << sel_width(Q), sel_width(Q), V.sc[w].sel_prefix[Q], V.sc[w].sel_rank[Q],
+                       prefix, rank, lds_u);
+    } else {
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        V.sc[w].sel_prefix[P] = prefix;
+        V.sc[w].sel_rank[P] = rank;
+    }
+#pragma unroll
+    for (int it = 0; it < kSelItems; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * kSelItems + it) * 256 + threadIdx.x;
+        if (idx < count) {
+            const unsigned long long key = f64_bits(keys[idx]);
+            bool match = true;
+            if (P > 0) match = (key >> sel_shift(P > 0 ? P - 1 : 0)) == prefix;
+            if (match) atomicAdd(&lh[(unsigned)(key >> sel_shift(P)) & (nbins - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256) {
+        const unsigned c = lh[b];
+        if (c) atomicAdd(&hist[P * kSelBins + b], c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- A2 + A3
+// One wave per pose: lanes stride over the pose's observation segment, accumulate the 21 + 6 unique entries of
+// sum(w J^T J), sum(w J^T r) in registers, then a fixed-shape xor butterfly gives every lane the totals
+// (bit-reproducible: no float atomics).  The raw (un-normalised) weight is kept per observation for the trials.
+__global__ __launch_bounds__(64 * kPosesPerAccBlock) void k_obs_accumulate(DevView V) {
+    __shared__ unsigned lds_u[260];
+    __shared__ double wmx[kPosesPerAccBlock];
+    const int w = blockIdx.y;
+    const int n = V.n[w];
+    if (blockIdx.x * kPosesPerAccBlock >= n) return;
+    WinScalars& sc = V.sc[w];
+    unsigned long long keybits;
+    long long rk;
+    select_resolve(V.hist + ((size_t)w * kSelPasses + 5) * kSelBins, 1 << sel_width(5), sel_width(5), sc.sel_prefix[5],
+                   sc.sel_rank[5], keybits, rk, lds_u);
+    const StepParams prm = *V.prm;
+    RobustParams rp;
+    rp.c = bits_f64(keybits);
+    rp.inv_c2 = 1.0 / (rp.c * rp.c);
+    rp.am2 = prm.am2;
+    rp.expo = prm.expo;
+    rp.alpha_is_2 = prm.alpha_is_2;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc.c_obs = rp.c;
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * kPosesPerAccBlock + wv;
+    double wmax_l = 0.0;
+    if (i < n) {
+        const size_t pb = (size_t)w * V.n_max + i;
+        const size_t ob = (size_t)w * V.m_max;
+        PoseCam pc;
+        pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
+        const int* ptr = V.pose_ptr + (size_t)w * (V.n_max + 1);
+        const int beg = ptr[i], end = ptr[i + 1];
+        double acc[27];
+#pragma unroll
+        for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+        for (int k = beg + lane; k < end; k += 64) {
+            double u, v, cam[3], d, J[12];
+            project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
+            project_jacobian(pc, cam, d, J);
+            const double ru = V.ou[ob + k] - u, rv = V.ov[ob + k] - v;
+            const double wr = robust_weight_raw(rp, ru, rv);
+            V.wraw[ob + k] = wr;
+            wmax_l = fmax(wmax_l, wr);
+            const double wc = wr * V.oconf[ob + k];
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const double ja = wc * J[a], jb = wc * J[6 + a];
+#pragma unroll
+                for (int b = a; b < 6; ++b) { acc[q] += ja * J[b] + jb * J[6 + b]; ++q; }
+                acc[21 + a] += ja * ru + jb * rv;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 27; ++q) acc[q] = wave_sum(acc[q]);
+        wmax_l = wave_max(wmax_l);
+        double* H = V.Hraw + pb * 21;
+        double* B = V.braw + pb * 6;
+#pragma unroll
+        for (int q = 0; q < 21; ++q) if (lane == q) H[q] = acc[q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) if (lane == 21 + q) B[q] = acc[21 + q];
+    }
+    if (lane == 0) wmx[wv] = wmax_l;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double mx = 0.0;
+        for (int q = 0; q < kPosesPerAccBlock; ++q) mx = fmax(mx, wmx[q]);
+        atomicMax(&sc.wmax_bits, f64_bits(mx));     // positive doubles order like their bit patterns
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- A8: trial residuals
+// blocks [0, nblk_obs): sum |w (uv - est')| over the observations (BA_filtering.py:61, 66);
+// blocks [nblk_obs, nblk_obs + nblk_dyn): sqrt(sigma) sum |r_pred'| over the pose edges (BA_filtering.py:65, 67).
+__global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
+    __shared__ double red[kObsBlock / 64];
+    const int w = blockIdx.y;
+    const WinScalars& sc = V.sc[w];
+    if (sc.done) return;
+    const int n = V.n[w], m = V.m[w];
+    const StepParams prm = *V.prm;
+    double s = 0.0;
+    const size_t sb = (size_t)w * V.n_max;
+    if ((int)blockIdx.x < V.nblk_obs) {
+        const int k = blockIdx.x * kObsBlock + threadIdx.x;
+        if (k < m) {
+            const size_t ob = (size_t)w * V.m_max;
+            const int pose = V.opose[ob + k];
+            PoseCam pc;
+            pose_camera(V.states_new + (sb + pose) * 10, V.intr + (sb + pose) * 4, pc);
+            double u, v, cam[3], d;
+            project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
+            const double wk = (V.wraw[ob + k] / bits_f64(sc.wmax_bits)) * V.oconf[ob + k];
+            s = fabs((V.ou[ob + k] - u) * wk) + fabs((V.ov[ob + k] - v) * wk);
+        }
+    } else {
+        const int db = blockIdx.x - V.nblk_obs;
+        const int i = db * kObsBlock + threadIdx.x;
+        if (!prm.initialize && i < n - 1) {
+            const double* st = V.states_new + (sb + i) * 10;
+            const double* sn = st + 10;
+            double x[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
+            const int steps = V.steps[sb + i];
+            for (int q = 0; q < steps; ++q) rk4_step<false>(x, nullptr);
+            s = fabs(x[0] - sn[0]) + fabs(x[1] - sn[1]) + fabs(x[2] - sn[2]) +
+                fabs((x[3] - sn[7]) * kVelCoeff) + fabs((x[4] - sn[8]) * kVelCoeff) + fabs((x[5] - sn[9]) * kVelCoeff);
+            s += fabs(attitude_residual(st + 3, V.cumrot + (sb + i) * 4, sn + 3));
+            s *= prm.sqrt_sigma;
+        }
+    }
+    const double t = block_sum<kObsBlock>(s, red);
+    if (threadIdx.x == 0) V.part_trial[(size_t)w * (V.nblk_obs + V.nblk_dyn) + blockIdx.x] = t;
+}
+
+// ---------------------------------------------------------------------------------------------- debug
+__global__ __launch_bounds__(kObsBlock) void k_debug_project(DevView V, int w, double* est, double* J, double* wt) {
+    const int m = V.m[w];
+    const int k = blockIdx.x * kObsBlock + threadIdx.x;
+    if (k >= m) return;
+    const size_t ob = (size_t)w * V.m_max;
+    const int pose = V.opose[ob + k];
+    const size_t pb = (size_t)w * V.n_max + pose;
+    PoseCam pc;
+    pose_camera(V.states_prev + pb * 10, V.intr + pb * 4, pc);
+    double u, v, cam[3], d;
+    project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
+    est[2 * k] = u;
+    est[2 * k + 1] = v;
+    project_jacobian(pc, cam, d, J + 12 * (size_t)k);
+    wt[k] = (V.wraw[ob + k] / bits_f64(V.sc[w].wmax_bits)) * V.oconf[ob + k];
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+void launch_step_begin(const DevView& V, hipStream_t s) { hipLaunchKernelGGL(k_step_begin, dim3(V.W), dim3(256), 0, s, V); }
+
+void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_obs_residual, dim3(V.nblk_obs, V.W), dim3(kObsBlock), 0, s, V, abs_out);
+}
+
+void launch_select(const DevView& V, hipStream_t s) {
+    const int64_t count = V.abs_all ? V.abs_all_count : 2 * V.m_max;
+    const int nb = (int)((count + 256 * kSelItems - 1) / (256 * kSelItems));
+    const dim3 g(nb > 0 ? nb : 1, V.W), b(256);
+    hipLaunchKernelGGL(k_select_pass<0>, g, b, 0, s, V);
+    hipLaunchKernelGGL(k_select_pass<1>, g, b, 0, s, V);
+    hipLaunchKernelGGL(k_select_pass<2>, g, b, 0, s, V);
+    hipLaunchKernelGGL(k_select_pass<3>, g, b, 0, s, V);
+    hipLaunchKernelGGL(k_select_pass<4>, g, b, 0, s, V);
+    hipLaunchKernelGGL(k_select_pass<5>, g, b, 0, s, V);
+}
+
+void launch_obs_accumulate(const DevView& V, hipStream_t s) {
+    const int nb = (V.n_max + kPosesPerAccBlock - 1) / kPosesPerAccBlock;
+    hipLaunchKernelGGL(k_obs_accumulate, dim3(nb, V.W), dim3(64 * kPosesPerAccBlock), 0, s, V);
+}
+
+void launch_trial(const DevView& V, hipStream_t s) {
+    hipLaunchKernelGGL(k_trial, dim3(V.nblk_obs + V.nblk_dyn, V.W), dim3(kObsBlock), 0, s, V);
+}
+
+void launch_debug_project(const DevView& V, int w, int m, double* est, double* J, double* wt, hipStream_t s) {
+    hipLaunchKernelGGL(k_debug_project, dim3((m + kObsBlock - 1) / kObsBlock), dim3(kObsBlock), 0, s, V, w, est, J, wt);
+}
+
+}  // namespace vba

@@ -1,0 +1,109 @@
+"""Thin object wrapper over the C ABI: one :class:`BAEngine` = one ``vba_handle``."""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_double, c_float, c_int, c_int64, c_uint, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._lib import PD, PI64
+
+DBG = dict(est=0, weight=1, H=2, b=3, Phi=4, r_pred=5, qgrad=6, Hq=7, bands=8, rhs=9, dpose=10, scalars=11, Jg=12)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a):
+    return a.ctypes.data_as(PD)
+
+
+class BAEngine:
+    """Device-resident bundle-adjustment context holding ``windows`` independent windows."""
+
+    def __init__(self, n_max, m_max, windows=1, device=0):
+        self.lib = _lib.load()
+        self.h = c_void_p()
+        _lib.check(self.lib.vba_create(device, windows, int(n_max), int(m_max), byref(self.h)), self.lib)
+        self.windows = windows
+        self.n = [0] * windows
+        self.m = [0] * windows
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.vba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ uploads
+    def upload_observations(self, landmarks_xyz, landmarks_uv, confidences, ii, n, window=0):
+        xyz, uv, conf, ii = _f64(landmarks_xyz).reshape(-1, 3), _f64(landmarks_uv).reshape(-1, 2), _f64(confidences).reshape(-1), _i64(ii).reshape(-1)
+        m = xyz.shape[0]
+        if not (uv.shape[0] == m and conf.shape[0] == m and ii.shape[0] == m):
+            raise ValueError("observation arrays disagree on the number of rows")
+        _lib.check(self.lib.vba_upload_observations(self.h, window, int(n), m, _p(xyz), _p(uv), _p(conf),
+                                                    ii.ctypes.data_as(PI64)), self.lib)
+        self.n[window], self.m[window] = int(n), m
+
+    def upload_window(self, intrinsics, cumrot_last, time_idx, window=0):
+        K, c, t = _f64(intrinsics).reshape(-1, 4), _f64(cumrot_last).reshape(-1, 4), _i64(time_idx).reshape(-1)
+        n = K.shape[0]
+        if not (c.shape[0] == n and t.shape[0] == n):
+            raise ValueError("per-pose arrays disagree on the number of poses")
+        _lib.check(self.lib.vba_upload_window(self.h, window, n, _p(K), _p(c), t.ctypes.data_as(PI64)), self.lib)
+        self.n[window] = n
+
+    def set_states(self, states, lamda, window=0):
+        s = _f64(states).reshape(-1, 10)
+        _lib.check(self.lib.vba_set_states(self.h, window, _p(s), float(lamda)), self.lib)
+
+    def get_states(self, window=0):
+        n = self.n[window]
+        s = np.empty((n, 10))
+        lam = c_double()
+        hess = np.empty((9, 9))
+        nt, fl = c_int(), c_uint()
+        _lib.check(self.lib.vba_get_states(self.h, window, _p(s), byref(lam), _p(hess), byref(nt), byref(fl)), self.lib)
+        return s, lam.value, hess, nt.value, fl.value
+
+    # ------------------------------------------------------------------ compute
+    def step(self, it, initialize):
+        _lib.check(self.lib.vba_step(self.h, int(it), int(bool(initialize))), self.lib)
+
+    def iterate(self, it, initialize, lamda, states):
+        """One ``BA()`` call on window 0: returns (states_new, lamda_out, last_hessian, n_trials, flags)."""
+        s = _f64(states).reshape(-1, 10)
+        out = np.empty_like(s)
+        lam = c_double()
+        hess = np.empty((9, 9))
+        nt, fl = c_int(), c_uint()
+        _lib.check(self.lib.vba_iterate(self.h, int(it), int(bool(initialize)), float(lamda), _p(s), _p(out), byref(lam),
+                                        _p(hess), byref(nt), byref(fl)), self.lib)
+        return out, lam.value, hess, nt.value, fl.value
+
+    def last_step_ms(self):
+        ms = c_float()
+        _lib.check(self.lib.vba_last_step_ms(self.h, byref(ms)), self.lib)
+        return ms.value
+
+    def debug(self, what, window=0):
+        n, m = self.n[window], self.m[window]
+        shapes = dict(est=(m, 2), weight=(m,), H=(n, 6, 6), b=(n, 6), Phi=(n, 6, 6), r_pred=(n - 1, 7), qgrad=(n, 3),
+                      Hq=(n, 3, 3, 3), bands=(n, 3, 9, 9), rhs=(n, 9), dpose=(n, 9), scalars=(8,), Jg=(m, 2, 6))
+        shp = shapes[what]
+        out = np.empty(int(np.prod(shp)))
+        cnt = c_int64()
+        _lib.check(self.lib.vba_debug_fetch(self.h, window, DBG[what], _p(out), out.size, byref(cnt)), self.lib)
+        assert cnt.value == out.size
+        return out.reshape(shp)
