@@ -110,6 +110,13 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
 /* Timing of the last vba_step measured with HIP events on the handle's stream, milliseconds. */
 int vba_last_step_ms(vba_handle h, float* ms);
 
+/* Same work as vba_step, with every kernel class bracketed by HIP events on the handle's stream (first LM
+ * trial only).  ms[VBA_NKERNELS] receives the durations in the order of the VBA_K_* enum; a class that did
+ * not run (dynamics in the landmark-only phase) reports 0. */
+enum { VBA_K_BEGIN = 0, VBA_K_RESIDUAL, VBA_K_SELECT, VBA_K_ACCUMULATE, VBA_K_DYNAMICS, VBA_K_ASSEMBLE, VBA_K_SOLVE,
+       VBA_K_TRIAL, VBA_K_DECIDE, VBA_NKERNELS };
+int vba_step_profiled(vba_handle h, int iter, int initialize, float* ms);
+
 /* ---- observation-sharded multi-GPU operation (one rank per GPU, window 0 only) -------------------------
  * Each rank uploads its slice of the observation rows and the full per-pose constants.  One BA() call is
  * the sequence   stage1 -> all-gather -> stage2 -> all-gather -> stage3 -> all-gather -> stage4 [-> stage3 ...]
@@ -118,14 +125,17 @@ int vba_last_step_ms(vba_handle h, float* ms);
  */
 /* number of doubles each rank contributes to the second exchange: per-pose blocks + gradient + scalars */
 int64_t vba_sh_partial_count(int n);
-/* stage 1: residuals of the local rows at the resident states; writes 2*m_local |r| values to d_abs_local. */
-int vba_sh_stage1(vba_handle h, int iter, int initialize, double* d_abs_local);
-/* stage 2: exact lower median over the gathered |r| of all ranks (count_all values), robust weights and the
- * local per-pose accumulation; writes vba_sh_partial_count(n) doubles to d_partial_local. */
+/* stage 1: residuals of the local rows at the resident states; writes 2*m_local |r| values to d_abs_local.
+ * m_total = number of observation rows over all ranks (fixes the median rank and the residual means). */
+int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, double* d_abs_local);
+/* stage 2: exact lower median over the gathered |r| of all ranks, robust weights and the local per-pose
+ * accumulation; writes vba_sh_partial_count(n) doubles to d_partial_local.  d_abs_all holds count_all values of
+ * which 2*m_total are keys; slots that pad unequal shards must hold +inf (they sort above every key). */
 int vba_sh_stage2(vba_handle h, const double* d_abs_all, int64_t count_all, double* d_partial_local);
 /* stage 3: reduce the R gathered partials in rank order, build + solve the system (every rank redundantly),
- * retract, and evaluate the local part of the trial residual into d_trial_local[0..1]. */
-int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, int64_t m_total, double* d_trial_local);
+ * retract, and evaluate the local part of the trial residual into d_trial_local[0..1].  d_partial_all == NULL
+ * runs another LM trial (next damping) on the system already built. */
+int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* d_trial_local);
 /* stage 4: accept test on the gathered trial sums (2 doubles per rank); *done = 1 when the LM loop ended
  * (states/lamda updated).  Synchronous. */
 int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done);

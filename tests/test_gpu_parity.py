@@ -94,7 +94,11 @@ def test_c2_weights_and_blocks_vs_oracle(eng_c2, c2):
                        inp["conf"], float(g["lamda_in"][k]), initialize=bool(g["initialize"][k]), debug=dbg)
         eng_c2.iterate(int(g["iters"][k]), bool(g["initialize"][k]), float(g["lamda_in"][k]), st)
         sc = eng_c2.debug("scalars")
-        assert sc[0] == dbg["c_obs"]                      # exact lower median: bit-exact
+        # the select is exact: recomputing the lower median on the host from the device's own reprojection
+        # gives the same bits (the oracle's value differs in the last ulp because its residuals do)
+        a = np.abs(inp["uv"] - eng_c2.debug("est")).reshape(-1)
+        assert sc[0] == np.sort(a)[(a.size - 1) // 2]
+        assert rel_err(sc[0], dbg["c_obs"]) < 1e-13
         assert rel_err(sc[1], dbg["wmax"]) < 1e-14
         assert rel_err(eng_c2.debug("weight"), dbg["w"]) < 1e-13
         assert rel_err(eng_c2.debug("H"), dbg["H"]) < 1e-12
@@ -123,3 +127,281 @@ def test_run_to_run_bit_stable(eng_c2, c2):
     a = eng_c2.iterate(12, False, 1e-4, g["states_out_11"][0])[0]
     b = eng_c2.iterate(12, False, 1e-4, g["states_out_11"][0])[0]
     assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ full-size windows
+def _window_from_seed(name):
+    from vinsat_amd import od_pipe, synth
+    det, orb = synth.make_sequence(name)
+    win = od_pipe.prepare_window(det, orb)
+    return win
+
+
+def _digest(v):
+    v = np.asarray(v, dtype=np.float64).reshape(-1)
+    return np.array([v.size, v.sum(), np.abs(v).sum(), v[0], v[v.size // 2], v[-1]])
+
+
+@pytest.mark.parametrize("name", ["c3", "c4"])
+def test_headline_windows_chained_vs_reference_states(name):
+    """C3 (500 poses / 50k observations) and C4 (500 / 200k): inputs regenerated from the seed, checked
+    against the digest of what the reference was fed, then all 20 calls chained on the GPU and compared with
+    the reference's states after calls 0, 9, 10, 14, 19."""
+    import os
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, f"{name}.npz")):
+        pytest.skip(f"{name} fixture not generated")
+    from vinsat_amd.engine import BAEngine
+    g = load_golden(name)
+    win = _window_from_seed(name.upper())
+    for key, arr in (("landmarks", win.landmarks_uv), ("landmarks_xyz", win.landmarks_xyz), ("confidences", win.confidences),
+                     ("intrinsics", win.intrinsics), ("cumrot_last", win.cumrot_last)):
+        assert rel_err(_digest(arr), g["digest_" + key]) < 1e-12, key
+    assert np.array_equal(win.time_idx, g["in_time_idx"])
+    assert np.array_equal(np.array([win.ii.size, win.ii.sum(), win.ii[0], win.ii[-1]]), g["in_ii_digest"])
+    n, m = win.time_idx.shape[0], win.ii.shape[0]
+    eng = BAEngine(n, m)
+    eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+    eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+    st, lam = g["states0"][0], 1e-4
+    for k in range(20):
+        st, lam, _, ntr, flags = eng.iterate(int(g["iters"][k]), bool(g["initialize"][k]), lam, st)
+        assert ntr == g["n_trials"][k] and lam == g["lamda_out"][k] and flags == 0
+        if f"states_out_{k}" in g:
+            ref = g[f"states_out_{k}"][0]
+            assert np.abs(st[:, :3] - ref[:, :3]).max() / np.abs(ref[:, :3]).max() < 1e-6, k
+            q, qr = st[:, 3:7], ref[:, 3:7]
+            assert (2 * np.arccos(np.clip(np.abs((q * qr).sum(-1)), 0, 1))).max() < 1e-6, k
+            assert rel_err(st, ref) < 1e-6, k
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ LM loop
+def _oracle_vs_gpu(eng, win_args, it, init, lam, st, tol=1e-7):
+    cum, uv, xyz, ii, t, K, conf = win_args
+    ref, lam_ref, hess_ref, ntr_ref = O.ba_iteration(it, st, cum, uv, xyz, ii, t, K, conf, lam, initialize=init)
+    out, lam_g, hess, ntr, flags = eng.iterate(it, init, lam, st)
+    assert ntr == ntr_ref
+    assert lam_g == lam_ref
+    assert rel_err(out, ref) < tol
+    assert rel_err(hess, hess_ref) < 1e-9
+    return out, lam_g, ntr, flags
+
+
+def test_rejected_trials_and_lambda_exhaustion(eng_c2, c2):
+    """Drive the LM loop through several trials (BA_filtering.py:52-77).  Near the optimum with unit
+    confidences the accept test (weighted trial vs unweighted initial residual, :51 vs :66) rejects the small
+    dampings; with confidences of 3 it can never pass, so lamda runs out after 9 trials and the last trial is kept."""
+    g, inp = c2, golden_inputs(c2)
+    n = g["states0"].shape[1]
+    base = [inp["cumrot"], inp["uv"], inp["xyz"], inp["ii"], inp["time_idx"], inp["K"], None]
+    try:
+        conf = np.ones_like(inp["conf"])
+        eng_c2.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
+        base[6] = conf
+        st, lam = g["states_out_19"][0].copy(), 1e-4
+        seen = []
+        for rep in range(4):
+            st, lam, ntr, flags = _oracle_vs_gpu(eng_c2, tuple(base), 0, True, lam, st, tol=1e-6)
+            seen.append(ntr)
+            assert flags == 0
+        assert max(seen) >= 4, seen
+        st5, _, ntr, _ = _oracle_vs_gpu(eng_c2, tuple(base), 5, True, 1e-4, g["states_out_19"][0], tol=1e-6)
+        assert ntr > 1
+        conf = np.full_like(inp["conf"], 3.0)
+        eng_c2.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
+        base[6] = conf
+        out, lam_o, ntr, flags = _oracle_vs_gpu(eng_c2, tuple(base), 0, True, 1e-4, g["states_out_19"][0], tol=1e-6)
+        assert ntr == 9 and (flags & 1) and lam_o == 0.1
+        out, lam_o, ntr, flags = _oracle_vs_gpu(eng_c2, tuple(base), 12, False, 1e-2, g["states_out_19"][0], tol=1e-6)
+        assert ntr == 7 and (flags & 1)
+    finally:
+        eng_c2.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+def test_unsorted_rows_empty_poses_and_ragged_gaps():
+    """Rows in arbitrary order, poses without any observation, uneven time gaps (1..37 s) and a very uneven
+    number of observations per pose; compared with the oracle."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    det, orb = synth.make_sequence(synth.WindowConfig("edge", 24, 37, 5), seed=3)
+    win = od_pipe.prepare_window(det, orb)
+    rng = np.random.default_rng(11)
+    # drop observations: poses 3 and 17 get none, pose 5 keeps one row, others a random subset
+    keep = rng.random(win.ii.size) < 0.7
+    keep[(win.ii == 3) | (win.ii == 17)] = False
+    idx5 = np.nonzero(win.ii == 5)[0]
+    keep[idx5] = False
+    keep[idx5[0]] = True
+    order = rng.permutation(np.nonzero(keep)[0])
+    xyz, uv, conf, ii = win.landmarks_xyz[order], win.landmarks_uv[order], win.confidences[order], win.ii[order]
+    conf = conf * rng.uniform(0.5, 1.0, size=conf.shape)
+    # ragged gaps: re-time the poses (dynamics residuals become large; parity is what matters here)
+    t = np.cumsum(np.concatenate([[10], rng.integers(1, 38, size=win.time_idx.size - 1)])).astype(np.int64)
+    n = t.size
+    eng = BAEngine(n, ii.size)
+    eng.upload_observations(xyz, uv, conf, ii, n)
+    eng.upload_window(win.intrinsics, win.cumrot_last, t)
+    args = (win.cumrot_last, uv, xyz, ii, t, win.intrinsics, conf)
+    st = od_pipe.initial_guess(win)
+    lam = 1e-4
+    for it, init in ((0, True), (1, True), (2, True), (3, True), (10, False), (11, False)):
+        st, lam, ntr, flags = _oracle_vs_gpu(eng, args, it, init, lam, st, tol=1e-7)
+    H = eng.debug("H")
+    assert np.all(H[3] == 0) and np.all(H[17] == 0)
+    eng.close()
+
+
+def test_minimum_window_two_poses_one_observation_each():
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    det, orb = synth.make_sequence(synth.WindowConfig("tiny", 2, 1, 5), seed=1)
+    win = od_pipe.prepare_window(det, orb)
+    eng = BAEngine(2, 2)
+    eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, 2)
+    eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+    args = (win.cumrot_last, win.landmarks_uv, win.landmarks_xyz, win.ii, win.time_idx, win.intrinsics, win.confidences)
+    st = win.states_gt.copy()
+    st[:, :3] += 1.0
+    _oracle_vs_gpu(eng, args, 0, True, 1e-4, st, tol=1e-7)
+    _oracle_vs_gpu(eng, args, 12, False, 1e-2, st, tol=1e-7)
+    eng.close()
+
+
+def test_argument_errors_are_reported():
+    from vinsat_amd._lib import VbaError
+    from vinsat_amd.engine import BAEngine
+    eng = BAEngine(8, 64)
+    with pytest.raises(VbaError):
+        eng.step(0, True)                                  # nothing uploaded
+    with pytest.raises(VbaError):
+        eng.upload_observations(np.zeros((4, 3)), np.zeros((4, 2)), np.ones(4), np.array([0, 1, 9, 2]), 8)   # ii out of range
+    with pytest.raises(VbaError):
+        eng.upload_window(np.ones((8, 4)), np.ones((8, 4)), np.array([0, 1, 2, 2, 3, 4, 5, 6]))              # repeated time
+    with pytest.raises(VbaError):
+        eng.upload_observations(np.zeros((100, 3)), np.zeros((100, 2)), np.ones(100), np.zeros(100, dtype=np.int64), 8)  # m > m_max
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ batched windows
+def test_batched_windows_equal_single_window_runs(c2):
+    """W windows in one handle (different data, different sizes) give bit-identical results to W separate runs."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    wins = []
+    for seed, cfg in ((0, synth.WindowConfig("a", 40, 30, 5)), (1, synth.WindowConfig("b", 64, 17, 5)),
+                      (2, synth.WindowConfig("c", 33, 50, 5))):
+        det, orb = synth.make_sequence(cfg, seed=seed)
+        wins.append(od_pipe.prepare_window(det, orb))
+    n_max = max(w.time_idx.size for w in wins)
+    m_max = max(w.ii.size for w in wins)
+    sched = [(0, True), (1, True), (4, True), (10, False), (11, False)]
+    singles = []
+    for w in wins:
+        e = BAEngine(n_max, m_max)
+        e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, w.time_idx.size)
+        e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx)
+        e.set_states(od_pipe.initial_guess(w), 1e-4)
+        for it, init in sched:
+            e.step(it, init)
+        singles.append(e.get_states())
+        e.close()
+    e = BAEngine(n_max, m_max, windows=3)
+    for k, w in enumerate(wins):
+        e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, w.time_idx.size, window=k)
+        e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx, window=k)
+        e.set_states(od_pipe.initial_guess(w), 1e-4, window=k)
+    for it, init in sched:
+        e.step(it, init)
+    for k in range(3):
+        s, lam, hess, ntr, flags = e.get_states(window=k)
+        assert np.array_equal(s, singles[k][0]) and lam == singles[k][1] and np.array_equal(hess, singles[k][2])
+    e.close()
+
+
+# ------------------------------------------------------------------------------------------------ drop-in surface
+def test_BA_call_surface_matches_reference_signature(c1):
+    import torch
+    from vinsat_amd.ba import BA
+    g, inp = c1, golden_inputs(c1)
+    n = inp["K"].shape[0]
+    imu = torch.zeros((1, n, 5, 10), dtype=torch.float64)
+    imu[0, :, -1, 6:] = torch.from_numpy(inp["cumrot"])
+    vel = torch.from_numpy(g["in_velocities"])
+    states, lam = torch.from_numpy(g["states0"]), 1e-4
+    for k in range(20):
+        states, v_out, lam, hess = BA(int(g["iters"][k]), states, vel, imu, torch.from_numpy(inp["uv"])[None],
+                                      torch.from_numpy(inp["xyz"])[None], inp["ii"], inp["time_idx"],
+                                      torch.from_numpy(inp["K"])[None], torch.from_numpy(inp["conf"]), 1e-3, 1e-3, lam,
+                                      torch.from_numpy(g["in_poses_gt_eci"]), initialize=bool(g["initialize"][k]))
+        assert v_out is vel and states.shape == (1, n, 10) and hess.shape == (1, 9, 9) and isinstance(lam, float)
+    assert rel_err(states[0].numpy(), g["states_out_19"][0]) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------------ sharded stages
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_sharded_stage_kernels_on_one_gpu(c2, ranks):
+    """The HIP stage entry points (vba_sh_stage1..4) driven for R emulated ranks on one GPU: buffers are
+    concatenated on the device in place of the RCCL all-gathers.  Must agree with the unsharded HIP path to
+    rounding and every emulated rank must end with bit-identical states."""
+    import torch
+    from vinsat_amd.dist import HipStageEngine, shard_bounds
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    n = inp["K"].shape[0]
+    m = inp["xyz"].shape[0] - 3
+    xyz, uv, conf, ii = inp["xyz"][:m], inp["uv"][:m], inp["conf"][:m].copy(), inp["ii"][:m]
+    conf[::7] = 2.5
+    b = shard_bounds(m, ranks)
+    m_pad = -(-m // ranks)
+    engs = []
+    for r in range(ranks):
+        lo, hi = int(b[r]), int(b[r + 1])
+        e = BAEngine(n, hi - lo)
+        e.upload_observations(xyz[lo:hi], uv[lo:hi], conf[lo:hi], ii[lo:hi], n)
+        e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+        engs.append(HipStageEngine(e))
+    single = BAEngine(n, m)
+    single.upload_observations(xyz, uv, conf, ii, n)
+    single.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+    st, lam = g["states0"][0], 1e-4
+    ref, lam_ref = st.copy(), lam
+    for e in engs:
+        e.set_states(st, lam)
+    pc = engs[0].partial_count(n)
+    abs_l = [torch.full((2 * m_pad,), float("inf"), dtype=torch.float64, device="cuda") for _ in range(ranks)]
+    part_l = [torch.empty(pc, dtype=torch.float64, device="cuda") for _ in range(ranks)]
+    trial_l = [torch.empty(2, dtype=torch.float64, device="cuda") for _ in range(ranks)]
+    saw_multi = False
+    for it, init in [(0, True), (1, True), (2, True), (5, True), (10, False), (11, False), (12, False)]:
+        for r, e in enumerate(engs):
+            e.stage1(it, init, m, abs_l[r])
+        abs_all = torch.cat(abs_l)
+        for r, e in enumerate(engs):
+            e.stage2(abs_all, part_l[r])
+        part_all = torch.cat(part_l)
+        first, trials = True, 0
+        while True:
+            for r, e in enumerate(engs):
+                e.stage3(part_all if first else None, ranks, trial_l[r])
+            trial_all = torch.cat(trial_l)
+            done = [e.stage4(trial_all, ranks) for e in engs]
+            first = False
+            trials += 1
+            assert all(d == done[0] for d in done)
+            if done[0]:
+                break
+            assert trials < 12
+        ref, lam_ref, hess_ref, ntr_ref, flags_ref = single.iterate(it, init, lam_ref, ref)
+        outs = [e.get_states() for e in engs]
+        assert trials == ntr_ref == outs[0][3]
+        saw_multi |= trials > 1
+        for o in outs:
+            assert np.array_equal(o[0], outs[0][0]) and o[1] == outs[0][1]
+        assert outs[0][1] == lam_ref
+        assert rel_err(outs[0][0], ref) < 1e-9
+        assert rel_err(outs[0][2], hess_ref) < 1e-9
+    for e in engs:
+        e.close()
+    single.close()

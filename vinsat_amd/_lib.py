@@ -31,10 +31,11 @@ SIGNATURES = {
     "vba_iterate": (c_int, [c_void_p, c_int, c_int, c_double, PD, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
     "vba_debug_fetch": (c_int, [c_void_p, c_int, c_int, PD, c_int64, PI64]),
     "vba_last_step_ms": (c_int, [c_void_p, POINTER(c_float)]),
+    "vba_step_profiled": (c_int, [c_void_p, c_int, c_int, POINTER(c_float)]),
     "vba_sh_partial_count": (c_int64, [c_int]),
-    "vba_sh_stage1": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "vba_sh_stage1": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p]),
     "vba_sh_stage2": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
-    "vba_sh_stage3": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "vba_sh_stage3": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "vba_sh_stage4": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int)]),
 }
 

@@ -333,7 +333,7 @@ int vba_get_states(vba_handle h, int window, double* states, double* lamda, doub
     return VBA_OK;
 }
 
-int vba_step(vba_handle h, int iter, int initialize) {
+static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
@@ -341,31 +341,64 @@ int vba_step(vba_handle h, int iter, int initialize) {
     DevView V = h->V;
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
     fill_params(*h->h_prm, iter, initialize);
+    hipEvent_t ev[VBA_NKERNELS + 1] = {};
+    if (prof) {
+        for (int k = 0; k <= VBA_NKERNELS; ++k) HIPCHK(hipEventCreate(&ev[k]));
+    }
+    auto mark = [&](int k) { if (prof) (void)hipEventRecord(ev[k], s); };
     HIPCHK(hipEventRecord(h->ev0, s));
     HIPCHK(hipMemcpyAsync(h->d_prm, h->h_prm, sizeof(StepParams), hipMemcpyHostToDevice, s));
+    mark(0);
     launch_step_begin(V, s);
+    mark(1);
     launch_obs_residual(V, nullptr, s);
+    mark(2);
     launch_select(V, s);
+    mark(3);
     launch_obs_accumulate(V, s);
+    mark(4);
     if (!initialize) launch_dynamics(V, s);
+    mark(5);
     launch_assemble(V, s);
+    mark(6);
     // LM loop (BA_filtering.py:52-77): lamda 1e-4 .. 1e4 in decades, at most 9 trials
+    int rc_out = VBA_OK;
     for (int trial = 0; trial < 12; ++trial) {
         launch_solve(V, s);
+        if (trial == 0) mark(7);
         launch_trial(V, s);
+        if (trial == 0) mark(8);
         launch_decide(V, nullptr, 0, s);
-        if (trial == 0) HIPCHK(hipEventRecord(h->ev1, s));
+        if (trial == 0) {
+            mark(9);
+            HIPCHK(hipEventRecord(h->ev1, s));
+        }
         HIPCHK(hipGetLastError());
-        if (int rc = read_heads(h)) return rc;
+        if (int rc = read_heads(h)) { rc_out = rc; break; }
         bool all = true;
         for (int w = 0; w < h->W; ++w) all = all && head(h, w)->done;
         if (all) break;
     }
-    HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    if (rc_out == VBA_OK) HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    if (prof) {
+        for (int k = 0; k < VBA_NKERNELS; ++k) {
+            prof[k] = 0.f;
+            if (rc_out == VBA_OK) (void)hipEventElapsedTime(&prof[k], ev[k], ev[k + 1]);
+        }
+        for (int k = 0; k <= VBA_NKERNELS; ++k) (void)hipEventDestroy(ev[k]);
+    }
+    if (rc_out != VBA_OK) return rc_out;
     h->stepped = true;
     h->last_iter = iter;
     h->last_init = initialize;
     return VBA_OK;
+}
+
+int vba_step(vba_handle h, int iter, int initialize) { return step_impl(h, iter, initialize, nullptr); }
+
+int vba_step_profiled(vba_handle h, int iter, int initialize, float* ms) {
+    if (!ms) return fail(VBA_EINVAL, "null ms");
+    return step_impl(h, iter, initialize, ms);
 }
 
 int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in, double* states_out,
@@ -493,14 +526,15 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
 // ------------------------------------------------------------------------------------------------ sharded mode
 int64_t vba_sh_partial_count(int n) { return 27 * (int64_t)n + 2; }
 
-int vba_sh_stage1(vba_handle h, int iter, int initialize, double* d_abs_local) {
-    if (!h || !d_abs_local) return fail(VBA_EINVAL, "null argument");
+int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, double* d_abs_local) {
+    if (!h || !d_abs_local || m_total < 1) return fail(VBA_EINVAL, "bad argument");
     if (h->W != 1) return fail(VBA_EINVAL, "sharded mode uses a single window per handle");
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     fill_params(*h->h_prm, iter, initialize);
     HIPCHK(hipMemcpyAsync(h->d_prm, h->h_prm, sizeof(StepParams), hipMemcpyHostToDevice, s));
+    h->V.m_total = m_total;
     launch_step_begin(h->V, s);
     launch_obs_residual(h->V, d_abs_local, s);
     HIPCHK(hipGetLastError());
@@ -511,6 +545,7 @@ int vba_sh_stage1(vba_handle h, int iter, int initialize, double* d_abs_local) {
 
 int vba_sh_stage2(vba_handle h, const double* d_abs_all, int64_t count_all, double* d_partial_local) {
     if (!h || !d_abs_all || !d_partial_local || count_all < 1) return fail(VBA_EINVAL, "bad argument");
+    if (h->V.m_total < 1 || count_all < 2 * h->V.m_total) return fail(VBA_ESTATE, "stage1 has not run or count_all < 2*m_total");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     DevView V = h->V;
@@ -523,11 +558,11 @@ int vba_sh_stage2(vba_handle h, const double* d_abs_all, int64_t count_all, doub
     return VBA_OK;
 }
 
-int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, int64_t m_total, double* d_trial_local) {
-    if (!h || !d_trial_local || m_total < 1) return fail(VBA_EINVAL, "bad argument");
+int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* d_trial_local) {
+    if (!h || !d_trial_local) return fail(VBA_EINVAL, "bad argument");
+    if (h->V.m_total < 1) return fail(VBA_ESTATE, "stage1 has not run");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    h->V.m_total = m_total;
     DevView V = h->V;
     if (d_partial_all) {    // first trial of this call; NULL = another LM trial on the same system
         if (ranks < 1) return fail(VBA_EINVAL, "ranks must be >= 1");

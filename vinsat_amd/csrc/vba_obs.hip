@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     constexpr int nbins = 1 << sel_width(P);
     for (int b = threadIdx.x; b < nbins; b += 256) lh[b] = 0u;
     unsigned long long prefix = 0ull;
-    long long rank = (count - 1) / 2;           // torch.median = lower median (BA_filtering.py:23)
+    // torch.median = lower median (BA_filtering.py:23); in sharded mode the gathered buffer may end in +inf padding
+    long long rank = ((V.m_total ? 2 * V.m_total : count) - 1) / 2;
     if (P > 0) {
         constexpr int Q = P > 0 ? P - 1 : 0;
         select_resolve(hist + Q * kSelBins, 1 << sel_width(Q), sel_width(Q), V.sc[w].sel_prefix[Q], V.sc[w].sel_rank[Q],

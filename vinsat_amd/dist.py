@@ -1,0 +1,140 @@
+"""Observation-sharded BA across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The observation rows of ONE window are split into contiguous slices, one per rank (rows are frame sorted,
+reference ``estimation/od_pipe.py:219-228``).  The stages that are indexed by observation (reprojection,
+robust weights, per-pose accumulation, trial residuals) run on the local slice; the pose-chain stages
+(dynamics factor, assembly, block-tridiagonal solve, retraction) are tiny and run redundantly on every
+rank.  Per ``BA()`` call three device buffers are exchanged with all-gathers and reduced in rank order, so
+every rank holds bit-identical normal equations and takes the same LM decisions:
+
+1. ``|r|`` keys (16 B per observation) -> exact global lower median (``BA_filtering.py:23``);
+2. per-pose partial sums of ``w J^T J`` / ``w J^T r`` (27 doubles per pose -- the "reduced camera" normal
+   equations) plus the local max weight and ``sum |r|``;
+3. two doubles per LM trial (weighted trial residual sums) for the accept test (``BA_filtering.py:73``).
+
+The class is written against a small stage interface so that the same control flow is exercised on CPU
+tensors with the gloo backend in the test-suite (with a stand-in engine) and on the GPU with RCCL.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def shard_bounds(m_total: int, world: int):
+    """Contiguous, near-equal row slices: rank r owns [b[r], b[r+1])."""
+    base, rem = divmod(m_total, world)
+    sizes = [base + (1 if r < rem else 0) for r in range(world)]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+class HipStageEngine:
+    """Stage interface backed by libvinsat_ba.so; buffers are torch CUDA tensors, exchanged by pointer."""
+
+    def __init__(self, eng):
+        import torch
+        self.eng = eng
+        self.lib = eng.lib
+        self.torch = torch
+        from ._lib import check
+        self._check = check
+        check(self.lib.vba_set_stream(eng.h, torch.cuda.current_stream().cuda_stream), self.lib)
+
+    def partial_count(self, n):
+        return int(self.lib.vba_sh_partial_count(int(n)))
+
+    def new_buffer(self, count):
+        return self.torch.empty(int(count), dtype=self.torch.float64, device="cuda")
+
+    def stage1(self, it, init, m_total, abs_local):
+        self._check(self.lib.vba_sh_stage1(self.eng.h, int(it), int(bool(init)), int(m_total), abs_local.data_ptr()), self.lib)
+
+    def stage2(self, abs_all, partial_local):
+        self._check(self.lib.vba_sh_stage2(self.eng.h, abs_all.data_ptr(), abs_all.numel(), partial_local.data_ptr()), self.lib)
+
+    def stage3(self, partial_all, ranks, trial_local):
+        ptr = partial_all.data_ptr() if partial_all is not None else None
+        self._check(self.lib.vba_sh_stage3(self.eng.h, ptr, int(ranks), trial_local.data_ptr()), self.lib)
+
+    def stage4(self, trial_all, ranks):
+        import ctypes
+        done = ctypes.c_int()
+        self._check(self.lib.vba_sh_stage4(self.eng.h, trial_all.data_ptr(), int(ranks), ctypes.byref(done)), self.lib)
+        return bool(done.value)
+
+    def set_states(self, states, lamda):
+        self.eng.set_states(states, lamda)
+
+    def get_states(self):
+        return self.eng.get_states()
+
+    def close(self):
+        self.lib.vba_set_stream(self.eng.h, None)
+        self.eng.close()
+
+
+class ShardedBA:
+    """One window, rows sharded over the ranks of ``group`` (default: the world group)."""
+
+    def __init__(self, engine, n, m_local, m_total, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.engine = engine
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n, self.m_local, self.m_total = int(n), int(m_local), int(m_total)
+        self.m_pad = int(math.ceil(m_total / self.world))        # equal-size all-gather slots
+        e = engine
+        self.abs_local = e.new_buffer(2 * self.m_pad)
+        self.abs_local.fill_(float("inf"))                       # padding sorts above every |r|
+        self.abs_all = e.new_buffer(2 * self.m_pad * self.world)
+        pc = e.partial_count(n)
+        self.partial_local = e.new_buffer(pc)
+        self.partial_all = e.new_buffer(pc * self.world)
+        self.trial_local = e.new_buffer(2)
+        self.trial_all = e.new_buffer(2 * self.world)
+        self.n_trials = 0
+
+    @classmethod
+    def from_window(cls, win, device=0, group=None):
+        """Build the GPU-backed sharded solver for a :class:`vinsat_amd.od_pipe.Window` on this rank."""
+        import torch.distributed as dist
+        from .engine import BAEngine
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        n, m = win.time_idx.size, win.ii.size
+        b = shard_bounds(m, world)
+        lo, hi = int(b[rank]), int(b[rank + 1])
+        eng = BAEngine(n, max(hi - lo, 1), windows=1, device=device)
+        eng.upload_observations(win.landmarks_xyz[lo:hi], win.landmarks_uv[lo:hi], win.confidences[lo:hi], win.ii[lo:hi], n)
+        eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+        return cls(HipStageEngine(eng), n, hi - lo, m, group)
+
+    def set_states(self, states, lamda):
+        self.engine.set_states(states, lamda)
+
+    def get_states(self):
+        return self.engine.get_states()
+
+    def step(self, it, initialize):
+        """One ``BA()`` call; returns the number of LM trials."""
+        d, e = self.dist, self.engine
+        e.stage1(it, initialize, self.m_total, self.abs_local)
+        d.all_gather_into_tensor(self.abs_all, self.abs_local, group=self.group)
+        e.stage2(self.abs_all, self.partial_local)
+        d.all_gather_into_tensor(self.partial_all, self.partial_local, group=self.group)
+        first = True
+        trials = 0
+        while True:
+            e.stage3(self.partial_all if first else None, self.world, self.trial_local)
+            d.all_gather_into_tensor(self.trial_all, self.trial_local, group=self.group)
+            trials += 1
+            first = False
+            if e.stage4(self.trial_all, self.world) or trials >= 12:
+                break
+        self.n_trials = trials
+        return trials
+
+    def close(self):
+        self.engine.close()

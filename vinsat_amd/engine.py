@@ -92,6 +92,14 @@ class BAEngine:
                                         _p(hess), byref(nt), byref(fl)), self.lib)
         return out, lam.value, hess, nt.value, fl.value
 
+    KERNELS = ("begin", "residual", "select", "accumulate", "dynamics", "assemble", "solve", "trial", "decide")
+
+    def step_profiled(self, it, initialize):
+        """Like :meth:`step`, returning {kernel class: milliseconds} measured with HIP events on the library stream."""
+        ms = (c_float * len(self.KERNELS))()
+        _lib.check(self.lib.vba_step_profiled(self.h, int(it), int(bool(initialize)), ms), self.lib)
+        return dict(zip(self.KERNELS, [float(x) for x in ms]))
+
     def last_step_ms(self):
         ms = c_float()
         _lib.check(self.lib.vba_last_step_ms(self.h, byref(ms)), self.lib)
