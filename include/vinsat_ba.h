@@ -73,9 +73,16 @@ int vba_device_count(int* count);
 int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* out);
 int vba_destroy(vba_handle h);
 
-/* Run all work of this handle on an existing HIP stream (e.g. the one RCCL collectives are issued on).
- * `hip_stream` is a hipStream_t; 0 restores the handle's own stream. */
-int vba_set_stream(vba_handle h, void* hip_stream);
+/* external != 0: run all work of this handle on the caller's HIP stream `hip_stream` (a hipStream_t; NULL is the
+ * legacy default stream), e.g. the stream RCCL collectives are ordered against.  external == 0: back to the
+ * handle's own stream. */
+int vba_set_stream(vba_handle h, void* hip_stream, int external);
+
+/* Choice of the block-tridiagonal solve: chunk = 0 one wavefront walks the whole pose chain (work optimal, used
+ * when many windows are batched); chunk in [2,60] cuts the chain into chunks of that many poses that are
+ * eliminated in parallel plus a reduced system over the separators; chunk < 0 restores the default
+ * (~sqrt(n_max), or 0 for >= 128 windows).  Both give the same answer to rounding. */
+int vba_set_solver(vba_handle h, int chunk);
 
 /* Observation rows of window `window`: landmarks_xyz [m,3] (ECI km), landmarks (uv) [m,2] px,
  * confidences [m], ii [m] pose index of each row (BA arguments landmarks_xyz, landmarks, confidences, ii:

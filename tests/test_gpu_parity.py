@@ -8,24 +8,27 @@ from oracle import ba_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng_c1(c1):
+# solver: -1 = default (chain cut into ~sqrt(n) chunks), 0 = one wave walks the whole chain, 7 = odd chunk size
+@pytest.fixture(scope="module", params=[-1, 0], ids=["partitioned", "sequential"])
+def eng_c1(c1, request):
     from vinsat_amd.engine import BAEngine
     inp = golden_inputs(c1)
     n, m = inp["K"].shape[0], inp["xyz"].shape[0]
     e = BAEngine(n, m)
+    e.set_solver(request.param)
     e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
     e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
     yield e
     e.close()
 
 
-@pytest.fixture(scope="module")
-def eng_c2(c2):
+@pytest.fixture(scope="module", params=[-1, 0, 7], ids=["partitioned", "sequential", "chunk7"])
+def eng_c2(c2, request):
     from vinsat_amd.engine import BAEngine
     inp = golden_inputs(c2)
     n, m = inp["K"].shape[0], inp["xyz"].shape[0]
     e = BAEngine(n, m)
+    e.set_solver(request.param)
     e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
     e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
     yield e
@@ -100,7 +103,7 @@ def test_c2_weights_and_blocks_vs_oracle(eng_c2, c2):
         assert sc[0] == np.sort(a)[(a.size - 1) // 2]
         assert rel_err(sc[0], dbg["c_obs"]) < 1e-13
         assert rel_err(sc[1], dbg["wmax"]) < 1e-14
-        assert rel_err(eng_c2.debug("weight"), dbg["w"]) < 1e-13
+        assert rel_err(eng_c2.debug("weight"), dbg["w"]) < 1e-11     # pow() differs in the last bits
         assert rel_err(eng_c2.debug("H"), dbg["H"]) < 1e-12
         assert rel_err(eng_c2.debug("b"), dbg["b"]) < 1e-10
         assert rel_err(sc[2], dbg["init_residual"]) < 1e-13
@@ -142,8 +145,9 @@ def _digest(v):
     return np.array([v.size, v.sum(), np.abs(v).sum(), v[0], v[v.size // 2], v[-1]])
 
 
+@pytest.mark.parametrize("solver", [-1, 0], ids=["partitioned", "sequential"])
 @pytest.mark.parametrize("name", ["c3", "c4"])
-def test_headline_windows_chained_vs_reference_states(name):
+def test_headline_windows_chained_vs_reference_states(name, solver):
     """C3 (500 poses / 50k observations) and C4 (500 / 200k): inputs regenerated from the seed, checked
     against the digest of what the reference was fed, then all 20 calls chained on the GPU and compared with
     the reference's states after calls 0, 9, 10, 14, 19."""
@@ -161,6 +165,7 @@ def test_headline_windows_chained_vs_reference_states(name):
     assert np.array_equal(np.array([win.ii.size, win.ii.sum(), win.ii[0], win.ii[-1]]), g["in_ii_digest"])
     n, m = win.time_idx.shape[0], win.ii.shape[0]
     eng = BAEngine(n, m)
+    eng.set_solver(solver)
     eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
     eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
     st, lam = g["states0"][0], 1e-4

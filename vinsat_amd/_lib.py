@@ -22,7 +22,8 @@ SIGNATURES = {
     "vba_device_count": (c_int, [POINTER(c_int)]),
     "vba_create": (c_int, [c_int, c_int, c_int, c_int64, POINTER(c_void_p)]),
     "vba_destroy": (c_int, [c_void_p]),
-    "vba_set_stream": (c_int, [c_void_p, c_void_p]),
+    "vba_set_stream": (c_int, [c_void_p, c_void_p, c_int]),
+    "vba_set_solver": (c_int, [c_void_p, c_int]),
     "vba_upload_observations": (c_int, [c_void_p, c_int, c_int, c_int64, PD, PD, PD, PI64]),
     "vba_upload_window": (c_int, [c_void_p, c_int, c_int, PD, PD, PI64]),
     "vba_set_states": (c_int, [c_void_p, c_int, PD, c_double]),

@@ -155,6 +155,8 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     need(W * kSelPasses * kSelBins * 4);
     const size_t per_pose = 21 + 6 + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
     need(W * N * per_pose * 8 + 16 * 256);
+    need(W * N * 171 * 8);
+    need(W * N * (171 + 171 + 81 + 9 + 9) * 8 + 6 * 256);     // reduced system (p_max <= n_max / 2 + 1)
     bytes += 1 << 16;
     if (hipMalloc(&h->arena.base, bytes) != hipSuccess) {
         delete h;
@@ -186,7 +188,17 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.Hd = A.take<double>(W * N * 9); V.Hu = A.take<double>(W * N * 9); V.Hl = A.take<double>(W * N * 9);
     V.bands = A.take<double>(W * N * 243); V.rhs = A.take<double>(W * N * 9);
     V.Xs = A.take<double>(W * N * 81); V.zs = A.take<double>(W * N * 9); V.dpose = A.take<double>(W * N * 9);
+    V.p_max = n_max / 2 + 1;
+    const size_t PM = V.p_max;
+    V.csol = A.take<double>(W * N * 171);
+    V.cL = A.take<double>(W * PM * 171); V.cR = A.take<double>(W * PM * 171);
+    V.rXs = A.take<double>(W * PM * 81); V.rzs = A.take<double>(W * PM * 9); V.rx = A.take<double>(W * PM * 9);
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
+    {   // solver choice: many windows supply their own parallelism; otherwise cut the chain into ~sqrt(n) chunks
+        int cs = (int)std::ceil(std::sqrt((double)n_max));
+        cs = std::min(std::max(cs, 2), 60);
+        V.chunk = (windows >= 128 || n_max < 8) ? 0 : cs;
+    }
     if (A.used > A.size) {
         hipFree(A.base);
         delete h;
@@ -221,10 +233,21 @@ int vba_destroy(vba_handle h) {
     return VBA_OK;
 }
 
-int vba_set_stream(vba_handle h, void* hip_stream) {
+int vba_set_solver(vba_handle h, int chunk) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (chunk < 0) {
+        int cs = (int)std::ceil(std::sqrt((double)h->n_max));
+        chunk = (h->W >= 128 || h->n_max < 8) ? 0 : std::min(std::max(cs, 2), 60);
+    }
+    if (chunk == 1 || chunk > 60) return fail(VBA_EINVAL, "chunk must be 0 (sequential) or in [2, 60]");
+    h->V.chunk = chunk;
+    return VBA_OK;
+}
+
+int vba_set_stream(vba_handle h, void* hip_stream, int external) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     hipStreamSynchronize(h->stream);
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = external ? (hipStream_t)hip_stream : h->own_stream;
     return VBA_OK;
 }
 

@@ -89,6 +89,11 @@ struct DevView {
     double* Xs;                     // [81]  D'^-1 U of the forward sweep
     double* zs;                     // [9]
     double* dpose;                  // [9]
+    // partitioned solve: chunk size (0 = one wave walks the whole chain), separators per window <= p_max
+    int chunk, p_max;
+    double* csol;                   // [W][n_max][19][9]  chunk solutions for the 19 right-hand sides
+    double *cL, *cR;                // [W][p_max][19][9]  L_j / U_j times the neighbouring chunk solutions
+    double *rXs, *rzs, *rx;         // reduced system over the separators, [W][p_max][81 | 9 | 9]
     int nblk_dyn;                   // ceil(n_max / kObsBlock)
     // sharded mode: number of observation rows over all ranks (0 = not sharded) and external key buffer
     int64_t m_total;

@@ -8,10 +8,21 @@
 //              [X_i | z_i] = D'_i^{-1} [U_i | y_i]           (Gauss-Jordan, row pivoting)
 //   backward:  x_{n-1} = z_{n-1},  x_i = z_i - X_i x_{i+1}
 //
-// One wavefront per window walks the chain.  Lane c of the wave owns COLUMN c of the 9 x 19 working matrix
-// [D' | U | y] in 9 registers, so the pivot search is lane-local and a pivot step is 8 broadcasts (v_readlane)
-// plus 8 FMAs per lane.  The lanes that end a step holding X_i are exactly the ones that need it as the
-// D' columns of step i+1, so the two column groups swap roles every step and nothing is shuffled.
+// A wavefront walks a chain.  Lane c owns COLUMN c of the working matrix [D' | U | right-hand sides] in 9
+// registers, so the pivot search is lane-local and a pivot step is 8 broadcasts (v_readlane) plus 8 FMAs
+// per lane; extra right-hand-side columns ride along in otherwise idle lanes.  The lanes that end a step
+// holding X_i are the ones that need it as the D' columns of step i+1, so the two column groups swap roles
+// every step and nothing is shuffled.
+//
+// Two drivers share that step:
+//   * k_solve          one wave per window walks all n blocks (work-optimal; used when many windows are
+//                      batched, the windows supply the parallelism);
+//   * k_solve_chunks / k_solve_reduced / k_solve_recover
+//                      the chain is cut into P chunks separated by single "separator" blocks.  Every chunk is
+//                      eliminated by its own wave with 19 right-hand sides (g and the couplings to its two
+//                      separators), a reduced block-tridiagonal system over the P-1 separators is solved by one
+//                      wave, and the interiors are recovered in parallel: ~ n/P + P sequential block steps
+//                      instead of n.
 #include "vba_device.h"
 #include "vba_launch.h"
 
@@ -24,57 +35,221 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return bits_f64(((unsigned long long)hi << 32) | lo);
 }
 
-// One forward step.  DB = first lane of the D' column group (0 or 9); the U group starts at 9 - DB.
-template <int DB>
-__device__ __forceinline__ void forward_step(const double* blk /*LDS: L,D,U (81 each), g(9)*/, double lam32, double (&a)[9],
-                                             int lane, bool& zero_pivot) {
-    constexpr int UB = 9 - DB;
-    const bool isD = lane >= DB && lane < DB + 9;
-    const bool isU = lane >= UB && lane < UB + 9;
-    const bool isY = lane == 18;
-    const int cc = isD ? lane - DB : (isU ? lane - UB : 0);
+// Lane roles of a forward step.  DB = first lane of the D' group (0 or 9), the U group starts at 9 - DB,
+// right-hand-side columns sit in lanes [18, 18 + NRHS).
+template <int DB, int NRHS>
+struct Roles {
+    static constexpr int UB = 9 - DB;
+    __device__ static bool isD(int lane) { return lane >= DB && lane < DB + 9; }
+    __device__ static bool isU(int lane) { return lane >= UB && lane < UB + 9; }
+    __device__ static bool isR(int lane) { return lane >= 18 && lane < 18 + NRHS; }
+};
+
+// 1/x to ~1 ulp: v_rcp_f64 plus two Newton steps (the full IEEE division sequence is 3x longer and sits on the
+// critical path of every pivot)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+
+// a[] enters holding this lane's column of [X_{i-1} | z_{i-1}] (or zeros), base[] this lane's column of
+// [D_i + lam I | U_i | rhs_i]; on exit a[] holds the column of [I | X_i | z_i].  Lmat (LDS, row major 9x9) is
+// L_i, or null for the first block of a chain.
+//
+// Per pivot the dependent chain is: lane-local tree search for the largest |entry| of the pivot column ->
+// reciprocal of that entry (computed by every lane on its own candidate, only the pivot lane's is used) ->
+// two broadcasts (row index, reciprocal) -> scale -> rank-1 update.  The row swap and the broadcasts of the
+// eight multipliers run beside the reciprocal.
+template <int DB, int NRHS>
+__device__ __forceinline__ void forward_step(const double* Lmat, const double (&base)[9], double (&a)[9], int lane,
+                                             bool& zero_pivot) {
+    using R = Roles<DB, NRHS>;
+    const bool carry = R::isD(lane) || R::isR(lane);
     double xp[9];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) xp[j] = (isD || isY) ? a[j] : 0.0;
-    const double* base = isD ? blk + 81 + cc : (isU ? blk + 162 + cc : blk + 243);
-    const int stride = isY ? 1 : 9;
+    for (int j = 0; j < 9; ++j) xp[j] = carry ? a[j] : 0.0;
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-        double v = (isD || isU || isY) ? base[r * stride] : 0.0;
-        if (isD && r == cc) v += lam32;
+        double v = base[r];
+        if (Lmat) {
 #pragma unroll
-        for (int j = 0; j < 9; ++j) v -= blk[r * 9 + j] * xp[j];   // L_i[r][j], broadcast read
+            for (int j = 0; j < 9; ++j) v -= Lmat[r * 9 + j] * xp[j];   // broadcast LDS read
+        }
         a[r] = v;
     }
-    // Gauss-Jordan with partial pivoting on the D' columns
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
+        const int pl = DB + k;
         constexpr int dummy = 0;
         (void)dummy;
-        const int pl = DB + k;
-        double best = fabs(a[k]);
-        int p = k;
-#pragma unroll
-        for (int r = k + 1; r < 9; ++r) {
-            const double v = fabs(a[r]);
-            if (v > best) { best = v; p = r; }
-        }
-        p = __builtin_amdgcn_readlane(p, pl);
-#pragma unroll
-        for (int r = k + 1; r < 9; ++r) {
-            if (p == r) { const double t = a[k]; a[k] = a[r]; a[r] = t; }
-        }
-        const double piv = readlane_f64(a[k], pl);
-        if (piv == 0.0) zero_pivot = true;
-        a[k] = a[k] / piv;
+        const int cnt = 9 - k;
+        double cv[9], cs[9];
+        int ci[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            if (r != k) {
-                const double f = readlane_f64(a[r], pl);
-                a[r] -= f * a[k];
+            if (r < cnt) { cs[r] = a[k + r]; cv[r] = fabs(cs[r]); ci[r] = k + r; }
+        }
+#pragma unroll
+        for (int step = 1; step < 9; step *= 2) {
+#pragma unroll
+            for (int r = 0; r < 9; r += 2 * step) {
+                if (r + step < cnt) {
+                    const bool take = cv[r + step] > cv[r];       // strict: the lowest row wins a tie
+                    cv[r] = take ? cv[r + step] : cv[r];
+                    cs[r] = take ? cs[r + step] : cs[r];
+                    ci[r] = take ? ci[r + step] : ci[r];
+                }
             }
         }
+        const double inv_l = fast_rcp(cs[0]);
+        const int p = __builtin_amdgcn_readlane(ci[0], pl);
+        const double inv = readlane_f64(inv_l, pl);
+        if (!(fabs(inv) <= 1.79e308)) zero_pivot = true;
+        // row swap k <-> p (p is wave uniform), branch free
+        const double ak = a[k];
+        double nk = ak;
+#pragma unroll
+        for (int r = k + 1; r < 9; ++r) {
+            const bool sel = (p == r);
+            const double ar = a[r];
+            nk = sel ? ar : nk;
+            a[r] = sel ? ak : ar;
+        }
+        double f[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) f[r] = (r != k) ? readlane_f64(a[r], pl) : 0.0;
+        a[k] = nk * inv;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            if (r != k) a[r] -= f[r] * a[k];
+        }
     }
+}
+
+// ================================================================================================== sequential
+// Walks blocks [0, n) of a block-tridiagonal system stored as bands[n][3][81], rhs[n][9]; damping lam32 is
+// added to the diagonal.  Writes the solution to x[n][9].  Xs/zs: scratch [n][81], [n][9] in global memory.
+// block sources: entry e of block i, e in [0,243) = sub|diag|super row major, [243,252) = right-hand side
+struct BandSource {
+    const double* bands;
+    const double* rhs;
+    __device__ double operator()(int i, int e) const { return e < 243 ? bands[(size_t)i * 243 + e] : rhs[(size_t)i * 9 + (e - 243)]; }
+};
+
+#ifdef VBA_STAMPS
+#define VBA_STAMP(k) do { if (stamps && lane == 0) stamps[k] = clock64(); } while (0)
+#else
+#define VBA_STAMP(k) do { } while (0)
+#endif
+
+template <class Src>
+__device__ __forceinline__ void chain_solve(const Src& src, int n, double lam32, double* Xs, double* zs, double* x_out,
+                                            double (*blk)[256], int lane, bool& zero_pivot, long long* stamps = nullptr) {
+    VBA_STAMP(0);
+    double a[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) a[j] = 0.0;
+    double pre[4];
+    auto fetch = [&](int i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q;
+            pre[q] = e < 252 ? src(i, e) : 0.0;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) blk[buf][lane + 64 * q] = pre[q];
+    };
+    auto load_base = [&](const double* b, int db, double (&base)[9]) {
+        const int ub = 9 - db;
+        const bool isD = lane >= db && lane < db + 9, isU = lane >= ub && lane < ub + 9, isY = lane == 18;
+        const int cc = isD ? lane - db : (isU ? lane - ub : 0);
+        const double* p = isD ? b + 81 + cc : (isU ? b + 162 + cc : b + 243);
+        const int stride = isY ? 1 : 9;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = (isD || isU || isY) ? p[r * stride] : 0.0;
+            if (isD && r == cc) v += lam32;
+            base[r] = v;
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const int buf = i & 1;
+        if (i + 1 < n) fetch(i + 1);
+        double base[9];
+        if (buf == 0) {
+            load_base(blk[0], 0, base);
+            forward_step<0, 1>(i > 0 ? blk[0] : nullptr, base, a, lane, zero_pivot);
+        } else {
+            load_base(blk[1], 9, base);
+            forward_step<9, 1>(blk[1], base, a, lane, zero_pivot);
+        }
+        const int ub = buf == 0 ? 9 : 0;    // X_i sits in the U group of this step, z_i in lane 18
+        if (lane >= ub && lane < ub + 9) {
+            double* X = Xs + (size_t)i * 81 + (lane - ub);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) X[r * 9] = a[r];
+        } else if (lane == 18) {
+            double* z = zs + (size_t)i * 9;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) z[r] = a[r];
+        }
+        if (i + 1 < n) stash(buf ^ 1);
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    VBA_STAMP(1);
+    // backward sweep, lane r = row r
+    const int r = lane < 9 ? lane : 0;
+    double x = zs[(size_t)(n - 1) * 9 + r];
+    if (lane < 9) x_out[(size_t)(n - 1) * 9 + r] = x;
+    double Xrow[9], zr = 0.0;
+    auto fetch_row = [&](int i) {
+        const double* X = Xs + (size_t)i * 81 + r * 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) Xrow[j] = X[j];
+        zr = zs[(size_t)i * 9 + r];
+    };
+    if (n > 1) fetch_row(n - 2);
+    for (int i = n - 2; i >= 0; --i) {
+        double cur[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) cur[j] = Xrow[j];
+        double v = zr;
+        if (i > 0) fetch_row(i - 1);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) v -= cur[j] * readlane_f64(x, j);
+        x = v;
+        if (lane < 9) x_out[(size_t)i * 9 + r] = x;
+    }
+    __threadfence_block();
+    __syncthreads();
+    VBA_STAMP(2);
+}
+
+// retraction of poses [lane, lane+64, ...) (BA_filtering.py:56-60); returns true if a non-finite step was seen
+__device__ __forceinline__ bool retract_range(const DevView& V, size_t sb, int n, int first, int stride) {
+    bool bad = false;
+    for (int i = first; i < n; i += stride) {
+        const double* dp = V.dpose + (sb + i) * 9;
+        double d9[9], o[10];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { d9[j] = dp[j]; bad |= !(fabs(d9[j]) <= 1.79e308); }
+        retract(V.states + (sb + i) * 10, d9, o);
+        double* sn = V.states_new + (sb + i) * 10;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) sn[j] = o[j];
+    }
+    return bad;
 }
 
 __global__ __launch_bounds__(64) void k_solve(DevView V) {
@@ -84,9 +259,271 @@ __global__ __launch_bounds__(64) void k_solve(DevView V) {
     if (sc.done) return;
     const int n = V.n[w];
     const int lane = threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const double lam32 = (double)(float)sc.lamda;      // torch.eye() is float32 (BA_filtering.py:54)
+    if (lane == 0) sc.lam32 = lam32;
+    bool zero_pivot = false;
+    const BandSource src{V.bands + sb * 243, V.rhs + sb * 9};
+    chain_solve(src, n, lam32, V.Xs + sb * 81, V.zs + sb * 9, V.dpose + sb * 9, blk, lane, zero_pivot);
+    const bool bad = retract_range(V, sb, n, lane, 64);
+    const unsigned long long anybad = __ballot(bad);
+    if (lane == 0 && (anybad || zero_pivot)) atomicOr(&sc.flags, (anybad ? 2u : 0u) | (zero_pivot ? 4u : 0u));
+}
+
+// ================================================================================================== partitioned
+// chunk c of a window covers blocks [c s, min((c+1) s, n)); its last block is a separator unless c is the last
+// chunk.  s >= 2, so every chunk has at least one interior block.
+__device__ __forceinline__ void chunk_range(int c, int s, int n, int& a, int& b, bool& has_sep) {
+    a = c * s;
+    const int end = min((c + 1) * s, n);        // exclusive
+    has_sep = end < n;
+    b = has_sep ? end - 2 : end - 1;            // last interior block
+}
+
+// Eliminates the interior of one chunk with 19 right-hand sides: column 0 = g, 1..9 = L_a (coupling to the left
+// separator), 10..18 = U_b (coupling to the right separator).  sol[i][col][r] receives T^{-1} of them.
+__global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int w = blockIdx.y, c = blockIdx.x;
+    WinScalars& sc = V.sc[w];
+    if (sc.done) return;
+    const int n = V.n[w];
+    if (c * s >= n) return;
+    int a0, b0;
+    bool has_sep;
+    chunk_range(c, s, n, a0, b0, has_sep);
+    const int len = b0 - a0 + 1;
+    const int lane = threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const double lam32 = (double)(float)sc.lamda;
+    if (c == 0 && lane == 0) sc.lam32 = lam32;
+    double (*blk)[256] = reinterpret_cast<double (*)[256]>(smem);           // [2][256]
+    double* Xb = smem + 512;                                                 // [s][81]
+    double* Zb = Xb + (size_t)s * 81;                                        // [s][19][9]
+    double* Cm = Zb + (size_t)s * 171;                                       // [2][81]: L of the right separator, U of the left one
+    const double* bands = V.bands + sb * 243;
+    const double* rhs = V.rhs + sb * 9;
+    for (int e = lane; e < 162; e += 64) {
+        double v = 0.0;
+        if (e < 81) { if (has_sep) v = bands[(size_t)(b0 + 1) * 243 + e]; }
+        else if (c > 0) v = bands[(size_t)(a0 - 1) * 243 + 162 + (e - 81)];
+        Cm[e] = v;
+    }
+
+    double a[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) a[j] = 0.0;
+    bool zero_pivot = false;
+    double pre[4];
+    auto fetch = [&](int i) {
+        const double* src = bands + (size_t)i * 243;
+        const double* rsrc = rhs + (size_t)i * 9;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q;
+            pre[q] = e < 243 ? src[e] : (e < 252 ? rsrc[e - 243] : 0.0);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) blk[buf][lane + 64 * q] = pre[q];
+    };
+    // lanes: D/U groups in 0..17 (alternating), V = 18..26, W = 27..35, y = 36  -> rhs column order in Zb: y, V, W
+    const bool isV = lane >= 18 && lane < 27, isW = lane >= 27 && lane < 36, isY = lane == 36;
+    const int zcol = isY ? 0 : (isV ? 1 + (lane - 18) : (isW ? 10 + (lane - 27) : 0));
+    auto load_base = [&](const double* b, int db, bool first, bool last, double (&base)[9]) {
+        const int ub = 9 - db;
+        const bool isD = lane >= db && lane < db + 9, isU = lane >= ub && lane < ub + 9;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = 0.0;
+            if (isD) v = b[81 + r * 9 + (lane - db)] + ((r == lane - db) ? lam32 : 0.0);
+            else if (isU) v = b[162 + r * 9 + (lane - ub)];
+            else if (isY) v = b[243 + r];
+            else if (isV && first) v = b[r * 9 + (lane - 18)];           // L_a
+            else if (isW && last) v = b[162 + r * 9 + (lane - 27)];      // U_b
+            base[r] = v;
+        }
+    };
+    fetch(a0);
+    stash(0);
+    __syncthreads();
+    for (int t = 0; t < len; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < len) fetch(a0 + t + 1);
+        double base[9];
+        if (buf == 0) {
+            load_base(blk[0], 0, t == 0, t == len - 1, base);
+            forward_step<0, 19>(t > 0 ? blk[0] : nullptr, base, a, lane, zero_pivot);
+        } else {
+            load_base(blk[1], 9, false, t == len - 1, base);
+            forward_step<9, 19>(blk[1], base, a, lane, zero_pivot);
+        }
+        const int ub = buf == 0 ? 9 : 0;
+        if (lane >= ub && lane < ub + 9) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) Xb[(size_t)t * 81 + r * 9 + (lane - ub)] = a[r];
+        } else if (isV || isW || isY) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) Zb[((size_t)t * 19 + zcol) * 9 + r] = a[r];
+        }
+        if (t + 1 < len) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // backward sweep for the 19 right-hand sides: lane q < 19 owns column q
+    const int col = lane < 19 ? lane : 0;
+    double x[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) x[r] = Zb[((size_t)(len - 1) * 19 + col) * 9 + r];
+    double* out = V.csol + (sb + a0) * 171;
+    if (lane < 19) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) out[((size_t)(len - 1) * 19 + col) * 9 + r] = x[r];
+    }
+    // contribution of this chunk to its right separator j = b+1:  L_j [yhat_b | Vhat_b | What_b]
+    if (has_sep && lane < 19) {
+        double* cl = V.cL + ((size_t)w * V.p_max + c) * 171 + (size_t)col * 9;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v += Cm[r * 9 + k] * x[k];
+            cl[r] = v;
+        }
+    }
+    for (int t = len - 2; t >= 0; --t) {
+        double xn[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = Zb[((size_t)t * 19 + col) * 9 + r];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) v -= Xb[(size_t)t * 81 + r * 9 + j] * x[j];
+            xn[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) x[r] = xn[r];
+        if (lane < 19) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) out[((size_t)t * 19 + col) * 9 + r] = x[r];
+        }
+    }
+    // contribution to the left separator j = a-1:  U_j [yhat_a | Vhat_a | What_a]
+    if (c > 0 && lane < 19) {
+        double* cr = V.cR + ((size_t)w * V.p_max + c - 1) * 171 + (size_t)col * 9;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) v += Cm[81 + r * 9 + k] * x[k];
+            cr[r] = v;
+        }
+    }
+    if (lane == 0 && zero_pivot) atomicOr(&sc.flags, 4u);
+}
+
+// Reduced system over the separators: row q couples separators q-1, q, q+1 (block j = (q+1) s - 1 of the chain):
+//   sub = -L_j Vhat_{j-1},  diag = D_j - L_j What_{j-1} - U_j Vhat_{j+1},  super = -U_j What_{j+1},
+//   rhs = g_j - L_j yhat_{j-1} - U_j yhat_{j+1};   the products were left in cL / cR by the chunk waves.
+struct ReducedSource {
+    const double* bands;    // of the window
+    const double* rhs;
+    const double* cL;       // [ns][19][9]
+    const double* cR;
+    int s;
+    __device__ double operator()(int q, int e) const {
+        const int j = (q + 1) * s - 1;
+        const double* l = cL + (size_t)q * 171;
+        const double* r_ = cR + (size_t)q * 171;
+        if (e >= 243) {
+            const int r = e - 243;
+            return rhs[(size_t)j * 9 + r] - l[r] - r_[r];
+        }
+        const int which = e / 81, r = (e % 81) / 9, cc = e % 9;
+        if (which == 0) return -l[(1 + cc) * 9 + r];
+        if (which == 2) return -r_[(10 + cc) * 9 + r];
+        return bands[(size_t)j * 243 + 81 + r * 9 + cc] - l[(10 + cc) * 9 + r] - r_[(1 + cc) * 9 + r];
+    }
+};
+
+// Solves the reduced block-tridiagonal system over the separators (one wave per window).
+__global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s) {
+    __shared__ double blk[2][256];
+    const int w = blockIdx.x;
+    WinScalars& sc = V.sc[w];
+    if (sc.done) return;
+    const int n = V.n[w];
+    const int P = (n + s - 1) / s;
+    const int ns = P - 1;
+    if (ns <= 0) return;
+    const int lane = threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lamda;
+    const ReducedSource src{V.bands + sb * 243, V.rhs + sb * 9, V.cL + rb * 171, V.cR + rb * 171, s};
+    bool zero_pivot = false;
+    chain_solve(src, ns, lam32, V.rXs + rb * 81, V.rzs + rb * 9, V.rx + rb * 9, blk, lane, zero_pivot);
+    if (lane == 0 && zero_pivot) atomicOr(&sc.flags, 4u);
+}
+
+// x_i = yhat_i - Vhat_i x_left - What_i x_right for interior blocks, separators copied; then the retraction.
+__global__ __launch_bounds__(64) void k_solve_recover(DevView V, int s) {
+    const int w = blockIdx.y;
+    WinScalars& sc = V.sc[w];
+    if (sc.done) return;
+    const int n = V.n[w];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const size_t rb = (size_t)w * V.p_max;
+    bool bad = false;
+    if (i < n) {
+        const int c = i / s;
+        const int P = (n + s - 1) / s;
+        const bool is_sep = (c < P - 1) && (i == (c + 1) * s - 1);
+        double d9[9];
+        if (is_sep) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) d9[r] = V.rx[(rb + c) * 9 + r];
+        } else {
+            const double* so = V.csol + (sb + i) * 171;
+            double xl[9], xr[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                xl[r] = c > 0 ? V.rx[(rb + c - 1) * 9 + r] : 0.0;
+                xr[r] = c < P - 1 ? V.rx[(rb + c) * 9 + r] : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                double v = so[r];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) v -= so[(1 + k) * 9 + r] * xl[k] + so[(10 + k) * 9 + r] * xr[k];
+                d9[r] = v;
+            }
+        }
+        double o[10];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) { V.dpose[(sb + i) * 9 + r] = d9[r]; bad |= !(fabs(d9[r]) <= 1.79e308); }
+        retract(V.states + (sb + i) * 10, d9, o);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) V.states_new[(sb + i) * 10 + r] = o[r];
+    }
+    const unsigned long long anybad = __ballot(bad);
+    if (threadIdx.x == 0 && anybad) atomicOr(&sc.flags, 2u);
+}
+
+// ================================================================================================== accept test
+// LM accept test (BA_filtering.py:51, 66-79).  ranks == 0: sum this window's block partials; ranks > 0: the
+// observation part is the rank-ordered sum of the gathered per-rank sums (sharded mode).
+__global__ __launch_bounds__(64) void k_decide(DevView V, const double* trial_all, int ranks) {
+    const int w = blockIdx.x;
+    WinScalars& sc = V.sc[w];
+    if (sc.done) return;
+    const int n = V.n[w];
+    const int lane = threadIdx.x;
     const StepParams prm = *V.prm;
     const size_t sb = (size_t)w * V.n_max;
-
+    const double M = V.m_total ? (double)V.m_total : (double)V.m[w];
+    const double denom = 2.0 * M + (prm.initialize ? 6.0 : 7.0) * (double)(n - 1);
+    double init_residual = sc.init_residual;
     if (sc.n_trials == 0) {
         // init_residual = mean |[r_obs ; sqrt(Sigma) r_pred]| with UNweighted r_obs (BA_filtering.py:51)
         double so;
@@ -106,119 +543,13 @@ __global__ __launch_bounds__(64) void k_solve(DevView V) {
             }
             sp = wave_sum(sp) * prm.sqrt_sigma;
         }
-        const double M = V.m_total ? (double)V.m_total : (double)V.m[w];
-        const double denom = 2.0 * M + (prm.initialize ? 6.0 : 7.0) * (double)(n - 1);
+        init_residual = (so + sp) / denom;
         if (lane == 0) {
             sc.sum_abs_robs = so;
             sc.sum_abs_rpred = sp;
-            sc.init_residual = (so + sp) / denom;
+            sc.init_residual = init_residual;
         }
     }
-
-    const double lam32 = (double)(float)sc.lamda;      // torch.eye() is float32 (BA_filtering.py:54)
-    if (lane == 0) sc.lam32 = lam32;
-
-    // ------------------------------------------------------------------ forward sweep
-    double a[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j) a[j] = 0.0;
-    bool zero_pivot = false;
-    double pre[4];
-    auto fetch = [&](int i) {
-        const double* src = V.bands + (sb + i) * 243;
-        const double* rsrc = V.rhs + (sb + i) * 9;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = lane + 64 * q;
-            pre[q] = e < 243 ? src[e] : (e < 252 ? rsrc[e - 243] : 0.0);
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) blk[buf][lane + 64 * q] = pre[q];
-    };
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int i = 0; i < n; ++i) {
-        const int buf = i & 1;
-        if (i + 1 < n) fetch(i + 1);
-        if (buf == 0) forward_step<0>(blk[0], lam32, a, lane, zero_pivot);
-        else forward_step<9>(blk[1], lam32, a, lane, zero_pivot);
-        // columns of X_i sit in the U group of this step, z_i in lane 18
-        const int ub = buf == 0 ? 9 : 0;
-        if (lane >= ub && lane < ub + 9) {
-            double* X = V.Xs + (sb + i) * 81 + (lane - ub);
-#pragma unroll
-            for (int r = 0; r < 9; ++r) X[r * 9] = a[r];
-        } else if (lane == 18) {
-            double* z = V.zs + (sb + i) * 9;
-#pragma unroll
-            for (int r = 0; r < 9; ++r) z[r] = a[r];
-        }
-        if (i + 1 < n) stash(buf ^ 1);
-        __syncthreads();
-    }
-    __threadfence_block();
-    __syncthreads();
-
-    // ------------------------------------------------------------------ backward sweep (lane r = row r)
-    const int r = lane < 9 ? lane : 0;
-    double x = V.zs[(sb + n - 1) * 9 + r];
-    if (lane < 9) V.dpose[(sb + n - 1) * 9 + r] = x;
-    double Xrow[9], zr;
-    auto fetch_row = [&](int i) {
-        const double* X = V.Xs + (sb + i) * 81 + r * 9;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) Xrow[j] = X[j];
-        zr = V.zs[(sb + i) * 9 + r];
-    };
-    if (n > 1) fetch_row(n - 2);
-    for (int i = n - 2; i >= 0; --i) {
-        double cur[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) cur[j] = Xrow[j];
-        double v = zr;
-        if (i > 0) fetch_row(i - 1);
-#pragma unroll
-        for (int j = 0; j < 9; ++j) v -= cur[j] * readlane_f64(x, j);
-        x = v;
-        if (lane < 9) V.dpose[(sb + i) * 9 + r] = x;
-    }
-    __threadfence_block();
-    __syncthreads();
-
-    // ------------------------------------------------------------------ retraction (BA_filtering.py:56-60)
-    bool bad = false;
-    for (int i = lane; i < n; i += 64) {
-        const double* dp = V.dpose + (sb + i) * 9;
-        double d9[9], o[10];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) { d9[j] = dp[j]; bad |= !(fabs(d9[j]) <= 1.79e308); }
-        retract(V.states + (sb + i) * 10, d9, o);
-        double* sn = V.states_new + (sb + i) * 10;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) sn[j] = o[j];
-    }
-    const unsigned long long anybad = __ballot(bad);
-    if (lane == 0) {
-        unsigned f = sc.flags;
-        if (anybad) f |= 2u;
-        if (zero_pivot) f |= 4u;
-        sc.flags = f;
-    }
-}
-
-// LM accept test (BA_filtering.py:66-79).  ranks == 0: sum this window's block partials; ranks > 0: the
-// observation part is the rank-ordered sum of the gathered per-rank sums (sharded mode).
-__global__ __launch_bounds__(64) void k_decide(DevView V, const double* trial_all, int ranks) {
-    const int w = blockIdx.x;
-    WinScalars& sc = V.sc[w];
-    if (sc.done) return;
-    const int n = V.n[w];
-    const int lane = threadIdx.x;
-    const StepParams prm = *V.prm;
-    const size_t sb = (size_t)w * V.n_max;
     double S;
     if (ranks > 0) {
         S = trial_all[1];
@@ -229,18 +560,17 @@ __global__ __launch_bounds__(64) void k_decide(DevView V, const double* trial_al
         for (int b = lane; b < V.nblk_obs + V.nblk_dyn; b += 64) s += pt[b];
         S = wave_sum(s);
     }
-    const double M = V.m_total ? (double)V.m_total : (double)V.m[w];
-    const double denom = 2.0 * M + (prm.initialize ? 6.0 : 7.0) * (double)(n - 1);
     const double residual = S / denom;
     const double lam = sc.lamda * 10.0;
-    const bool accept = residual < sc.init_residual;
+    const double lam32 = sc.lam32;
+    const bool accept = residual < init_residual;
     const bool stop = accept || lam > 1e4;
     if (stop) {
         const double* s_new = V.states_new + sb * 10;
         double* s_cur = V.states + sb * 10;
         for (int k = lane; k < n * 10; k += 64) s_cur[k] = s_new[k];
         const double* D = V.bands + (sb + n - 1) * 243 + 81;
-        for (int k = lane; k < 81; k += 64) sc.last_hessian[k] = D[k] + ((k / 9 == k % 9) ? sc.lam32 : 0.0);
+        for (int k = lane; k < 81; k += 64) sc.last_hessian[k] = D[k] + ((k / 9 == k % 9) ? lam32 : 0.0);
     }
     if (lane == 0) {
         sc.trial_residual = residual;
@@ -256,7 +586,24 @@ __global__ __launch_bounds__(64) void k_decide(DevView V, const double* trial_al
     }
 }
 
-void launch_solve(const DevView& V, hipStream_t s) { hipLaunchKernelGGL(k_solve, dim3(V.W), dim3(64), 0, s, V); }
+void launch_solve(const DevView& V, hipStream_t s) {
+    if (V.chunk <= 0) {
+        hipLaunchKernelGGL(k_solve, dim3(V.W), dim3(64), 0, s, V);
+        return;
+    }
+    const int cs = V.chunk;
+    const int P = (V.n_max + cs - 1) / cs;
+    const size_t lds = (512 + (size_t)cs * 81 + (size_t)cs * 171 + 162) * sizeof(double);
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {     // chunks above ~30 poses need more than the default 64 KiB of dynamic LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((512 + 60 * 252 + 162) * sizeof(double)));
+        lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(k_solve_chunks, dim3(P, V.W), dim3(64), lds, s, V, cs);
+    hipLaunchKernelGGL(k_solve_reduced, dim3(V.W), dim3(64), 0, s, V, cs);
+    hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, cs);
+}
 
 void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStream_t s) {
     hipLaunchKernelGGL(k_decide, dim3(V.W), dim3(64), 0, s, V, trial_all, ranks);

@@ -39,7 +39,7 @@ class HipStageEngine:
         self.torch = torch
         from ._lib import check
         self._check = check
-        check(self.lib.vba_set_stream(eng.h, torch.cuda.current_stream().cuda_stream), self.lib)
+        check(self.lib.vba_set_stream(eng.h, torch.cuda.current_stream().cuda_stream, 1), self.lib)
 
     def partial_count(self, n):
         return int(self.lib.vba_sh_partial_count(int(n)))
@@ -70,7 +70,7 @@ class HipStageEngine:
         return self.eng.get_states()
 
     def close(self):
-        self.lib.vba_set_stream(self.eng.h, None)
+        self.lib.vba_set_stream(self.eng.h, None, 0)
         self.eng.close()
 
 

@@ -46,6 +46,10 @@ class BAEngine:
         except Exception:
             pass
 
+    def set_solver(self, chunk):
+        """0 = sequential chain, 2..60 = partitioned with that chunk size, <0 = default."""
+        _lib.check(self.lib.vba_set_solver(self.h, int(chunk)), self.lib)
+
     # ------------------------------------------------------------------ uploads
     def upload_observations(self, landmarks_xyz, landmarks_uv, confidences, ii, n, window=0):
         xyz, uv, conf, ii = _f64(landmarks_xyz).reshape(-1, 3), _f64(landmarks_uv).reshape(-1, 2), _f64(confidences).reshape(-1), _i64(ii).reshape(-1)
