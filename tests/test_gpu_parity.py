@@ -410,3 +410,31 @@ def test_sharded_stage_kernels_on_one_gpu(c2, ranks):
     for e in engs:
         e.close()
     single.close()
+
+
+def test_median_with_massive_ties_and_signed_zero():
+    """All residuals identical (and a block of exact zeros): the radix select must still return the exact lower
+    median; exercises the compaction-list overflow path of the select."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    det, orb = synth.make_sequence(synth.WindowConfig("ties", 16, 40, 5), seed=2)
+    win = od_pipe.prepare_window(det, orb)
+    n, m = win.time_idx.size, win.ii.size
+    st = win.states_gt.copy()
+    # measurements = exact reprojection at these states, shifted by the same offset everywhere -> |r| all equal
+    est = O.landmark_project(st, win.landmarks_xyz, win.intrinsics, win.ii, jacobian=False)
+    for shift in (0.0, 3.0):
+        uv = est + shift
+        eng = BAEngine(n, m)
+        eng.upload_observations(win.landmarks_xyz, uv, win.confidences, win.ii, n)
+        eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+        if shift == 0.0:
+            continue        # c_obs ~ 1e-13: weights overflow in the reference too; only the non-degenerate case is compared
+        out, lam, hess, ntr, flags = eng.iterate(3, True, 1e-4, st)
+        sc = eng.debug("scalars")
+        a = np.abs(uv - eng.debug("est")).reshape(-1)
+        assert sc[0] == np.sort(a)[(a.size - 1) // 2]
+        ref = O.ba_iteration(3, st, win.cumrot_last, uv, win.landmarks_xyz, win.ii, win.time_idx, win.intrinsics,
+                             win.confidences, 1e-4, initialize=True)
+        assert ntr == ref[3] and rel_err(out, ref[0]) < 1e-7
+        eng.close()

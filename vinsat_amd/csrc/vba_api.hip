@@ -151,7 +151,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     need(W * M * 4); need(W * (N + 1) * 4);
     need(W * N * 10 * 8); need(W * N * 10 * 8); need(W * N * 10 * 8);
     need(W * N * 4 * 8); need(W * N * 4 * 8); need(W * N * 4);
-    need(W * 2 * M * 8); need(W * M * 8); need(W * nblk_obs * 8); need(W * (nblk_obs + nblk_dyn) * 8);
+    need(W * 2 * M * 8); need(W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * (nblk_obs + nblk_dyn) * 8);
     need(W * kSelPasses * kSelBins * 4);
     const size_t per_pose = 21 + 6 + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
     need(W * N * per_pose * 8 + 16 * 256);
@@ -179,7 +179,14 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.intr = h->d_intr = A.take<double>(W * N * 4);
     V.cumrot = h->d_cumrot = A.take<double>(W * N * 4);
     V.steps = h->d_steps = A.take<int>(W * N);
-    V.absr = A.take<double>(W * 2 * M); V.wraw = A.take<double>(W * M);
+    V.absr = A.take<double>(W * 2 * M); V.wraw = A.take<double>(W * M); V.ckeys = A.take<double>(W * 2 * M);
+    {   // lanes per pose of the accumulation kernel: about 12 observations per lane at the handle's capacity
+        // ratio (a function of the handle geometry only, so results do not depend on what else is batched)
+        const double avg = (double)m_max / (double)n_max;
+        int G = 4;
+        while (G < 64 && avg / G > 12.0) G *= 2;
+        V.acc_lanes = G;
+    }
     V.part_init = A.take<double>(W * nblk_obs); V.part_trial = A.take<double>(W * (nblk_obs + nblk_dyn));
     V.hist = A.take<unsigned>(W * kSelPasses * kSelBins);
     V.Hraw = A.take<double>(W * N * 21); V.braw = A.take<double>(W * N * 6);

@@ -13,7 +13,6 @@ constexpr int kObsBlock = 256;          // threads per block of the per-observat
 constexpr int kSelItems = 8;            // keys per thread per radix-select pass
 constexpr int kSelPasses = 6;           // 63 key bits = 10 + 11 + 11 + 11 + 11 + 9
 constexpr int kSelBins = 2048;
-constexpr int kPosesPerAccBlock = 4;    // one wave per pose in the accumulation kernel
 constexpr int kDynLanes = 8;            // lanes per pose in the dynamics kernel (6 tangents + attitude + spare)
 
 __host__ __device__ constexpr int sel_shift(int p) { return p == 0 ? 53 : p == 1 ? 42 : p == 2 ? 31 : p == 3 ? 20 : p == 4 ? 9 : 0; }
@@ -42,7 +41,7 @@ struct WinScalars {
     int done;
     int n_trials;
     unsigned flags;
-    int pad;
+    unsigned sel_cnt;               // keys appended to the compacted select list
     unsigned long long sel_prefix[kSelPasses + 1];
     long long sel_rank[kSelPasses + 1];
     double last_hessian[81];
@@ -71,6 +70,8 @@ struct DevView {
     // work
     double* absr;                   // [W][2 m_max]  |r| components
     double* wraw;                   // [W][m_max]    raw robust weight
+    double* ckeys;                  // [W][2 m_max]  keys surviving the first two select digits (usually a handful)
+    int acc_lanes;                  // lanes per pose in k_obs_accumulate (4..64)
     double* part_init;              // [W][nblk_obs] block sums of |r_obs|
     double* part_trial;             // [W][nblk_obs + nblk_dyn]
     unsigned* hist;                 // [W][kSelPasses][kSelBins]

@@ -2,8 +2,11 @@
 //
 //   k_step_begin       reset per-step state
 //   k_obs_residual     A1: reprojection residuals at the input states, |r| keys, sum |r|
-//   k_select_pass<P>   A3a: exact lower median of the 2m keys by most-significant-digit radix select
-//   k_obs_accumulate   A2 + A3a + A3b: Jacobian, robust weight, per-pose 6x6 / 6 accumulation (one wave per pose)
+//   k_select_pass<P>   A3a: exact lower median of the 2m keys by most-significant-digit radix select:
+//                      digit 0 (exponent) is histogrammed inside k_obs_residual, digits 1 and 2 read the keys
+//                      once each, the second of them compacting the (few) keys that match the 32 known bits,
+//                      and k_select_final finishes digits 3..5 on that short list in one block
+//   k_obs_accumulate<G> A2 + A3a + A3b: Jacobian, robust weight, per-pose 6x6 / 6 accumulation (G lanes per pose)
 //   k_trial            A8: weighted trial residuals (observations) and dynamics residuals at the trial states
 //   k_debug_project    recompute est / Jacobian at the step's input states for vba_debug_fetch
 //
@@ -29,16 +32,24 @@ __global__ __launch_bounds__(256) void k_step_begin(DevView V) {
         sc.flags = 0u;
         sc.wmax_bits = 0ull;
         sc.sum_abs_rpred = 0.0;
+        sc.sel_cnt = 0u;
     }
 }
 
 // ---------------------------------------------------------------------------------------------- A1
+// HIST0: also histogram the top radix digit (the 10 exponent bits) of the keys this block produced.
+template <bool HIST0>
 __global__ __launch_bounds__(kObsBlock) void k_obs_residual(DevView V, double* abs_out /*null: V.absr*/) {
     __shared__ double red[kObsBlock / 64];
+    __shared__ unsigned lh[HIST0 ? 1024 : 1];
     const int w = blockIdx.y;
     const int m = V.m[w];
     const size_t ob = (size_t)w * V.m_max;
     const int k = blockIdx.x * kObsBlock + threadIdx.x;
+    if (HIST0) {
+        for (int b = threadIdx.x; b < 1024; b += kObsBlock) lh[b] = 0u;
+        __syncthreads();
+    }
     double s = 0.0;
     if (k < m) {
         const int pose = V.opose[ob + k];
@@ -51,13 +62,29 @@ __global__ __launch_bounds__(kObsBlock) void k_obs_residual(DevView V, double* a
         double* ab = abs_out ? abs_out : V.absr + 2 * ob;
         reinterpret_cast<double2*>(ab)[k] = make_double2(ru, rv);
         s = ru + rv;
+        if (HIST0) {
+            atomicAdd(&lh[(unsigned)(f64_bits(ru) >> 53) & 1023u], 1u);
+            atomicAdd(&lh[(unsigned)(f64_bits(rv) >> 53) & 1023u], 1u);
+        }
     }
     const double t = block_sum<kObsBlock>(s, red);
     if (threadIdx.x == 0) V.part_init[(size_t)w * V.nblk_obs + blockIdx.x] = t;
+    if (HIST0) {
+        unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
+        for (int b = threadIdx.x; b < 1024; b += kObsBlock) {
+            const unsigned c = lh[b];
+            if (c) atomicAdd(&hist[b], c);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            V.sc[w].sel_prefix[0] = 0ull;
+            V.sc[w].sel_rank[0] = (2 * (long long)m - 1) / 2;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- A3a: select
-template <int P>
+// COMPACT: additionally append the keys that match the digits known so far to the short list V.ckeys.
+template <int P, bool COMPACT>
 __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     __shared__ unsigned lh[kSelBins];
     __shared__ unsigned lds_u[260];
@@ -90,6 +117,23 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
             bool match = true;
             if (P > 0) match = (key >> sel_shift(P > 0 ? P - 1 : 0)) == prefix;
             if (match) atomicAdd(&lh[(unsigned)(key >> sel_shift(P)) & (nbins - 1)], 1u);
+            if (COMPACT) {
+                // wave-aggregated append: one atomic per wave instruction
+                const unsigned long long mask = __ballot(match);
+                if (mask) {
+                    const int lane = threadIdx.x & 63;
+                    const int leader = __ffsll((long long)mask) - 1;
+                    unsigned base = 0;
+                    if (lane == leader) base = atomicAdd(&V.sc[w].sel_cnt, (unsigned)__popcll(mask));
+                    base = __shfl(base, leader, kWave);
+                    if (match) {
+                        const unsigned off = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                        // the list has room for 2 m_max keys; if more match (massive ties) k_select_final sees
+                        // sel_cnt > capacity and rescans the full key array instead
+                        if ((int64_t)base + off < 2 * V.m_max) V.ckeys[2 * (size_t)w * V.m_max + base + off] = keys[idx];
+                    }
+                }
+            }
         }
     }
     __syncthreads();
@@ -99,44 +143,77 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------- A2 + A3
-// One wave per pose: lanes stride over the pose's observation segment, accumulate the 21 + 6 unique entries of
-// sum(w J^T J), sum(w J^T r) in registers, then a fixed-shape xor butterfly gives every lane the totals
-// (bit-reproducible: no float atomics).  The raw (un-normalised) weight is kept per observation for the trials.
-__global__ __launch_bounds__(64 * kPosesPerAccBlock) void k_obs_accumulate(DevView V) {
+// Finishes the select on the compacted list (keys whose top 32 bits are known to match): digits 3, 4, 5 with a
+// block-local histogram each, then publishes c_obs.  One block per window.
+__global__ __launch_bounds__(256) void k_select_final(DevView V) {
+    __shared__ unsigned lh[kSelBins];
     __shared__ unsigned lds_u[260];
-    __shared__ double wmx[kPosesPerAccBlock];
+    const int w = blockIdx.x;
+    WinScalars& sc = V.sc[w];
+    unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
+    unsigned long long prefix;
+    long long rank;
+    select_resolve(hist + 2 * kSelBins, 1 << sel_width(2), sel_width(2), sc.sel_prefix[2], sc.sel_rank[2], prefix, rank, lds_u);
+    unsigned cnt = sc.sel_cnt;
+    const double* ck = V.ckeys + 2 * (size_t)w * V.m_max;
+    if ((int64_t)cnt > 2 * V.m_max) {       // list overflowed: fall back to the full key array
+        ck = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
+        cnt = (unsigned)(V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w]);
+    }
+#pragma unroll
+    for (int P = 3; P < 6; ++P) {
+        const int nbins = 1 << sel_width(P);
+        for (int b = threadIdx.x; b < kSelBins; b += 256) lh[b] = 0u;
+        __syncthreads();
+        for (unsigned q = threadIdx.x; q < cnt; q += 256) {
+            const unsigned long long key = f64_bits(ck[q]);
+            if ((key >> sel_shift(P - 1)) == prefix) atomicAdd(&lh[(unsigned)(key >> sel_shift(P)) & (nbins - 1)], 1u);
+        }
+        __syncthreads();
+        unsigned long long np;
+        long long nr;
+        select_resolve(lh, nbins, sel_width(P), prefix, rank, np, nr, lds_u);
+        prefix = np;
+        rank = nr;
+    }
+    if (threadIdx.x == 0) sc.c_obs = bits_f64(prefix);
+}
+
+// ---------------------------------------------------------------------------------------------- A2 + A3
+// G lanes per pose (power of two): every lane strides over its share of the pose's observation segment and
+// keeps the 21 + 6 unique entries of sum(w J^T J), sum(w J^T r) in registers; a log2(G)-step xor butterfly
+// then gives the lanes of the group the totals.  The shape of the reduction is fixed, so results are bit
+// reproducible (no float atomics).  The raw (un-normalised) weight is stored per observation for the trials.
+template <int G>
+__global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
+    __shared__ double wmx[4];
+    constexpr int PPB = 256 / G;            // poses per block
     const int w = blockIdx.y;
     const int n = V.n[w];
-    if (blockIdx.x * kPosesPerAccBlock >= n) return;
+    if (blockIdx.x * PPB >= n) return;
     WinScalars& sc = V.sc[w];
-    unsigned long long keybits;
-    long long rk;
-    select_resolve(V.hist + ((size_t)w * kSelPasses + 5) * kSelBins, 1 << sel_width(5), sel_width(5), sc.sel_prefix[5],
-                   sc.sel_rank[5], keybits, rk, lds_u);
     const StepParams prm = *V.prm;
     RobustParams rp;
-    rp.c = bits_f64(keybits);
+    rp.c = sc.c_obs;
     rp.inv_c2 = 1.0 / (rp.c * rp.c);
     rp.am2 = prm.am2;
     rp.expo = prm.expo;
     rp.alpha_is_2 = prm.alpha_is_2;
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc.c_obs = rp.c;
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i = blockIdx.x * kPosesPerAccBlock + wv;
+    const int sub = threadIdx.x % G;
+    const int i = blockIdx.x * PPB + threadIdx.x / G;
     double wmax_l = 0.0;
+    double acc[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+    const size_t pb = (size_t)w * V.n_max + (i < n ? i : 0);
+    const size_t ob = (size_t)w * V.m_max;
     if (i < n) {
-        const size_t pb = (size_t)w * V.n_max + i;
-        const size_t ob = (size_t)w * V.m_max;
         PoseCam pc;
         pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
         const int* ptr = V.pose_ptr + (size_t)w * (V.n_max + 1);
         const int beg = ptr[i], end = ptr[i + 1];
-        double acc[27];
-#pragma unroll
-        for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-        for (int k = beg + lane; k < end; k += 64) {
+        for (int k = beg + sub; k < end; k += G) {
             double u, v, cam[3], d, J[12];
             project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
             project_jacobian(pc, cam, d, J);
@@ -154,21 +231,25 @@ __global__ __launch_bounds__(64 * kPosesPerAccBlock) void k_obs_accumulate(DevVi
                 acc[21 + a] += ja * ru + jb * rv;
             }
         }
+    }
 #pragma unroll
-        for (int q = 0; q < 27; ++q) acc[q] = wave_sum(acc[q]);
-        wmax_l = wave_max(wmax_l);
+    for (int off = G / 2; off > 0; off >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 27; ++q) acc[q] += shfl_xor_f64(acc[q], off);
+    }
+    if (i < n) {
         double* H = V.Hraw + pb * 21;
         double* B = V.braw + pb * 6;
 #pragma unroll
-        for (int q = 0; q < 21; ++q) if (lane == q) H[q] = acc[q];
+        for (int q = 0; q < 21; ++q) if (q % G == sub) H[q] = acc[q];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) if (lane == 21 + q) B[q] = acc[21 + q];
+        for (int q = 0; q < 6; ++q) if ((21 + q) % G == sub) B[q] = acc[21 + q];
     }
-    if (lane == 0) wmx[wv] = wmax_l;
+    wmax_l = wave_max(wmax_l);
+    if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = wmax_l;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double mx = 0.0;
-        for (int q = 0; q < kPosesPerAccBlock; ++q) mx = fmax(mx, wmx[q]);
+        const double mx = fmax(fmax(wmx[0], wmx[1]), fmax(wmx[2], wmx[3]));
         atomicMax(&sc.wmax_bits, f64_bits(mx));     // positive doubles order like their bit patterns
     }
 }
@@ -238,24 +319,32 @@ __global__ __launch_bounds__(kObsBlock) void k_debug_project(DevView V, int w, d
 void launch_step_begin(const DevView& V, hipStream_t s) { hipLaunchKernelGGL(k_step_begin, dim3(V.W), dim3(256), 0, s, V); }
 
 void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_obs_residual, dim3(V.nblk_obs, V.W), dim3(kObsBlock), 0, s, V, abs_out);
+    // the exponent histogram is fused only when the keys of this launch are the whole key set (not sharded)
+    if (abs_out) hipLaunchKernelGGL(k_obs_residual<false>, dim3(V.nblk_obs, V.W), dim3(kObsBlock), 0, s, V, abs_out);
+    else hipLaunchKernelGGL(k_obs_residual<true>, dim3(V.nblk_obs, V.W), dim3(kObsBlock), 0, s, V, abs_out);
 }
 
 void launch_select(const DevView& V, hipStream_t s) {
     const int64_t count = V.abs_all ? V.abs_all_count : 2 * V.m_max;
     const int nb = (int)((count + 256 * kSelItems - 1) / (256 * kSelItems));
     const dim3 g(nb > 0 ? nb : 1, V.W), b(256);
-    hipLaunchKernelGGL(k_select_pass<0>, g, b, 0, s, V);
-    hipLaunchKernelGGL(k_select_pass<1>, g, b, 0, s, V);
-    hipLaunchKernelGGL(k_select_pass<2>, g, b, 0, s, V);
-    hipLaunchKernelGGL(k_select_pass<3>, g, b, 0, s, V);
-    hipLaunchKernelGGL(k_select_pass<4>, g, b, 0, s, V);
-    hipLaunchKernelGGL(k_select_pass<5>, g, b, 0, s, V);
+    if (V.abs_all) hipLaunchKernelGGL((k_select_pass<0, false>), g, b, 0, s, V);   // sharded: digit 0 over the gathered keys
+    hipLaunchKernelGGL((k_select_pass<1, false>), g, b, 0, s, V);
+    hipLaunchKernelGGL((k_select_pass<2, true>), g, b, 0, s, V);
+    hipLaunchKernelGGL(k_select_final, dim3(V.W), dim3(256), 0, s, V);
 }
 
 void launch_obs_accumulate(const DevView& V, hipStream_t s) {
-    const int nb = (V.n_max + kPosesPerAccBlock - 1) / kPosesPerAccBlock;
-    hipLaunchKernelGGL(k_obs_accumulate, dim3(nb, V.W), dim3(64 * kPosesPerAccBlock), 0, s, V);
+    const int G = V.acc_lanes;
+    const int nb = (V.n_max * G + 255) / 256;
+    const dim3 g(nb, V.W), b(256);
+    switch (G) {
+        case 4: hipLaunchKernelGGL(k_obs_accumulate<4>, g, b, 0, s, V); break;
+        case 8: hipLaunchKernelGGL(k_obs_accumulate<8>, g, b, 0, s, V); break;
+        case 16: hipLaunchKernelGGL(k_obs_accumulate<16>, g, b, 0, s, V); break;
+        case 32: hipLaunchKernelGGL(k_obs_accumulate<32>, g, b, 0, s, V); break;
+        default: hipLaunchKernelGGL(k_obs_accumulate<64>, g, b, 0, s, V); break;
+    }
 }
 
 void launch_trial(const DevView& V, hipStream_t s) {
