@@ -72,8 +72,7 @@ def run_steps(eng, st0, nsteps, windows=1):
     for k in range(nsteps):
         it, init = schedule(k)
         if it == 0:
-            for w in range(windows):
-                eng.set_states(st0, 1e-4, window=w)
+            eng.set_states(st0, 1e-4, window=-1 if windows > 1 else 0)
         eng.step(it, init)
 
 
@@ -188,8 +187,7 @@ def main():
         for k in range(20):
             it, init = schedule(k)
             if it == 0:
-                for w in range(W):
-                    be.set_states(st0, 1e-4, window=w)
+                be.set_states(st0, 1e-4, window=-1)
             for name, v in be.step_profiled(it, init).items():
                 if v > 0:
                     bk[name].append(v)

@@ -86,7 +86,9 @@ int vba_set_solver(vba_handle h, int chunk);
 
 /* Observation rows of window `window`: landmarks_xyz [m,3] (ECI km), landmarks (uv) [m,2] px,
  * confidences [m], ii [m] pose index of each row (BA arguments landmarks_xyz, landmarks, confidences, ii:
- * BA_filtering.py:4; ii is int64 as at BA_filtering.py:35).  n is the number of poses the indices refer to. */
+ * BA_filtering.py:4; ii is int64 as at BA_filtering.py:35).  n is the number of poses the indices refer to.
+ * Uploading with a pose count different from the window's current one starts a new window: the other upload
+ * (pose constants / observations) and the states must follow before the next step. */
 int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const double* landmarks_xyz,
                             const double* landmarks_uv, const double* confidences, const int64_t* ii);
 
@@ -96,7 +98,8 @@ int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const do
 int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics, const double* cumrot_last,
                       const int64_t* time_idx);
 
-/* Device-resident state of a window: [n,10] = p(3) q(4, scalar last) v(3); lamda is the LM damping. */
+/* Device-resident state of a window: [n,10] = p(3) q(4, scalar last) v(3); lamda is the LM damping.
+ * window == -1 in vba_set_states gives every window the same states (equal pose counts required). */
 int vba_set_states(vba_handle h, int window, const double* states, double lamda);
 int vba_get_states(vba_handle h, int window, double* states, double* lamda, double* last_hessian /*[81] or NULL*/,
                    int* n_trials /*or NULL*/, unsigned* flags /*or NULL*/);

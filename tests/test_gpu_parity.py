@@ -406,7 +406,7 @@ def test_sharded_stage_kernels_on_one_gpu(c2, ranks):
             assert np.array_equal(o[0], outs[0][0]) and o[1] == outs[0][1]
         assert outs[0][1] == lam_ref
         assert rel_err(outs[0][0], ref) < 1e-9
-        assert rel_err(outs[0][2], hess_ref) < 1e-9
+        assert rel_err(outs[0][2], hess_ref) < 1e-7     # different accumulation tree (handle geometry differs)
     for e in engs:
         e.close()
     single.close()
@@ -438,3 +438,33 @@ def test_median_with_massive_ties_and_signed_zero():
                              win.confidences, 1e-4, initialize=True)
         assert ntr == ref[3] and rel_err(out, ref[0]) < 1e-7
         eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ driver on the GPU
+def test_streaming_driver_two_pass_on_gpu():
+    """The drop-in driver + HIP BA on the two-pass sequence against the reference's own run: 40 BA calls, growing
+    window (12 then 25 poses), a pose without observations, RK4 chains of ~900 steps inside the dynamics kernel."""
+    from vinsat_amd import od_pipe, synth
+    g = load_golden("gap")
+    det, orb = synth.make_two_pass_sequence()
+    rec = []
+    errors, first_det, times = od_pipe.streaming_version(detections=det, orbit_np=orb, record=rec)
+    assert [r["states"].shape[1] for r in rec] == list(g["n_poses_per_call"])
+    for k in range(40):
+        ref = g[f"states_out_{k}"][0]
+        st = rec[k]["states"][0].numpy()
+        assert np.abs(st[:, :3] - ref[:, :3]).max() / np.abs(ref[:, :3]).max() < 1e-6, k
+        assert rel_err(st, ref) < 1e-6, k
+        assert rec[k]["lamda"] == g["lamda_out"][k]
+    assert rel_err(errors.numpy(), g["errors"]) < 1e-5
+    assert int(first_det) == int(g["first_detection"])
+    assert np.array_equal(np.concatenate([np.atleast_1d(t) for t in times]), g["times"])
+
+
+def test_streaming_driver_single_pass_on_gpu(c1):
+    from vinsat_amd import od_pipe, synth
+    det, orb = synth.make_sequence("C1")
+    rec = []
+    errors, first_det, times = od_pipe.streaming_version(detections=det, orbit_np=orb, record=rec)
+    assert rel_err(rec[-1]["states"][0].numpy(), c1["states_out_19"][0]) < 1e-7
+    assert rel_err(errors.numpy(), c1["errors"]) < 1e-6

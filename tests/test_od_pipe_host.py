@@ -47,39 +47,23 @@ def test_streaming_version_single_batch_matches_reference_errors():
     assert np.array_equal(np.concatenate([np.atleast_1d(t) for t in times]), g["times"])
 
 
-def test_batch_cut_and_knots():
-    """Two passes separated by a long gap: knot poses every 1000 s, a cut after >4 contiguous rows and a >200 s gap
-    (reference identify_next_batch_new, od_pipe.py:898-905), dead-reckoning across the gap."""
-    cfg = synth.WindowConfig("gap", 12, 6, 5)
-    det, orb = synth.make_sequence(cfg, seed=4)
-    # second pass 1500 s later on a longer orbit
-    n_sec = 1700
-    traj = synth.integrate_orbit(n_sec)
-    from vinsat_amd import frames
-    orbit = np.zeros((n_sec, 12))
-    orbit[:, :3] = frames.eci_to_ecef(traj[:, :3], np.arange(n_sec)) * 1000.0
-    det2 = det.copy()
-    det2[:, 0] += 1500
-    # re-project the second pass so that it is consistent with the orbit at the later time
-    xe, ye, ze = frames.ecef_to_eci(orbit[:, 0] / 1000, orbit[:, 1] / 1000, orbit[:, 2] / 1000, np.arange(n_sec))
-    pos = np.stack([xe, ye, ze], -1)
-    allrows = []
-    rng = np.random.default_rng(0)
-    for d in (det, det2):
-        fr = d[:, 0].astype(int)
-        sub = orbit[fr, :3] / 1000
-        lat = np.rad2deg(np.arcsin(sub[:, 2] / np.linalg.norm(sub, axis=-1))) + rng.uniform(-1, 1, len(fr))
-        lon = np.rad2deg(np.arctan2(sub[:, 1], sub[:, 0])) + rng.uniform(-1.5, 1.5, len(fr))
-        xyz = frames.latlon_to_eci(lat, lon, d[:, 0])
-        uv = synth.project(pos[fr], frames.nadir_quaternion(pos[fr]), xyz, synth.INTRINSICS)
-        allrows.append(np.stack([d[:, 0], lon, lat, uv[:, 0], uv[:, 1], d[:, 5]], -1))
-    dets = np.concatenate(allrows)
-    win = od_pipe.prepare_window(dets, orbit)
-    assert 1000 in win.time_idx                      # knot pose without observations is kept
-    assert np.all(np.diff(win.ii) >= 0)
+def test_two_pass_sequence_matches_reference_run():
+    """Two passes 1500 s apart: batch cut (od_pipe.py:898-905), a knot pose without observations, dynamics factors
+    over ~900 RK4 steps, dead-reckoning between the batches (BA_utils.py:114-129).  Every one of the reference's
+    40 BA calls, its errors and its time stamps are reproduced (fixture tests/golden/gap.npz)."""
+    g = load_golden("gap")
+    det, orb = synth.make_two_pass_sequence()
+    win = od_pipe.prepare_window(det, orb)
+    assert 1000 in win.time_idx and win.max_gap > 400
     t1, i1, end1 = od_pipe.next_batch(win.ii, win.time_idx, 0)
-    assert not end1 and i1 == 72 and win.time_idx[t1 - 1] == det[-1, 0]
-    t2, i2, end2 = od_pipe.next_batch(win.ii, win.time_idx, i1)
-    assert end2 and i2 == 144
-    errors, first_det, times = od_pipe.streaming_version(detections=dets, orbit_np=orbit, ba=_oracle_ba, num_iters=3)
-    assert torch.isfinite(errors).all() and errors.numel() == sum(len(np.atleast_1d(t)) for t in times)
+    assert (t1, i1, end1) == (12, 72, False)
+    assert od_pipe.next_batch(win.ii, win.time_idx, i1) == (25, 144, True)
+    rec = []
+    errors, first_det, times = od_pipe.streaming_version(detections=det, orbit_np=orb, ba=_oracle_ba, record=rec)
+    assert [r["states"].shape[1] for r in rec] == list(g["n_poses_per_call"])       # integer: exact
+    for k in range(40):
+        assert rel_err(rec[k]["states"][0].numpy(), g[f"states_out_{k}"][0]) < 1e-9, k
+        assert rec[k]["lamda"] == g["lamda_out"][k]
+    assert rel_err(errors.numpy(), g["errors"]) < 1e-6
+    assert int(first_det) == int(g["first_detection"])
+    assert np.array_equal(np.concatenate([np.atleast_1d(t) for t in times]), g["times"])

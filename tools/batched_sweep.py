@@ -24,8 +24,7 @@ def main():
             for k in range(20):
                 it, init = schedule(k)
                 if it == 0:
-                    for w in range(W):
-                        e.set_states(st0, 1e-4, window=w)
+                    e.set_states(st0, 1e-4, window=-1)
                 ms = e.step_profiled(it, init)
                 if rep:
                     for name, v in ms.items():
@@ -34,8 +33,7 @@ def main():
         for k in range(20):
             it, init = schedule(k)
             if it == 0:
-                for w in range(W):
-                    e.set_states(st0, 1e-4, window=w)
+                e.set_states(st0, 1e-4, window=-1)
             e.step(it, init)
         dt = time.perf_counter() - t0
         out = {"W": W, "it_per_s": 20 * W / dt, "ms_per_step": 1e3 * dt / 20,

@@ -193,7 +193,10 @@ class Capture:
 
 
 def run_config(name, od_pipe, baf, full_iters, store_inputs, store_states):
-    det, orbit = synth.make_sequence(name, seed=0)
+    if name == "GAP":
+        det, orbit = synth.make_two_pass_sequence()
+    else:
+        det, orbit = synth.make_sequence(name, seed=0)
     cap = Capture(od_pipe, baf, full_iters)
     cap.install()
     try:
@@ -217,6 +220,7 @@ def run_config(name, od_pipe, baf, full_iters, store_inputs, store_states):
         out["in_poses_gt_eci"] = inp["poses_gt_eci"]
         out["in_velocities"] = inp["velocities"]
     ncall = len(cap.calls)
+    out["n_poses_per_call"] = np.array([c["states_in"].shape[1] for c in cap.calls])
     out["iters"] = np.array([c["iter"] for c in cap.calls])
     out["initialize"] = np.array([c["initialize"] for c in cap.calls])
     out["n_trials"] = np.array([c["n_trials"] for c in cap.calls])
@@ -264,6 +268,7 @@ PLAN = {
     "C2": dict(full_iters=(0, 9, 10, 19), store_inputs=True, store_states="all"),
     "C3": dict(full_iters=(), store_inputs=False, store_states=(0, 9, 10, 14, 19)),
     "C4": dict(full_iters=(), store_inputs=False, store_states=(0, 9, 10, 14, 19)),
+    "GAP": dict(full_iters=(), store_inputs=True, store_states="all"),
 }
 
 

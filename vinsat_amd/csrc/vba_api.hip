@@ -264,7 +264,7 @@ int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const do
     if (!xyz || !uv || !conf || !ii) return fail(VBA_EINVAL, "null observation array");
     if (n < 2 || n > h->n_max) return fail(VBA_EINVAL, "n out of range (need 2 <= n <= n_max)");
     if (m < 1 || m > h->m_max) return fail(VBA_EINVAL, "m out of range (need 1 <= m <= m_max)");
-    if (h->have_win[window] && h->n[window] != n) return fail(VBA_EINVAL, "n differs from the uploaded pose constants");
+    if (h->have_win[window] && h->n[window] != n) { h->have_win[window] = 0; h->have_state[window] = 0; }   // a new window: re-upload its constants
     HIPCHK(hipSetDevice(h->device));
     // stable counting sort by pose: the reference's segment sums run in input order inside a pose
     std::vector<int> ptr(n + 1, 0);
@@ -313,7 +313,7 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
     if (int rc = check_window(h, window)) return rc;
     if (!intrinsics || !cumrot_last || !time_idx) return fail(VBA_EINVAL, "null pose-constant array");
     if (n < 2 || n > h->n_max) return fail(VBA_EINVAL, "n out of range (need 2 <= n <= n_max)");
-    if (h->have_obs[window] && h->n[window] != n) return fail(VBA_EINVAL, "n differs from the uploaded observations");
+    if (h->have_obs[window] && h->n[window] != n) { h->have_obs[window] = 0; h->have_state[window] = 0; }   // a new window: re-upload its rows
     HIPCHK(hipSetDevice(h->device));
     std::vector<int> steps(n);
     for (int i = 0; i + 1 < n; ++i) {
@@ -334,8 +334,26 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
 }
 
 int vba_set_states(vba_handle h, int window, const double* states, double lamda) {
-    if (int rc = check_window(h, window)) return rc;
+    if (!h) return fail(VBA_EINVAL, "null handle");
     if (!states) return fail(VBA_EINVAL, "null states");
+    if (window == -1) {     // the same states for every window (all windows must have the same number of poses)
+        const int n = h->n[0];
+        for (int w = 0; w < h->W; ++w) {
+            if (!h->have_obs[w] && !h->have_win[w]) return fail(VBA_ESTATE, "upload the windows before their states");
+            if (h->n[w] != n) return fail(VBA_EINVAL, "window = -1 needs equal pose counts");
+        }
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->V.states, states, (size_t)n * 80, hipMemcpyHostToDevice));
+        for (int w = 1; w < h->W; ++w)
+            HIPCHK(hipMemcpyAsync(h->V.states + (size_t)w * h->n_max * 10, h->V.states, (size_t)n * 80, hipMemcpyDeviceToDevice, h->stream));
+        std::vector<double> lam(h->W, lamda);
+        HIPCHK(hipMemcpy2DAsync(&h->V.sc[0].lamda, sizeof(WinScalars), lam.data(), 8, 8, h->W, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int w = 0; w < h->W; ++w) h->have_state[w] = 1;
+        return VBA_OK;
+    }
+    if (int rc = check_window(h, window)) return rc;
     if (!h->have_obs[window] && !h->have_win[window]) return fail(VBA_ESTATE, "upload the window before its states");
     HIPCHK(hipSetDevice(h->device));
     const int n = h->n[window];

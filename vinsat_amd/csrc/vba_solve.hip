@@ -513,42 +513,49 @@ __global__ __launch_bounds__(64) void k_solve_recover(DevView V, int s) {
 // ================================================================================================== accept test
 // LM accept test (BA_filtering.py:51, 66-79).  ranks == 0: sum this window's block partials; ranks > 0: the
 // observation part is the rank-ordered sum of the gathered per-rank sums (sharded mode).
-__global__ __launch_bounds__(64) void k_decide(DevView V, const double* trial_all, int ranks) {
+__global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_all, int ranks) {
+    __shared__ double red[4];
+    __shared__ double bc[2];
     const int w = blockIdx.x;
     WinScalars& sc = V.sc[w];
     if (sc.done) return;
     const int n = V.n[w];
-    const int lane = threadIdx.x;
+    const int t = threadIdx.x;
     const StepParams prm = *V.prm;
     const size_t sb = (size_t)w * V.n_max;
     const double M = V.m_total ? (double)V.m_total : (double)V.m[w];
     const double denom = 2.0 * M + (prm.initialize ? 6.0 : 7.0) * (double)(n - 1);
+    const bool first = sc.n_trials == 0;
     double init_residual = sc.init_residual;
-    if (sc.n_trials == 0) {
+    const double lam_in = sc.lamda, lam32 = sc.lam32;
+    if (first) {
         // init_residual = mean |[r_obs ; sqrt(Sigma) r_pred]| with UNweighted r_obs (BA_filtering.py:51)
         double so;
         if (V.m_total == 0) {
             double s = 0.0;
             const double* pi = V.part_init + (size_t)w * V.nblk_obs;
-            for (int b = lane; b < V.nblk_obs; b += 64) s += pi[b];
-            so = wave_sum(s);
+            for (int b = t; b < V.nblk_obs; b += 256) s += pi[b];
+            so = block_sum<256>(s, red);
         } else {
             so = sc.sum_abs_robs;
         }
         double sp = 0.0;
         if (!prm.initialize) {
-            for (int i = lane; i < n - 1; i += 64) {
+            for (int i = t; i < n - 1; i += 256) {
                 const double* ro = V.rorb + (sb + i) * 6;
                 sp += fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]) + fabs(V.fatt[sb + i]);
             }
-            sp = wave_sum(sp) * prm.sqrt_sigma;
+            sp = block_sum<256>(sp, red) * prm.sqrt_sigma;
         }
-        init_residual = (so + sp) / denom;
-        if (lane == 0) {
+        if (t == 0) {
+            init_residual = (so + sp) / denom;
             sc.sum_abs_robs = so;
             sc.sum_abs_rpred = sp;
             sc.init_residual = init_residual;
+            bc[0] = init_residual;
         }
+        __syncthreads();
+        init_residual = bc[0];
     }
     double S;
     if (ranks > 0) {
@@ -557,22 +564,24 @@ __global__ __launch_bounds__(64) void k_decide(DevView V, const double* trial_al
     } else {
         const double* pt = V.part_trial + (size_t)w * (V.nblk_obs + V.nblk_dyn);
         double s = 0.0;
-        for (int b = lane; b < V.nblk_obs + V.nblk_dyn; b += 64) s += pt[b];
-        S = wave_sum(s);
+        for (int b = t; b < V.nblk_obs + V.nblk_dyn; b += 256) s += pt[b];
+        s = block_sum<256>(s, red);
+        if (t == 0) bc[1] = s;
+        __syncthreads();
+        S = bc[1];
     }
     const double residual = S / denom;
-    const double lam = sc.lamda * 10.0;
-    const double lam32 = sc.lam32;
+    const double lam = lam_in * 10.0;
     const bool accept = residual < init_residual;
     const bool stop = accept || lam > 1e4;
     if (stop) {
         const double* s_new = V.states_new + sb * 10;
         double* s_cur = V.states + sb * 10;
-        for (int k = lane; k < n * 10; k += 64) s_cur[k] = s_new[k];
+        for (int k = t; k < n * 10; k += 256) s_cur[k] = s_new[k];
         const double* D = V.bands + (sb + n - 1) * 243 + 81;
-        for (int k = lane; k < 81; k += 64) sc.last_hessian[k] = D[k] + ((k / 9 == k % 9) ? lam32 : 0.0);
+        if (t < 81) sc.last_hessian[t] = D[t] + ((t / 9 == t % 9) ? lam32 : 0.0);
     }
-    if (lane == 0) {
+    if (t == 0) {
         sc.trial_residual = residual;
         sc.n_trials += 1;
         if (stop) {
@@ -606,7 +615,7 @@ void launch_solve(const DevView& V, hipStream_t s) {
 }
 
 void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(V.W), dim3(64), 0, s, V, trial_all, ranks);
+    hipLaunchKernelGGL(k_decide, dim3(V.W), dim3(256), 0, s, V, trial_all, ranks);
 }
 
 }  // namespace vba

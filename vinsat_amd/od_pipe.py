@@ -168,12 +168,16 @@ def next_batch(ii, time_idx, i):
     return int(ii[-1]) + 1, len(ii), True
 
 
-def propagate_between_batches(state, omega, tdiff, duration, rk4_step):
+def propagate_between_batches(state, velocity, omega, tdiff, duration, rk4_step):
     """Dead-reckon the last estimate across a gap (reference ``propagate_dynamics_init``
     BA_utils.py:114-129): ``tdiff`` steps to reach the first new frame, then ``duration``
     more, returning the per-second states from the first new frame on, [duration+1, 10].
+
+    As in the reference the orbit is started from the estimated POSITION but from the ``velocities``
+    tensor the driver carries beside the states (od_pipe.py:1011), which ``BA`` hands back untouched
+    (BA_filtering.py:98) -- not from the velocity inside the state vector.
     """
-    x = np.concatenate([state[:3], state[7:10]])
+    x = np.concatenate([state[:3], velocity])
     q = state[3:7].copy()
     out = []
     for k in range(tdiff + duration):
@@ -231,7 +235,7 @@ def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, dete
             omega = win.omega_gt[time_idx[t_init - 1]:time_idx[t - 1]]
             tdiff = int(time_idx[t_init] - time_idx[t_init - 1])
             duration = int(time_idx[t - 1] - time_idx[t_init])
-            prop = propagate_between_batches(states_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
+            prop = propagate_between_batches(states_t[0, -1].numpy(), vel_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
             sel = time_idx[t_init:t] - time_idx[t_init]
             prop = torch.from_numpy(prop[sel])[None]
             states_t = torch.cat([states_t, prop], dim=1)
@@ -255,7 +259,7 @@ def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, dete
             omega = win.omega_gt[time_idx[t_init - 1]:time_idx[t - 1]]
             tdiff = int(time_idx[t_init] - time_idx[t_init - 1])
             duration = int(time_idx[t - 1] - time_idx[t_init])
-            prop = propagate_between_batches(states_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
+            prop = propagate_between_batches(states_t[0, -1].numpy(), vel_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
             prop = torch.from_numpy(prop[time_idx[t_init:t] - time_idx[t_init]])
             errors.append((prop[:, :3] - poses_gt[t_init:t, :3]).norm(dim=-1))
             times.append(time_idx[-prop.shape[0]:])

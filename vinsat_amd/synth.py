@@ -151,3 +151,38 @@ def make_sequence(cfg: WindowConfig | str, seed: int = 0, pixel_noise: float = 1
     uv = project(p, q, xyz, INTRINSICS) + rng.normal(0.0, pixel_noise, size=(cfg.n_obs, 2))
     det = np.stack([frame_col.astype(np.float64), lon, lat, uv[:, 0], uv[:, 1], np.full(cfg.n_obs, conf)], -1)
     return det, orbit_np
+
+
+def make_two_pass_sequence(n_poses=12, obs_per_pose=6, stride=5, gap=1500, seed=4, pixel_noise=1.0, conf=0.95, tail=140):
+    """Two ground-station-like passes separated by ``gap`` seconds without detections.
+
+    Exercises what a single dense pass does not: the batch cut of the driver (``od_pipe.py:898-905``), knot poses
+    every 1000 s that carry no observation, dynamics factors spanning ~1000 RK4 steps and dead-reckoning between
+    batches.  Returns ``(detections [M,6], orbit_np [N,12])``.
+    """
+    t0 = 10
+    n_sec = t0 + n_poses * stride + gap + n_poses * stride + tail
+    traj = integrate_orbit(n_sec)
+    times = np.arange(n_sec)
+    ecef_km = frames.eci_to_ecef(traj[:, :3], times)
+    orbit_np = np.zeros((n_sec, 12))
+    orbit_np[:, :3] = ecef_km * 1000.0
+    xe, ye, ze = frames.ecef_to_eci(orbit_np[:, 0] / 1000, orbit_np[:, 1] / 1000, orbit_np[:, 2] / 1000, times)
+    pos_eci = np.stack([xe, ye, ze], -1)
+    rng = np.random.default_rng(seed)
+    first = t0 + stride * np.arange(n_poses)
+    frames_t = np.concatenate([first, first + gap])
+    k = obs_per_pose
+    frame_col = np.repeat(frames_t, k)
+    sub = ecef_km[frames_t]
+    sub_lat = np.rad2deg(np.arcsin(sub[:, 2] / np.linalg.norm(sub, axis=-1)))
+    sub_lon = np.rad2deg(np.arctan2(sub[:, 1], sub[:, 0]))
+    m = frame_col.size
+    lat = np.repeat(sub_lat, k) + rng.uniform(-1.2, 1.2, size=m)
+    lon = np.repeat(sub_lon, k) + rng.uniform(-2.0, 2.0, size=m)
+    xyz = frames.latlon_to_eci(lat, lon, frame_col)
+    p = np.repeat(pos_eci[frames_t], k, axis=0)
+    q = np.repeat(frames.nadir_quaternion(pos_eci[frames_t]), k, axis=0)
+    uv = project(p, q, xyz, INTRINSICS) + rng.normal(0.0, pixel_noise, size=(m, 2))
+    det = np.stack([frame_col.astype(np.float64), lon, lat, uv[:, 0], uv[:, 1], np.full(m, conf)], -1)
+    return det, orbit_np
