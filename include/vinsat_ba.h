@@ -84,6 +84,14 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external);
  * (~sqrt(n_max), or 0 for >= 128 windows).  Both give the same answer to rounding. */
 int vba_set_solver(vba_handle h, int chunk);
 
+/* Row pivoting inside the 9x9 diagonal blocks.  always == 0 (default): the blocks are eliminated without row
+ * exchanges (the damped normal equations are positive definite up to a ~1e-6 non-symmetric term) while every pivot
+ * is checked against the diagonal entry it started from; a failed check repeats that solve with pivoting, so the
+ * result is never taken from an unchecked elimination.  always != 0: pivot from the start.
+ * vba_solver_fallbacks reports how many solves were repeated (diagnostic). */
+int vba_set_pivoting(vba_handle h, int always);
+int vba_solver_fallbacks(vba_handle h, int* count);
+
 /* Observation rows of window `window`: landmarks_xyz [m,3] (ECI km), landmarks (uv) [m,2] px,
  * confidences [m], ii [m] pose index of each row (BA arguments landmarks_xyz, landmarks, confidences, ii:
  * BA_filtering.py:4; ii is int64 as at BA_filtering.py:35).  n is the number of poses the indices refer to.

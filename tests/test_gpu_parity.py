@@ -9,26 +9,29 @@ pytestmark = pytest.mark.gpu
 
 
 # solver: -1 = default (chain cut into ~sqrt(n) chunks), 0 = one wave walks the whole chain, 7 = odd chunk size
-@pytest.fixture(scope="module", params=[-1, 0], ids=["partitioned", "sequential"])
+@pytest.fixture(scope="module", params=[(-1, False), (0, False), (-1, True)], ids=["partitioned", "sequential", "partitioned-pivot"])
 def eng_c1(c1, request):
     from vinsat_amd.engine import BAEngine
     inp = golden_inputs(c1)
     n, m = inp["K"].shape[0], inp["xyz"].shape[0]
     e = BAEngine(n, m)
-    e.set_solver(request.param)
+    e.set_solver(request.param[0])
+    e.set_pivoting(request.param[1])
     e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
     e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
     yield e
     e.close()
 
 
-@pytest.fixture(scope="module", params=[-1, 0, 7], ids=["partitioned", "sequential", "chunk7"])
+@pytest.fixture(scope="module", params=[(-1, False), (0, False), (7, False), (-1, True), (0, True)],
+                ids=["partitioned", "sequential", "chunk7", "partitioned-pivot", "sequential-pivot"])
 def eng_c2(c2, request):
     from vinsat_amd.engine import BAEngine
     inp = golden_inputs(c2)
     n, m = inp["K"].shape[0], inp["xyz"].shape[0]
     e = BAEngine(n, m)
-    e.set_solver(request.param)
+    e.set_solver(request.param[0])
+    e.set_pivoting(request.param[1])
     e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
     e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
     yield e
@@ -468,3 +471,36 @@ def test_streaming_driver_single_pass_on_gpu(c1):
     errors, first_det, times = od_pipe.streaming_version(detections=det, orbit_np=orb, record=rec)
     assert rel_err(rec[-1]["states"][0].numpy(), c1["states_out_19"][0]) < 1e-7
     assert rel_err(errors.numpy(), c1["errors"]) < 1e-6
+
+
+def test_unpivoted_fast_path_falls_back_when_a_pivot_check_fails(c2):
+    """Negative confidences make the normal equations indefinite: the positive-definite fast path must notice
+    (pivot check), repeat the solve with row pivoting, and agree with the oracle's LAPACK banded LU."""
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    conf = inp["conf"].copy()
+    conf[inp["ii"] % 3 == 0] = -0.5
+    for solver in (-1, 0):
+        eng = BAEngine(n, m)
+        eng.set_solver(solver)
+        eng.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
+        eng.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+        args = (inp["cumrot"], inp["uv"], inp["xyz"], inp["ii"], inp["time_idx"], inp["K"], conf)
+        st = g["states_out_19"][0]
+        for it, init, lam in ((3, True, 1e-4), (12, False, 1e-2)):
+            ref, lam_ref, hess_ref, ntr_ref = O.ba_iteration(it, st, *args, lam, initialize=init)
+            out, lam_g, hess, ntr, flags = eng.iterate(it, init, lam, st)
+            assert ntr == ntr_ref and lam_g == lam_ref
+            assert rel_err(out, ref) < 1e-6
+        assert eng.solver_fallbacks() >= 2
+        eng.close()
+    # and a healthy window never needs the fallback
+    eng = BAEngine(n, m)
+    eng.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
+    eng.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+    st, lam = g["states0"][0], 1e-4
+    for k in range(20):
+        st, lam, _, ntr, flags = eng.iterate(int(g["iters"][k]), bool(g["initialize"][k]), lam, st)
+    assert eng.solver_fallbacks() == 0
+    eng.close()

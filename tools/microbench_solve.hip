@@ -6,12 +6,15 @@
 #include "../vinsat_amd/csrc/vba_solve.hip"
 
 using namespace vba;
+#ifndef PIVOT_MB
+#define PIVOT_MB false
+#endif
 
 __global__ __launch_bounds__(64) void k_time(const double* bands, const double* rhs, int n, double* Xs, double* zs, double* x, long long* st) {
     __shared__ double blk[2][256];
     bool zp = false;
     const BandSource src{bands, rhs};
-    chain_solve(src, n, 1e-4, Xs, zs, x, blk, threadIdx.x, zp, st);
+    chain_solve<PIVOT_MB, false>(src, n, 1e-4, Xs, zs, x, blk, threadIdx.x, zp, st);
 }
 
 int main() {

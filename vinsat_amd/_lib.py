@@ -24,6 +24,8 @@ SIGNATURES = {
     "vba_destroy": (c_int, [c_void_p]),
     "vba_set_stream": (c_int, [c_void_p, c_void_p, c_int]),
     "vba_set_solver": (c_int, [c_void_p, c_int]),
+    "vba_set_pivoting": (c_int, [c_void_p, c_int]),
+    "vba_solver_fallbacks": (c_int, [c_void_p, POINTER(c_int)]),
     "vba_upload_observations": (c_int, [c_void_p, c_int, c_int, c_int64, PD, PD, PD, PI64]),
     "vba_upload_window": (c_int, [c_void_p, c_int, c_int, PD, PD, PI64]),
     "vba_set_states": (c_int, [c_void_p, c_int, PD, c_double]),

@@ -64,6 +64,8 @@ struct vba_context {
     float last_ms = 0.f;
     bool stepped = false;
     int last_iter = 0, last_init = 0;
+    int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
+    int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
     size_t dbg_cap = 0;
 };
@@ -251,6 +253,18 @@ int vba_set_solver(vba_handle h, int chunk) {
     return VBA_OK;
 }
 
+int vba_set_pivoting(vba_handle h, int always) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    h->pivot_mode = always ? 1 : 0;
+    return VBA_OK;
+}
+
+int vba_solver_fallbacks(vba_handle h, int* count) {
+    if (!h || !count) return fail(VBA_EINVAL, "null argument");
+    *count = h->fallbacks;
+    return VBA_OK;
+}
+
 int vba_set_stream(vba_handle h, void* hip_stream, int external) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     hipStreamSynchronize(h->stream);
@@ -411,8 +425,9 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
     mark(6);
     // LM loop (BA_filtering.py:52-77): lamda 1e-4 .. 1e4 in decades, at most 9 trials
     int rc_out = VBA_OK;
-    for (int trial = 0; trial < 12; ++trial) {
-        launch_solve(V, s);
+    V.pivot = h->pivot_mode;
+    for (int trial = 0; trial < 24; ++trial) {
+        launch_solve(V, initialize, s);
         if (trial == 0) mark(7);
         launch_trial(V, s);
         if (trial == 0) mark(8);
@@ -423,8 +438,16 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
         }
         HIPCHK(hipGetLastError());
         if (int rc = read_heads(h)) { rc_out = rc; break; }
-        bool all = true;
-        for (int w = 0; w < h->W; ++w) all = all && head(h, w)->done;
+        bool all = true, repeat = false;
+        for (int w = 0; w < h->W; ++w) {
+            all = all && head(h, w)->done;
+            repeat = repeat || (head(h, w)->flags & 8u);
+        }
+        if (repeat && !V.pivot) {       // a pivot check failed on the fast path: same trial again with row pivoting
+            V.pivot = 1;
+            h->fallbacks++;
+            continue;
+        }
         if (all) break;
     }
     if (rc_out == VBA_OK) HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
@@ -618,7 +641,8 @@ int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* 
         if (!h->last_init) launch_dynamics(V, s);
         launch_assemble(V, s);
     }
-    launch_solve(V, s);
+    V.pivot = 1;        // sharded mode: every rank must take the same path without a host round trip
+    launch_solve(V, h->last_init, s);
     launch_trial(V, s);
     launch_shard_trial_sum(V, d_trial_local, s);
     HIPCHK(hipGetLastError());

@@ -19,7 +19,7 @@ void launch_dynamics(const DevView& V, hipStream_t s);
 void launch_assemble(const DevView& V, hipStream_t s);
 
 // vba_solve.hip
-void launch_solve(const DevView& V, hipStream_t s);
+void launch_solve(const DevView& V, int initialize, hipStream_t s);
 void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStream_t s);
 
 // vba_shard.hip

@@ -64,9 +64,16 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // reciprocal of that entry (computed by every lane on its own candidate, only the pivot lane's is used) ->
 // two broadcasts (row index, reciprocal) -> scale -> rank-1 update.  The row swap and the broadcasts of the
 // eight multipliers run beside the reciprocal.
-template <int DB, int NRHS>
+// PIVOT = false is the fast path: the damped normal equations are symmetric positive definite up to a ~1e-6
+// relative non-symmetric term, for which elimination without row exchanges is as stable as Cholesky; every
+// pivot is checked against the diagonal entry it started from and a failed check (`bad`) makes the host repeat
+// the solve with PIVOT = true (row pivoting inside the 9x9 block).
+// SPARSE_L: L_i of the assembled system has the pattern [pp 0 pv; 0 rr 0; vp 0 vv] over (position, rotation,
+// velocity) (the orbit factor does not touch the rotation slots and the attitude term touches nothing else),
+// so 45 instead of 81 multiply-adds; not valid for the reduced system.
+template <int DB, int NRHS, bool PIVOT, bool SPARSE_L>
 __device__ __forceinline__ void forward_step(const double* Lmat, const double (&base)[9], double (&a)[9], int lane,
-                                             bool& zero_pivot) {
+                                             bool& bad) {
     using R = Roles<DB, NRHS>;
     const bool carry = R::isD(lane) || R::isR(lane);
     double xp[9];
@@ -77,57 +84,75 @@ __device__ __forceinline__ void forward_step(const double* Lmat, const double (&
         double v = base[r];
         if (Lmat) {
 #pragma unroll
-            for (int j = 0; j < 9; ++j) v -= Lmat[r * 9 + j] * xp[j];   // broadcast LDS read
+            for (int j = 0; j < 9; ++j) {
+                const bool rot_r = (r >= 3 && r < 6), rot_j = (j >= 3 && j < 6);
+                if (!SPARSE_L || rot_r == rot_j) v -= Lmat[r * 9 + j] * xp[j];   // broadcast LDS read
+            }
         }
         a[r] = v;
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int pl = DB + k;
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int cnt = 9 - k;
-        double cv[9], cs[9];
-        int ci[9];
+        double inv;
+        if (PIVOT) {
+            // lane-local tree search for the largest |entry| of the pivot column, reciprocal of that entry
+            // computed by every lane on its own candidate, then two broadcasts (row index, reciprocal)
+            const int cnt = 9 - k;
+            double cv[9], cs[9];
+            int ci[9];
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            if (r < cnt) { cs[r] = a[k + r]; cv[r] = fabs(cs[r]); ci[r] = k + r; }
-        }
+            for (int r = 0; r < 9; ++r) {
+                if (r < cnt) { cs[r] = a[k + r]; cv[r] = fabs(cs[r]); ci[r] = k + r; }
+            }
 #pragma unroll
-        for (int step = 1; step < 9; step *= 2) {
+            for (int step = 1; step < 9; step *= 2) {
 #pragma unroll
-            for (int r = 0; r < 9; r += 2 * step) {
-                if (r + step < cnt) {
-                    const bool take = cv[r + step] > cv[r];       // strict: the lowest row wins a tie
-                    cv[r] = take ? cv[r + step] : cv[r];
-                    cs[r] = take ? cs[r + step] : cs[r];
-                    ci[r] = take ? ci[r + step] : ci[r];
+                for (int r = 0; r < 9; r += 2 * step) {
+                    if (r + step < cnt) {
+                        const bool take = cv[r + step] > cv[r];       // strict: the lowest row wins a tie
+                        cv[r] = take ? cv[r + step] : cv[r];
+                        cs[r] = take ? cs[r + step] : cs[r];
+                        ci[r] = take ? ci[r + step] : ci[r];
+                    }
                 }
             }
-        }
-        const double inv_l = fast_rcp(cs[0]);
-        const int p = __builtin_amdgcn_readlane(ci[0], pl);
-        const double inv = readlane_f64(inv_l, pl);
-        if (!(fabs(inv) <= 1.79e308)) zero_pivot = true;
-        // row swap k <-> p (p is wave uniform), branch free
-        const double ak = a[k];
-        double nk = ak;
+            const double inv_l = fast_rcp(cs[0]);
+            const int p = __builtin_amdgcn_readlane(ci[0], pl);
+            inv = readlane_f64(inv_l, pl);
+            if (!(fabs(inv) <= 1.79e308)) bad = true;
+            const double ak = a[k];
+            double nk = ak;
 #pragma unroll
-        for (int r = k + 1; r < 9; ++r) {
-            const bool sel = (p == r);
-            const double ar = a[r];
-            nk = sel ? ar : nk;
-            a[r] = sel ? ak : ar;
+            for (int r = k + 1; r < 9; ++r) {     // row swap k <-> p (p is wave uniform), branch free
+                const bool sel = (p == r);
+                const double ar = a[r];
+                nk = sel ? ar : nk;
+                a[r] = sel ? ak : ar;
+            }
+            a[k] = nk;
+        } else {
+            // pivot on the diagonal; it must stay a healthy fraction of the diagonal entry it started from
+            if (lane == pl && !(a[k] > 1e-10 * base[k])) bad = true;
+            inv = readlane_f64(fast_rcp(a[k]), pl);
         }
         double f[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) f[r] = (r != k) ? readlane_f64(a[r], pl) : 0.0;
-        a[k] = nk * inv;
+        a[k] = a[k] * inv;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             if (r != k) a[r] -= f[r] * a[k];
         }
     }
+}
+
+// A failed pivot check: with row pivoting it is a numerically singular block (flag 4, result kept as in the
+// reference); without it the host is asked to repeat this solve with pivoting (internal flag 8).
+template <bool PIVOT>
+__device__ __forceinline__ void report_pivot(bool bad, WinScalars& sc, int lane) {
+    const unsigned long long any = __ballot(bad);
+    if (lane == 0 && any) atomicOr(&sc.flags, PIVOT ? 4u : 8u);
 }
 
 // ================================================================================================== sequential
@@ -146,7 +171,7 @@ struct BandSource {
 #define VBA_STAMP(k) do { } while (0)
 #endif
 
-template <class Src>
+template <bool PIVOT, bool SPARSE_L, class Src>
 __device__ __forceinline__ void chain_solve(const Src& src, int n, double lam32, double* Xs, double* zs, double* x_out,
                                             double (*blk)[256], int lane, bool& zero_pivot, long long* stamps = nullptr) {
     VBA_STAMP(0);
@@ -187,10 +212,10 @@ __device__ __forceinline__ void chain_solve(const Src& src, int n, double lam32,
         double base[9];
         if (buf == 0) {
             load_base(blk[0], 0, base);
-            forward_step<0, 1>(i > 0 ? blk[0] : nullptr, base, a, lane, zero_pivot);
+            forward_step<0, 1, PIVOT, SPARSE_L>(i > 0 ? blk[0] : nullptr, base, a, lane, zero_pivot);
         } else {
             load_base(blk[1], 9, base);
-            forward_step<9, 1>(blk[1], base, a, lane, zero_pivot);
+            forward_step<9, 1, PIVOT, SPARSE_L>(blk[1], base, a, lane, zero_pivot);
         }
         const int ub = buf == 0 ? 9 : 0;    // X_i sits in the U group of this step, z_i in lane 18
         if (lane >= ub && lane < ub + 9) {
@@ -252,6 +277,7 @@ __device__ __forceinline__ bool retract_range(const DevView& V, size_t sb, int n
     return bad;
 }
 
+template <bool PIVOT>
 __global__ __launch_bounds__(64) void k_solve(DevView V) {
     __shared__ double blk[2][256];
     const int w = blockIdx.x;
@@ -261,13 +287,17 @@ __global__ __launch_bounds__(64) void k_solve(DevView V) {
     const int lane = threadIdx.x;
     const size_t sb = (size_t)w * V.n_max;
     const double lam32 = (double)(float)sc.lamda;      // torch.eye() is float32 (BA_filtering.py:54)
-    if (lane == 0) sc.lam32 = lam32;
-    bool zero_pivot = false;
+    if (lane == 0) {
+        sc.lam32 = lam32;
+        if (PIVOT) atomicAnd(&sc.flags, ~8u);
+    }
+    bool badp = false;
     const BandSource src{V.bands + sb * 243, V.rhs + sb * 9};
-    chain_solve(src, n, lam32, V.Xs + sb * 81, V.zs + sb * 9, V.dpose + sb * 9, blk, lane, zero_pivot);
+    chain_solve<PIVOT, true>(src, n, lam32, V.Xs + sb * 81, V.zs + sb * 9, V.dpose + sb * 9, blk, lane, badp);
+    report_pivot<PIVOT>(badp, sc, lane);
     const bool bad = retract_range(V, sb, n, lane, 64);
     const unsigned long long anybad = __ballot(bad);
-    if (lane == 0 && (anybad || zero_pivot)) atomicOr(&sc.flags, (anybad ? 2u : 0u) | (zero_pivot ? 4u : 0u));
+    if (lane == 0 && anybad) atomicOr(&sc.flags, 2u);
 }
 
 // ================================================================================================== partitioned
@@ -282,6 +312,7 @@ __device__ __forceinline__ void chunk_range(int c, int s, int n, int& a, int& b,
 
 // Eliminates the interior of one chunk with 19 right-hand sides: column 0 = g, 1..9 = L_a (coupling to the left
 // separator), 10..18 = U_b (coupling to the right separator).  sol[i][col][r] receives T^{-1} of them.
+template <bool PIVOT>
 __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int w = blockIdx.y, c = blockIdx.x;
@@ -296,7 +327,10 @@ __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
     const int lane = threadIdx.x;
     const size_t sb = (size_t)w * V.n_max;
     const double lam32 = (double)(float)sc.lamda;
-    if (c == 0 && lane == 0) sc.lam32 = lam32;
+    if (c == 0 && lane == 0) {
+        sc.lam32 = lam32;
+        if (PIVOT) atomicAnd(&sc.flags, ~8u);
+    }
     double (*blk)[256] = reinterpret_cast<double (*)[256]>(smem);           // [2][256]
     double* Xb = smem + 512;                                                 // [s][81]
     double* Zb = Xb + (size_t)s * 81;                                        // [s][19][9]
@@ -354,10 +388,10 @@ __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
         double base[9];
         if (buf == 0) {
             load_base(blk[0], 0, t == 0, t == len - 1, base);
-            forward_step<0, 19>(t > 0 ? blk[0] : nullptr, base, a, lane, zero_pivot);
+            forward_step<0, 19, PIVOT, true>(t > 0 ? blk[0] : nullptr, base, a, lane, zero_pivot);
         } else {
             load_base(blk[1], 9, false, t == len - 1, base);
-            forward_step<9, 19>(blk[1], base, a, lane, zero_pivot);
+            forward_step<9, 19, PIVOT, true>(blk[1], base, a, lane, zero_pivot);
         }
         const int ub = buf == 0 ? 9 : 0;
         if (lane >= ub && lane < ub + 9) {
@@ -418,7 +452,7 @@ __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
             cr[r] = v;
         }
     }
-    if (lane == 0 && zero_pivot) atomicOr(&sc.flags, 4u);
+    report_pivot<PIVOT>(zero_pivot, sc, lane);
 }
 
 // Reduced system over the separators: row q couples separators q-1, q, q+1 (block j = (q+1) s - 1 of the chain):
@@ -446,6 +480,7 @@ struct ReducedSource {
 };
 
 // Solves the reduced block-tridiagonal system over the separators (one wave per window).
+template <bool PIVOT>
 __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s) {
     __shared__ double blk[2][256];
     const int w = blockIdx.x;
@@ -461,11 +496,12 @@ __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s) {
     const double lam32 = (double)(float)sc.lamda;
     const ReducedSource src{V.bands + sb * 243, V.rhs + sb * 9, V.cL + rb * 171, V.cR + rb * 171, s};
     bool zero_pivot = false;
-    chain_solve(src, ns, lam32, V.rXs + rb * 81, V.rzs + rb * 9, V.rx + rb * 9, blk, lane, zero_pivot);
-    if (lane == 0 && zero_pivot) atomicOr(&sc.flags, 4u);
+    chain_solve<PIVOT, false>(src, ns, lam32, V.rXs + rb * 81, V.rzs + rb * 9, V.rx + rb * 9, blk, lane, zero_pivot);
+    report_pivot<PIVOT>(zero_pivot, sc, lane);
 }
 
 // x_i = yhat_i - Vhat_i x_left - What_i x_right for interior blocks, separators copied; then the retraction.
+// s == 0: dpose already holds the solution (block-diagonal phase), only the retraction is done.
 __global__ __launch_bounds__(64) void k_solve_recover(DevView V, int s) {
     const int w = blockIdx.y;
     WinScalars& sc = V.sc[w];
@@ -476,11 +512,14 @@ __global__ __launch_bounds__(64) void k_solve_recover(DevView V, int s) {
     const size_t rb = (size_t)w * V.p_max;
     bool bad = false;
     if (i < n) {
-        const int c = i / s;
-        const int P = (n + s - 1) / s;
-        const bool is_sep = (c < P - 1) && (i == (c + 1) * s - 1);
+        const int c = s > 0 ? i / s : 0;
+        const int P = s > 0 ? (n + s - 1) / s : 1;
+        const bool is_sep = s > 0 && (c < P - 1) && (i == (c + 1) * s - 1);
         double d9[9];
-        if (is_sep) {
+        if (s == 0) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) d9[r] = V.dpose[(sb + i) * 9 + r];
+        } else if (is_sep) {
 #pragma unroll
             for (int r = 0; r < 9; ++r) d9[r] = V.rx[(rb + c) * 9 + r];
         } else {
@@ -510,6 +549,64 @@ __global__ __launch_bounds__(64) void k_solve_recover(DevView V, int s) {
     if (threadIdx.x == 0 && anybad) atomicOr(&sc.flags, 2u);
 }
 
+// Landmark-only phase (initialize): the dynamics factor is absent (BA_utils.py:463-466), the system is block
+// DIAGONAL and every pose is an independent 9x9 solve; a wave takes PB consecutive poses.
+template <bool PIVOT>
+__global__ __launch_bounds__(64) void k_solve_blockdiag(DevView V, int PB) {
+    __shared__ double blk[2][128];
+    const int w = blockIdx.y;
+    WinScalars& sc = V.sc[w];
+    if (sc.done) return;
+    const int n = V.n[w];
+    const int i0 = blockIdx.x * PB;
+    if (i0 >= n) return;
+    const int lane = threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const double lam32 = (double)(float)sc.lamda;
+    if (blockIdx.x == 0 && lane == 0) {
+        sc.lam32 = lam32;
+        if (PIVOT) atomicAnd(&sc.flags, ~8u);
+    }
+    const int cnt = min(PB, n - i0);
+    bool badp = false;
+    double pre[2];
+    auto fetch = [&](int i) {       // diagonal block (81) + right-hand side (9)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = lane + 64 * q;
+            pre[q] = e < 81 ? V.bands[(sb + i) * 243 + 81 + e] : (e < 90 ? V.rhs[(sb + i) * 9 + (e - 81)] : 0.0);
+        }
+    };
+    fetch(i0);
+    blk[0][lane] = pre[0];
+    blk[0][lane + 64] = pre[1];
+    __syncthreads();
+    for (int t = 0; t < cnt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < cnt) fetch(i0 + t + 1);
+        double base[9], a[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = 0.0;
+            if (lane < 9) v = blk[buf][r * 9 + lane] + (r == lane ? lam32 : 0.0);
+            else if (lane == 18) v = blk[buf][81 + r];
+            base[r] = v;
+            a[r] = 0.0;
+        }
+        forward_step<0, 1, PIVOT, false>(nullptr, base, a, lane, badp);
+        if (lane == 18) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) V.dpose[(sb + i0 + t) * 9 + r] = a[r];
+        }
+        if (t + 1 < cnt) {
+            blk[buf ^ 1][lane] = pre[0];
+            blk[buf ^ 1][lane + 64] = pre[1];
+        }
+        __syncthreads();
+    }
+    report_pivot<PIVOT>(badp, sc, lane);
+}
+
 // ================================================================================================== accept test
 // LM accept test (BA_filtering.py:51, 66-79).  ranks == 0: sum this window's block partials; ranks > 0: the
 // observation part is the rank-ordered sum of the gathered per-rank sums (sharded mode).
@@ -519,6 +616,7 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
     const int w = blockIdx.x;
     WinScalars& sc = V.sc[w];
     if (sc.done) return;
+    if (sc.flags & 8u) return;      // the un-pivoted solve failed its check: the host repeats it with pivoting
     const int n = V.n[w];
     const int t = threadIdx.x;
     const StepParams prm = *V.prm;
@@ -595,9 +693,19 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
     }
 }
 
-void launch_solve(const DevView& V, hipStream_t s) {
+void launch_solve(const DevView& V, int initialize, hipStream_t s) {
+    const bool pv = V.pivot != 0;
+    if (initialize) {       // block diagonal: independent poses
+        const int PB = V.W >= 64 ? 8 : 2;
+        const dim3 g((V.n_max + PB - 1) / PB, V.W);
+        if (pv) hipLaunchKernelGGL(k_solve_blockdiag<true>, g, dim3(64), 0, s, V, PB);
+        else hipLaunchKernelGGL(k_solve_blockdiag<false>, g, dim3(64), 0, s, V, PB);
+        hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, 0);
+        return;
+    }
     if (V.chunk <= 0) {
-        hipLaunchKernelGGL(k_solve, dim3(V.W), dim3(64), 0, s, V);
+        if (pv) hipLaunchKernelGGL(k_solve<true>, dim3(V.W), dim3(64), 0, s, V);
+        else hipLaunchKernelGGL(k_solve<false>, dim3(V.W), dim3(64), 0, s, V);
         return;
     }
     const int cs = V.chunk;
@@ -605,12 +713,18 @@ void launch_solve(const DevView& V, hipStream_t s) {
     const size_t lds = (512 + (size_t)cs * 81 + (size_t)cs * 171 + 162) * sizeof(double);
     static bool lds_attr_set = false;
     if (!lds_attr_set) {     // chunks above ~30 poses need more than the default 64 KiB of dynamic LDS
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((512 + 60 * 252 + 162) * sizeof(double)));
+        const int cap = (int)((512 + 60 * 252 + 162) * sizeof(double));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         lds_attr_set = true;
     }
-    hipLaunchKernelGGL(k_solve_chunks, dim3(P, V.W), dim3(64), lds, s, V, cs);
-    hipLaunchKernelGGL(k_solve_reduced, dim3(V.W), dim3(64), 0, s, V, cs);
+    if (pv) {
+        hipLaunchKernelGGL(k_solve_chunks<true>, dim3(P, V.W), dim3(64), lds, s, V, cs);
+        hipLaunchKernelGGL(k_solve_reduced<true>, dim3(V.W), dim3(64), 0, s, V, cs);
+    } else {
+        hipLaunchKernelGGL(k_solve_chunks<false>, dim3(P, V.W), dim3(64), lds, s, V, cs);
+        hipLaunchKernelGGL(k_solve_reduced<false>, dim3(V.W), dim3(64), 0, s, V, cs);
+    }
     hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, cs);
 }
 

@@ -50,6 +50,15 @@ class BAEngine:
         """0 = sequential chain, 2..60 = partitioned with that chunk size, <0 = default."""
         _lib.check(self.lib.vba_set_solver(self.h, int(chunk)), self.lib)
 
+    def set_pivoting(self, always):
+        """False (default): unpivoted fast path with checked pivots and automatic fallback; True: always pivot."""
+        _lib.check(self.lib.vba_set_pivoting(self.h, int(bool(always))), self.lib)
+
+    def solver_fallbacks(self):
+        c = c_int()
+        _lib.check(self.lib.vba_solver_fallbacks(self.h, byref(c)), self.lib)
+        return c.value
+
     # ------------------------------------------------------------------ uploads
     def upload_observations(self, landmarks_xyz, landmarks_uv, confidences, ii, n, window=0):
         xyz, uv, conf, ii = _f64(landmarks_xyz).reshape(-1, 3), _f64(landmarks_uv).reshape(-1, 2), _f64(confidences).reshape(-1), _i64(ii).reshape(-1)
