@@ -84,6 +84,11 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external);
  * (~sqrt(n_max), or 0 for >= 128 windows).  Both give the same answer to rounding. */
 int vba_set_solver(vba_handle h, int chunk);
 
+/* Lanes per pose of the per-pose accumulation kernel (4, 8, 16, 32 or 64; 0 = choose from the handle geometry:
+ * ~12 observations per lane, more lanes when few windows leave the GPU idle).  The value fixes the shape of the
+ * reduction tree, i.e. results are bit-reproducible for equal settings. */
+int vba_set_accumulate_lanes(vba_handle h, int lanes);
+
 /* Row pivoting inside the 9x9 diagonal blocks.  always == 0 (default): the blocks are eliminated without row
  * exchanges (the damped normal equations are positive definite up to a ~1e-6 non-symmetric term) while every pivot
  * is checked against the diagonal entry it started from; a failed check repeats that solve with pivoting, so the

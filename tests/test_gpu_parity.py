@@ -308,6 +308,7 @@ def test_batched_windows_equal_single_window_runs(c2):
     singles = []
     for w in wins:
         e = BAEngine(n_max, m_max)
+        e.set_accumulate_lanes(8)       # same reduction tree in both runs
         e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, w.time_idx.size)
         e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx)
         e.set_states(od_pipe.initial_guess(w), 1e-4)
@@ -316,6 +317,7 @@ def test_batched_windows_equal_single_window_runs(c2):
         singles.append(e.get_states())
         e.close()
     e = BAEngine(n_max, m_max, windows=3)
+    e.set_accumulate_lanes(8)
     for k, w in enumerate(wins):
         e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, w.time_idx.size, window=k)
         e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx, window=k)

@@ -47,8 +47,8 @@ struct vba_context {
     int device = 0;
     int W = 0, n_max = 0;
     int64_t m_max = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr, aux_stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     Arena arena;
     DevView V{};
     // mutable device pointers (DevView holds const views of some)
@@ -116,6 +116,8 @@ int ready(vba_handle h) {
 
 extern "C" {
 
+int vba_set_accumulate_lanes(vba_handle h, int lanes);
+
 int vba_version(void) { return 100; }
 
 const char* vba_last_error(void) { return g_err.c_str(); }
@@ -182,13 +184,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.cumrot = h->d_cumrot = A.take<double>(W * N * 4);
     V.steps = h->d_steps = A.take<int>(W * N);
     V.absr = A.take<double>(W * 2 * M); V.wraw = A.take<double>(W * M); V.ckeys = A.take<double>(W * 2 * M);
-    {   // lanes per pose of the accumulation kernel: about 12 observations per lane at the handle's capacity
-        // ratio (a function of the handle geometry only, so results do not depend on what else is batched)
-        const double avg = (double)m_max / (double)n_max;
-        int G = 4;
-        while (G < 64 && avg / G > 12.0) G *= 2;
-        V.acc_lanes = G;
-    }
+    V.acc_lanes = 8;    // set after construction by vba_set_accumulate_lanes(h, 0)
     V.part_init = A.take<double>(W * nblk_obs); V.part_trial = A.take<double>(W * (nblk_obs + nblk_dyn));
     V.hist = A.take<unsigned>(W * kSelPasses * kSelBins);
     V.Hraw = A.take<double>(W * N * 21); V.braw = A.take<double>(W * N * 6);
@@ -208,13 +204,24 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
         cs = std::min(std::max(cs, 2), 60);
         V.chunk = (windows >= 128 || n_max < 8) ? 0 : cs;
     }
-    if (A.used > A.size) {
-        hipFree(A.base);
-        delete h;
-        return fail(VBA_ENOMEM, "internal: arena under-sized");
+    {   // every device array a kernel may touch must have been carved: a null here would fault on the GPU
+        const void* must[] = {V.n, V.m, V.prm, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
+                              V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.absr, V.wraw, V.ckeys, V.part_init,
+                              V.part_trial, V.hist, V.Hraw, V.braw, V.xhat, V.Phi, V.rorb, V.fatt, V.qgrad, V.Hd, V.Hu, V.Hl,
+                              V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx};
+        bool ok = A.used <= A.size;
+        for (const void* q : must) ok = ok && q != nullptr;
+        if (!ok) {
+            hipFree(A.base);
+            delete h;
+            return fail(VBA_ENOMEM, "internal: device arena mis-carved");
+        }
     }
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void**)&h->h_prm, sizeof(StepParams)) != hipSuccess ||
         hipHostMalloc((void**)&h->h_head, W * kHead) != hipSuccess) {
         vba_destroy(h);
@@ -224,6 +231,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     h->n.assign(W, 0); h->m.assign(W, 0);
     h->have_obs.assign(W, 0); h->have_win.assign(W, 0); h->have_state.assign(W, 0);
     h->perm.resize(W);
+    vba_set_accumulate_lanes(h, 0);
     *out = h;
     return VBA_OK;
 }
@@ -232,6 +240,9 @@ int vba_destroy(vba_handle h) {
     if (!h) return VBA_OK;
     hipSetDevice(h->device);
     if (h->own_stream) { hipStreamSynchronize(h->own_stream); hipStreamDestroy(h->own_stream); }
+    if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->h_prm) hipHostFree(h->h_prm);
@@ -250,6 +261,21 @@ int vba_set_solver(vba_handle h, int chunk) {
     }
     if (chunk == 1 || chunk > 60) return fail(VBA_EINVAL, "chunk must be 0 (sequential) or in [2, 60]");
     h->V.chunk = chunk;
+    return VBA_OK;
+}
+
+int vba_set_accumulate_lanes(vba_handle h, int lanes) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (lanes == 0) {
+        const double avg = (double)h->m_max / (double)h->n_max;
+        int G = 4;
+        while (G < 64 && avg / G > 12.0) G *= 2;
+        // few windows: spend idle lanes on shorter per-lane loops (latency) instead of fewer shuffles (throughput)
+        while (G < 64 && (int64_t)h->W * h->n_max * G * 2 <= 32768) G *= 2;
+        lanes = G;
+    }
+    if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return fail(VBA_EINVAL, "lanes must be 0, 4, 8, 16, 32 or 64");
+    h->V.acc_lanes = lanes;
     return VBA_OK;
 }
 
@@ -411,15 +437,23 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
     HIPCHK(hipEventRecord(h->ev0, s));
     HIPCHK(hipMemcpyAsync(h->d_prm, h->h_prm, sizeof(StepParams), hipMemcpyHostToDevice, s));
     mark(0);
-    launch_step_begin(V, s);
     mark(1);
+    // the dynamics factor depends only on the states: it runs beside the observation pipeline on a second stream
+    const bool overlap = !initialize && !prof;
+    if (overlap) {
+        HIPCHK(hipEventRecord(h->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+        launch_dynamics(V, h->aux_stream);
+        HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
+    }
     launch_obs_residual(V, nullptr, s);
     mark(2);
     launch_select(V, s);
     mark(3);
     launch_obs_accumulate(V, s);
     mark(4);
-    if (!initialize) launch_dynamics(V, s);
+    if (!initialize && !overlap) launch_dynamics(V, s);
+    if (overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     mark(5);
     launch_assemble(V, s);
     mark(6);
@@ -606,7 +640,6 @@ int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, doubl
     fill_params(*h->h_prm, iter, initialize);
     HIPCHK(hipMemcpyAsync(h->d_prm, h->h_prm, sizeof(StepParams), hipMemcpyHostToDevice, s));
     h->V.m_total = m_total;
-    launch_step_begin(h->V, s);
     launch_obs_residual(h->V, d_abs_local, s);
     HIPCHK(hipGetLastError());
     h->last_iter = iter;

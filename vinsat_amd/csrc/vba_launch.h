@@ -7,7 +7,6 @@
 namespace vba {
 
 // vba_obs.hip
-void launch_step_begin(const DevView& V, hipStream_t s);
 void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s);
 void launch_select(const DevView& V, hipStream_t s);
 void launch_obs_accumulate(const DevView& V, hipStream_t s);

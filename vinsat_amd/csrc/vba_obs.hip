@@ -1,6 +1,5 @@
 // vba_obs.hip -- observation-indexed kernels of the BA iteration (gfx950).
 //
-//   k_step_begin       reset per-step state
 //   k_obs_residual     A1: reprojection residuals at the input states, |r| keys, sum |r|
 //   k_select_pass<P>   A3a: exact lower median of the 2m keys by most-significant-digit radix select:
 //                      digit 0 (exponent) is histogrammed inside k_obs_residual, digits 1 and 2 read the keys
@@ -17,23 +16,19 @@
 
 namespace vba {
 
-__global__ __launch_bounds__(256) void k_step_begin(DevView V) {
-    const int w = blockIdx.x;
-    const int n = V.n[w];
-    unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
-    for (int b = threadIdx.x; b < kSelPasses * kSelBins; b += 256) hist[b] = 0u;
-    double* sp = V.states_prev + (size_t)w * V.n_max * 10;
-    const double* s = V.states + (size_t)w * V.n_max * 10;
-    for (int k = threadIdx.x; k < n * 10; k += 256) sp[k] = s[k];
-    if (threadIdx.x == 0) {
-        WinScalars& sc = V.sc[w];
-        sc.done = 0;
-        sc.n_trials = 0;
-        sc.flags = 0u;
-        sc.wmax_bits = 0ull;
-        sc.sum_abs_rpred = 0.0;
-        sc.sel_cnt = 0u;
-    }
+// Per-step state that must be clean before the first kernel touches it:
+//   * radix histograms: zeroed by k_select_final of the PREVIOUS step (and by the allocation), because the first
+//     kernel of a step already accumulates digit 0 into them;
+//   * scalars (done, n_trials, flags, max weight, list length): reset by thread 0 of block 0 of k_obs_residual,
+//     no later block or kernel of the step reads them before the next kernel boundary;
+//   * states_prev (debug copy of the step's input): written by k_decide just before it commits the new states.
+__device__ __forceinline__ void reset_step_scalars(WinScalars& sc) {
+    sc.done = 0;
+    sc.n_trials = 0;
+    sc.flags = 0u;
+    sc.wmax_bits = 0ull;
+    sc.sum_abs_rpred = 0.0;
+    sc.sel_cnt = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------- A1
@@ -69,6 +64,7 @@ __global__ __launch_bounds__(kObsBlock) void k_obs_residual(DevView V, double* a
     }
     const double t = block_sum<kObsBlock>(s, red);
     if (threadIdx.x == 0) V.part_init[(size_t)w * V.nblk_obs + blockIdx.x] = t;
+    if (blockIdx.x == 0 && threadIdx.x == 0) reset_step_scalars(V.sc[w]);
     if (HIST0) {
         unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
         for (int b = threadIdx.x; b < 1024; b += kObsBlock) {
@@ -177,6 +173,7 @@ __global__ __launch_bounds__(256) void k_select_final(DevView V) {
         rank = nr;
     }
     if (threadIdx.x == 0) sc.c_obs = bits_f64(prefix);
+    for (int b = threadIdx.x; b < 3 * kSelBins; b += 256) hist[b] = 0u;     // clean for the next step
 }
 
 // ---------------------------------------------------------------------------------------------- A2 + A3
@@ -316,7 +313,6 @@ __global__ __launch_bounds__(kObsBlock) void k_debug_project(DevView V, int w, d
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
-void launch_step_begin(const DevView& V, hipStream_t s) { hipLaunchKernelGGL(k_step_begin, dim3(V.W), dim3(256), 0, s, V); }
 
 void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s) {
     // the exponent histogram is fused only when the keys of this launch are the whole key set (not sharded)

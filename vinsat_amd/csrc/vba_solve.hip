@@ -675,7 +675,8 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
     if (stop) {
         const double* s_new = V.states_new + sb * 10;
         double* s_cur = V.states + sb * 10;
-        for (int k = t; k < n * 10; k += 256) s_cur[k] = s_new[k];
+        double* s_prev = V.states_prev + sb * 10;
+        for (int k = t; k < n * 10; k += 256) { s_prev[k] = s_cur[k]; s_cur[k] = s_new[k]; }
         const double* D = V.bands + (sb + n - 1) * 243 + 81;
         if (t < 81) sc.last_hessian[t] = D[t] + ((t / 9 == t % 9) ? lam32 : 0.0);
     }

@@ -50,6 +50,10 @@ class BAEngine:
         """0 = sequential chain, 2..60 = partitioned with that chunk size, <0 = default."""
         _lib.check(self.lib.vba_set_solver(self.h, int(chunk)), self.lib)
 
+    def set_accumulate_lanes(self, lanes):
+        """Lanes per pose of the accumulation kernel (0 = automatic)."""
+        _lib.check(self.lib.vba_set_accumulate_lanes(self.h, int(lanes)), self.lib)
+
     def set_pivoting(self, always):
         """False (default): unpivoted fast path with checked pivots and automatic fallback; True: always pivot."""
         _lib.check(self.lib.vba_set_pivoting(self.h, int(bool(always))), self.lib)
