@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Print the GPU timeline of the last N kernels of a rocprofv3 --kernel-trace CSV (start offset, duration, gap)."""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+rows = rows[-n:]
+t0 = int(rows[0]["Start_Timestamp"]); prev_end = t0
+for r in rows:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("vba::", "")
+    print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.1f}  gap {(s - prev_end) / 1e3:6.1f}  {name}")
+    prev_end = e

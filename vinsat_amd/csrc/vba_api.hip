@@ -55,9 +55,7 @@ struct vba_context {
     int *d_n = nullptr, *d_m = nullptr, *d_opose = nullptr, *d_pose_ptr = nullptr, *d_steps = nullptr;
     double *d_ox = nullptr, *d_oy = nullptr, *d_oz = nullptr, *d_ou = nullptr, *d_ov = nullptr, *d_oconf = nullptr;
     double *d_intr = nullptr, *d_cumrot = nullptr;
-    StepParams* d_prm = nullptr;
-    StepParams* h_prm = nullptr;            // pinned
-    char* h_head = nullptr;                 // pinned, W * kHead bytes
+    WinHead* h_head = nullptr;              // mapped pinned host memory, [W]
     std::vector<int> n, m;
     std::vector<char> have_obs, have_win, have_state;
     std::vector<std::vector<int64_t>> perm; // sorted position -> input row
@@ -72,7 +70,6 @@ struct vba_context {
 
 namespace {
 
-constexpr size_t kHead = offsetof(WinScalars, sel_prefix);
 
 void fill_params(StepParams& p, int iter, int initialize) {
     // BA_filtering.py:22: alpha = min(max(1 - (2*(iter/5) - 1), 1), 2);  :26: Sigma = min(10000*(iter+1)**2, 1000000)
@@ -97,13 +94,13 @@ int check_window(vba_handle h, int window) {
     return VBA_OK;
 }
 
+// k_decide wrote the outcome of the trial into mapped host memory; waiting for the stream is all that is needed
 int read_heads(vba_handle h) {
-    HIPCHK(hipMemcpy2DAsync(h->h_head, kHead, h->V.sc, sizeof(WinScalars), kHead, h->W, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return VBA_OK;
 }
 
-const WinScalars* head(vba_handle h, int w) { return reinterpret_cast<const WinScalars*>(h->h_head + (size_t)w * kHead); }
+const volatile WinHead* head(vba_handle h, int w) { return h->h_head + w; }
 
 int ready(vba_handle h) {
     for (int w = 0; w < h->W; ++w)
@@ -150,7 +147,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     const int nblk_dyn = (int)((N + kObsBlock - 1) / kObsBlock);
     size_t bytes = 0;
     auto need = [&](size_t b) { bytes += ((b + 255) & ~size_t(255)) + 256; };
-    need(W * 4); need(W * 4); need(sizeof(StepParams)); need(W * sizeof(WinScalars));
+    need(W * 4); need(W * 4); need(W * sizeof(WinScalars));
     for (int k = 0; k < 6; ++k) need(W * M * 8);
     need(W * M * 4); need(W * (N + 1) * 4);
     need(W * N * 10 * 8); need(W * N * 10 * 8); need(W * N * 10 * 8);
@@ -173,7 +170,6 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.W = windows; V.n_max = n_max; V.m_max = m_max; V.nblk_obs = nblk_obs; V.nblk_dyn = nblk_dyn;
     V.n = h->d_n = A.take<int>(W);
     V.m = h->d_m = A.take<int>(W);
-    V.prm = h->d_prm = A.take<StepParams>(1);
     V.sc = A.take<WinScalars>(W);
     V.ox = h->d_ox = A.take<double>(W * M); V.oy = h->d_oy = A.take<double>(W * M); V.oz = h->d_oz = A.take<double>(W * M);
     V.ou = h->d_ou = A.take<double>(W * M); V.ov = h->d_ov = A.take<double>(W * M); V.oconf = h->d_oconf = A.take<double>(W * M);
@@ -205,7 +201,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
         V.chunk = (windows >= 128 || n_max < 8) ? 0 : cs;
     }
     {   // every device array a kernel may touch must have been carved: a null here would fault on the GPU
-        const void* must[] = {V.n, V.m, V.prm, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
+        const void* must[] = {V.n, V.m, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
                               V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.absr, V.wraw, V.ckeys, V.part_init,
                               V.part_trial, V.hist, V.Hraw, V.braw, V.xhat, V.Phi, V.rorb, V.fatt, V.qgrad, V.Hd, V.Hu, V.Hl,
                               V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx};
@@ -222,8 +218,8 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_prm, sizeof(StepParams)) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_head, W * kHead) != hipSuccess) {
+        hipHostMalloc((void**)&h->h_head, W * sizeof(WinHead), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->V.host_head, h->h_head, 0) != hipSuccess) {
         vba_destroy(h);
         return fail(VBA_EHIP, "stream/event/pinned allocation failed");
     }
@@ -245,7 +241,6 @@ int vba_destroy(vba_handle h) {
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
-    if (h->h_prm) hipHostFree(h->h_prm);
     if (h->h_head) hipHostFree(h->h_head);
     if (h->d_dbg) hipFree(h->d_dbg);
     if (h->arena.base) hipFree(h->arena.base);
@@ -428,14 +423,13 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
     hipStream_t s = h->stream;
     DevView V = h->V;
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
-    fill_params(*h->h_prm, iter, initialize);
+    fill_params(V.prm, iter, initialize);
     hipEvent_t ev[VBA_NKERNELS + 1] = {};
     if (prof) {
         for (int k = 0; k <= VBA_NKERNELS; ++k) HIPCHK(hipEventCreate(&ev[k]));
     }
     auto mark = [&](int k) { if (prof) (void)hipEventRecord(ev[k], s); };
     HIPCHK(hipEventRecord(h->ev0, s));
-    HIPCHK(hipMemcpyAsync(h->d_prm, h->h_prm, sizeof(StepParams), hipMemcpyHostToDevice, s));
     mark(0);
     mark(1);
     // the dynamics factor depends only on the states: it runs beside the observation pipeline on a second stream
@@ -637,8 +631,7 @@ int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, doubl
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    fill_params(*h->h_prm, iter, initialize);
-    HIPCHK(hipMemcpyAsync(h->d_prm, h->h_prm, sizeof(StepParams), hipMemcpyHostToDevice, s));
+    fill_params(h->V.prm, iter, initialize);
     h->V.m_total = m_total;
     launch_obs_residual(h->V, d_abs_local, s);
     HIPCHK(hipGetLastError());

@@ -47,6 +47,17 @@ struct WinScalars {
     double last_hessian[81];
 };
 
+// What the host needs to know after a trial; written by k_decide straight into mapped pinned host memory so that
+// the host only has to wait for the stream (no device-to-host copy in the loop).
+struct WinHead {
+    double lamda;
+    double trial_residual;
+    int done;
+    int n_trials;
+    unsigned flags;
+    int pad;
+};
+
 // Everything a kernel needs; passed by value.  Arrays of W windows use the *_max strides.
 struct DevView {
     int W, n_max;
@@ -54,7 +65,8 @@ struct DevView {
     int nblk_obs;                   // ceil(m_max / kObsBlock)
     const int* n;                   // [W]
     const int* m;                   // [W]
-    const StepParams* prm;
+    StepParams prm;                 // per-call constants, travel with the kernel arguments
+    WinHead* host_head;             // [W] mapped pinned host memory: k_decide publishes the outcome here
     WinScalars* sc;                 // [W]
     // observations, pose sorted, SoA [W][m_max]
     const double *ox, *oy, *oz, *ou, *ov, *oconf;

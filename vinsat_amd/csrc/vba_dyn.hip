@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     const int n = V.n[w];
     const int i = blockIdx.x;
     if (i >= n) return;
-    const StepParams prm = *V.prm;
+    const StepParams& prm = V.prm;
     const size_t pb = (size_t)w * V.n_max + i;
     const bool dyn = !prm.initialize;
     AsmRow R;

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     const int n = V.n[w];
     if (blockIdx.x * PPB >= n) return;
     WinScalars& sc = V.sc[w];
-    const StepParams prm = *V.prm;
+    const StepParams& prm = V.prm;
     RobustParams rp;
     rp.c = sc.c_obs;
     rp.inv_c2 = 1.0 / (rp.c * rp.c);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     const WinScalars& sc = V.sc[w];
     if (sc.done) return;
     const int n = V.n[w], m = V.m[w];
-    const StepParams prm = *V.prm;
+    const StepParams& prm = V.prm;
     double s = 0.0;
     const size_t sb = (size_t)w * V.n_max;
     if ((int)blockIdx.x < V.nblk_obs) {

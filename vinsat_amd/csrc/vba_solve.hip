@@ -616,10 +616,17 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
     const int w = blockIdx.x;
     WinScalars& sc = V.sc[w];
     if (sc.done) return;
-    if (sc.flags & 8u) return;      // the un-pivoted solve failed its check: the host repeats it with pivoting
+    if (sc.flags & 8u) {            // the un-pivoted solve failed its check: the host repeats it with pivoting
+        if (threadIdx.x == 0) {
+            V.host_head[w].flags = sc.flags;
+            V.host_head[w].done = 0;
+            __threadfence_system();
+        }
+        return;
+    }
     const int n = V.n[w];
     const int t = threadIdx.x;
-    const StepParams prm = *V.prm;
+    const StepParams& prm = V.prm;
     const size_t sb = (size_t)w * V.n_max;
     const double M = V.m_total ? (double)V.m_total : (double)V.m[w];
     const double denom = 2.0 * M + (prm.initialize ? 6.0 : 7.0) * (double)(n - 1);
@@ -691,6 +698,13 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
         } else {
             sc.lamda = lam;
         }
+        WinHead& hh = V.host_head[w];
+        hh.lamda = sc.lamda;
+        hh.trial_residual = residual;
+        hh.n_trials = sc.n_trials;
+        hh.flags = sc.flags;
+        hh.done = stop ? 1 : 0;
+        __threadfence_system();
     }
 }
 
