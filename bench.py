@@ -207,6 +207,7 @@ def main():
     # ---- observation-sharded mode (N > 1): ONE window whose rows are split over the ranks
     sharded = None
     if world > 1 and not args.no_sharded:
+      try:
         from vinsat_amd.dist import ShardedBA
         cfg_s = synth.WindowConfig("sharded", cfg.n_poses, cfg.obs_per_pose * world, cfg.stride)
         det_s, orb_s = synth.make_sequence(cfg_s, seed=0)
@@ -234,6 +235,8 @@ def main():
                    "observations_total": int(win_s.ii.size), "observations_per_rank": int(win_s.ii.size // world),
                    "collectives_per_call": "3 all-gathers (|r| keys, per-pose blocks, trial sums) over RCCL"}
         sba.close()
+      except Exception as exc:      # never lose the headline line to the secondary measurement
+        sharded = {"error": repr(exc)[:300]}
 
     # ---- accuracy: the 20-call schedule once more from the initial guess, against the reference's final states
     accuracy = None

@@ -59,34 +59,65 @@ __global__ __launch_bounds__(256) void k_dynamics(DevView V) {
     }
 }
 
-// One block per pose row: 3 x 81 band entries + 9 right-hand-side entries, one thread each (BA_filtering.py:40-48).
+// Block-tridiagonal assembly (BA_filtering.py:40-48): 3 x 81 band entries + 9 right-hand-side entries per pose.
+// A block of 256 threads takes kAsmPoses consecutive poses: the per-pose inputs (141 doubles each, plus the
+// transition matrix of the pose in front) are staged once in LDS with coalesced loads, then every thread forms
+// entries from LDS and the block writes its 252 * kAsmPoses outputs contiguously.
+constexpr int kAsmPoses = 4;
+constexpr int kAsmIn = 21 + 6 + 36 + 6 + 3 + 27;     // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl
+
 __global__ __launch_bounds__(256) void k_assemble(DevView V) {
+    __shared__ double in[(kAsmPoses + 1) * kAsmIn];
     const int w = blockIdx.y;
     const int n = V.n[w];
-    const int i = blockIdx.x;
-    if (i >= n) return;
+    const int i0 = blockIdx.x * kAsmPoses;
+    if (i0 >= n) return;
     const StepParams& prm = V.prm;
-    const size_t pb = (size_t)w * V.n_max + i;
+    const size_t sb = (size_t)w * V.n_max;
     const bool dyn = !prm.initialize;
-    AsmRow R;
-    R.Hraw = V.Hraw + pb * 21;
-    R.braw = V.braw + pb * 6;
-    R.inv_wmax = 1.0 / bits_f64(V.sc[w].wmax_bits);
-    R.sigma = dyn ? prm.sigma : 0.0;
-    R.Phi_i = (dyn && i < n - 1) ? V.Phi + pb * 36 : nullptr;
-    R.Phi_im1 = (dyn && i > 0) ? V.Phi + (pb - 1) * 36 : nullptr;
-    R.rorb_i = (dyn && i < n - 1) ? V.rorb + pb * 6 : nullptr;
-    R.rorb_im1 = (dyn && i > 0) ? V.rorb + (pb - 1) * 6 : nullptr;
-    R.qgrad = V.qgrad + pb * 3;
-    R.Hd = V.Hd + pb * 9;
-    R.Hu = V.Hu + pb * 9;
-    R.Hl = V.Hl + pb * 9;
-    const int t = threadIdx.x;
-    if (t < 243) {
-        const int which = t / 81, e = t % 81;
-        V.bands[pb * 243 + t] = band_entry(R, which, e / 9, e % 9);
-    } else if (t < 252) {
-        V.rhs[pb * 9 + (t - 243)] = rhs_entry(R, t - 243);
+    // slot 0 = pose i0-1 (only Phi and rorb are used), slots 1..kAsmPoses = poses i0 ..
+    for (int e = threadIdx.x; e < (kAsmPoses + 1) * kAsmIn; e += 256) {
+        const int slot = e / kAsmIn, q = e % kAsmIn;
+        const int i = i0 - 1 + slot;
+        double v = 0.0;
+        if (i >= 0 && i < n) {
+            const size_t pb = sb + i;
+            if (q < 21) v = V.Hraw[pb * 21 + q];
+            else if (q < 27) v = V.braw[pb * 6 + (q - 21)];
+            else if (dyn) {
+                if (q < 63) v = V.Phi[pb * 36 + (q - 27)];
+                else if (q < 69) v = V.rorb[pb * 6 + (q - 63)];
+                else if (q < 72) v = V.qgrad[pb * 3 + (q - 69)];
+                else if (q < 81) v = V.Hd[pb * 9 + (q - 72)];
+                else if (q < 90) v = V.Hu[pb * 9 + (q - 81)];
+                else v = V.Hl[pb * 9 + (q - 90)];
+            }
+        }
+        in[e] = v;
+    }
+    __syncthreads();
+    const double inv_wmax = 1.0 / bits_f64(V.sc[w].wmax_bits);
+    const int cnt = min(kAsmPoses, n - i0);
+    for (int e = threadIdx.x; e < cnt * 252; e += 256) {
+        const int p = e / 252, t = e % 252;
+        const int i = i0 + p;
+        const double* me = in + (p + 1) * kAsmIn;
+        const double* pv = in + p * kAsmIn;
+        AsmRow R;
+        R.Hraw = me;
+        R.braw = me + 21;
+        R.inv_wmax = inv_wmax;
+        R.sigma = dyn ? prm.sigma : 0.0;
+        R.Phi_i = (dyn && i < n - 1) ? me + 27 : nullptr;
+        R.Phi_im1 = (dyn && i > 0) ? pv + 27 : nullptr;
+        R.rorb_i = (dyn && i < n - 1) ? me + 63 : nullptr;
+        R.rorb_im1 = (dyn && i > 0) ? pv + 63 : nullptr;
+        R.qgrad = me + 69;
+        R.Hd = me + 72;
+        R.Hu = me + 81;
+        R.Hl = me + 90;
+        if (t < 243) V.bands[(sb + i) * 243 + t] = band_entry(R, t / 81, (t % 81) / 9, t % 9);
+        else V.rhs[(sb + i) * 9 + (t - 243)] = rhs_entry(R, t - 243);
     }
 }
 
@@ -96,7 +127,7 @@ void launch_dynamics(const DevView& V, hipStream_t s) {
 }
 
 void launch_assemble(const DevView& V, hipStream_t s) {
-    hipLaunchKernelGGL(k_assemble, dim3(V.n_max, V.W), dim3(256), 0, s, V);
+    hipLaunchKernelGGL(k_assemble, dim3((V.n_max + kAsmPoses - 1) / kAsmPoses, V.W), dim3(256), 0, s, V);
 }
 
 }  // namespace vba

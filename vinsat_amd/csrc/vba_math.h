@@ -88,14 +88,22 @@ struct RobustParams {
     double am2;         // |alpha-2|
     double expo;        // alpha/2 - 1
     int alpha_is_2;     // alpha == 2: ((r/c)^2/0 + 1)^0 == 1 by IEEE inf**0 / nan**0 (BA_filtering.py:24)
+    int expo_is_mhalf;  // alpha == 1 (every call from iter 3 on): x^(-1/2) = 1/sqrt(x), no pow() needed
 };
 
 // mean over the two pixel components of the Barron-style weight (BA_filtering.py:24), before /max and *conf
 VBA_HD double robust_weight_raw(const RobustParams& rp, double ru, double rv) {
     if (rp.alpha_is_2) return rp.inv_c2;
     const double su = ru / rp.c, sv = rv / rp.c;
-    const double wu = pow(su * su / rp.am2 + 1.0, rp.expo) * rp.inv_c2;
-    const double wv = pow(sv * sv / rp.am2 + 1.0, rp.expo) * rp.inv_c2;
+    const double xu = su * su / rp.am2 + 1.0, xv = sv * sv / rp.am2 + 1.0;
+    double wu, wv;
+    if (rp.expo_is_mhalf) {
+        wu = (1.0 / sqrt(xu)) * rp.inv_c2;
+        wv = (1.0 / sqrt(xv)) * rp.inv_c2;
+    } else {
+        wu = pow(xu, rp.expo) * rp.inv_c2;
+        wv = pow(xv, rp.expo) * rp.inv_c2;
+    }
     return (wu + wv) * 0.5;
 }
 

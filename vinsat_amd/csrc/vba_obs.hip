@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     rp.am2 = prm.am2;
     rp.expo = prm.expo;
     rp.alpha_is_2 = prm.alpha_is_2;
+    rp.expo_is_mhalf = prm.expo == -0.5;
 
     const int sub = threadIdx.x % G;
     const int i = blockIdx.x * PPB + threadIdx.x / G;
