@@ -84,6 +84,12 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external);
  * (~sqrt(n_max), or 0 for >= 128 windows).  Both give the same answer to rounding. */
 int vba_set_solver(vba_handle h, int chunk);
 
+/* Orbit integrator of the dynamics factor.  0 (default): one-second RK4 steps, the reference's CPU branch `predict`
+ * (BA_utils.py:73-87) -- the parity target.  1: the coarse schedule of `propagate_orbit_dynamics_skip`
+ * (BA_utils.py:52-71: steps of 100 s plus one remainder step) that the reference itself switches to when it sees a
+ * GPU (`predict_gpu`, BA_filtering.py:16-17); results differ from mode 0 by the integration error. */
+int vba_set_integrator(vba_handle h, int hop100);
+
 /* Lanes per pose of the per-pose accumulation kernel (4, 8, 16, 32 or 64; 0 = choose from the handle geometry:
  * ~12 observations per lane, more lanes when few windows leave the GPU idle).  The value fixes the shape of the
  * reduction tree, i.e. results are bit-reproducible for equal settings. */

@@ -193,30 +193,48 @@ def rk4_step(x, h=1.0):
     return x + (h / 6.0) * (f1 + 2 * f2 + 2 * f3 + f4)
 
 
-def rk4_step_stm(x, Phi, h=1.0):
-    """RK4 step of the state together with its 6x6 sensitivity (forward mode)."""
+def rk4_step_stm(x, Phi, h=1.0, hm=None):
+    """RK4 step of the state together with its 6x6 sensitivity (forward mode); hm = h shaped for the matrices."""
+    if hm is None:
+        hm = h
     f1 = _deriv(x)
     d1 = _deriv_jvp(x, Phi)
     x2 = x + 0.5 * h * f1
     f2 = _deriv(x2)
-    d2 = _deriv_jvp(x2, Phi + 0.5 * h * d1)
+    d2 = _deriv_jvp(x2, Phi + 0.5 * hm * d1)
     x3 = x + 0.5 * h * f2
     f3 = _deriv(x3)
-    d3 = _deriv_jvp(x3, Phi + 0.5 * h * d2)
+    d3 = _deriv_jvp(x3, Phi + 0.5 * hm * d2)
     x4 = x + h * f3
     f4 = _deriv(x4)
-    d4 = _deriv_jvp(x4, Phi + h * d3)
-    return x + (h / 6.0) * (f1 + 2 * f2 + 2 * f3 + f4), Phi + (h / 6.0) * (d1 + 2 * d2 + 2 * d3 + d4)
+    d4 = _deriv_jvp(x4, Phi + hm * d3)
+    return x + (h / 6.0) * (f1 + 2 * f2 + 2 * f3 + f4), Phi + (hm / 6.0) * (d1 + 2 * d2 + 2 * d3 + d4)
 
 
-def propagate_orbit(x, steps, stm=True):
-    """Advance pose i by steps[i] one-second RK4 steps (BA_utils.py:73-87).
+def propagate_orbit(x, steps, stm=True, hop=False):
+    """Advance pose i over a gap of steps[i] seconds.
 
+    hop=False: steps[i] one-second RK4 steps (``propagate_orbit_dynamics`` BA_utils.py:73-87, the CPU branch).
+    hop=True : ``propagate_orbit_dynamics_skip`` (BA_utils.py:52-71, used by ``predict_gpu``): floor(d/100) steps of
+    100 s followed by one step of d % 100 s.
     x [n,6] -> x_hat [n,6] (, Phi [n,6,6] = d x_hat / d x).
     """
     x = x.copy()
     n = x.shape[0]
     Phi = np.broadcast_to(np.eye(6), (n, 6, 6)).copy()
+    if hop:
+        hops = steps // 100
+        for s in range(int(hops.max()) + 1 if n else 0):
+            h = np.where(hops == s, steps % 100, np.where(hops > s, 100, 0)).astype(np.float64)
+            act = h > 0
+            if not act.any():
+                continue
+            hh = h[act][:, None]
+            if stm:
+                x[act], Phi[act] = rk4_step_stm(x[act], Phi[act], hh, hh[:, :, None])
+            else:
+                x[act] = rk4_step(x[act], hh)
+        return (x, Phi) if stm else x
     for s in range(int(steps.max()) if n else 0):
         act = steps > s
         if stm:
@@ -232,7 +250,7 @@ def step_counts(time_idx):
     return np.concatenate([d, np.ones(1, dtype=np.int64)])
 
 
-def orbit_factor(states, time_idx, jacobian=True):
+def orbit_factor(states, time_idx, jacobian=True, hop=False):
     """Position/velocity dynamics residual and its two 6x9 Jacobian blocks per edge.
 
     Reference: ``predict`` BA_utils.py:467-476, 488-490, 501-509.
@@ -242,9 +260,9 @@ def orbit_factor(states, time_idx, jacobian=True):
     steps = step_counts(time_idx)
     D = np.array([1.0, 1.0, 1.0, VEL_COEFF, VEL_COEFF, VEL_COEFF])
     if jacobian:
-        xh, Phi = propagate_orbit(x, steps, stm=True)
+        xh, Phi = propagate_orbit(x, steps, stm=True, hop=hop)
     else:
-        xh = propagate_orbit(x, steps, stm=False)
+        xh = propagate_orbit(x, steps, stm=False, hop=hop)
     r = (xh[:-1] - x[1:]) * D
     if not jacobian:
         return r
@@ -370,20 +388,21 @@ def retract(states, dpose):
     return np.concatenate([pos, rot, vel], -1)
 
 
-def dynamics_residual(states, cumrot, time_idx, initialize):
+def dynamics_residual(states, cumrot, time_idx, initialize, hop=False):
     """r_pred [n-1, 6 or 7] exactly as ``predict`` returns it (BA_utils.py:463-466, 476)."""
     n = states.shape[0]
     if initialize:
         return np.zeros((n - 1, 6))
-    r = orbit_factor(states, time_idx, jacobian=False)
+    r = orbit_factor(states, time_idx, jacobian=False, hop=hop)
     f = attitude_factor(states, cumrot, jacobian=False)
     return np.concatenate([r, f[:, None]], -1)
 
 
 def ba_iteration(it, states, cumrot, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences,
-                 lamda_init, initialize=False, solver="banded", debug=None):
+                 lamda_init, initialize=False, solver="banded", debug=None, hop=False):
     """One call of the reference's ``BA`` (BA_filtering.py:4-98) for batch size 1.
 
+    hop=True swaps the orbit integrator for the coarse one of the reference's ``predict_gpu`` (BA_utils.py:52-71, 544).
     Arrays carry no batch dimension: states [n,10], cumrot [n,4] (= imu_meas[0,:,-1,6:10]),
     landmarks [m,2], landmarks_xyz [m,3], ii [m], time_idx [n], intrinsics [n,4],
     confidences [m].  Returns (states_new [n,10], lamda_out, last_hessian [9,9], n_trials).
@@ -400,7 +419,7 @@ def ba_iteration(it, states, cumrot, landmarks, landmarks_xyz, ii, time_idx, int
         r_pred = np.zeros((n - 1, 6))
         E = F = r_orb = qgrad = Hd = Hu = Hl = None
     else:
-        r_orb, E, F = orbit_factor(states, time_idx, jacobian=True)
+        r_orb, E, F = orbit_factor(states, time_idx, jacobian=True, hop=hop)
         f, qgrad, Hd, Hu, Hl = attitude_factor(states, cumrot, jacobian=True)
         r_pred = np.concatenate([r_orb, f[:, None]], -1)
     bands, rhs = assemble(H, b, 1.0, float(sigma), E, F, r_orb, qgrad, Hd, Hu, Hl, initialize)
@@ -420,7 +439,7 @@ def ba_iteration(it, states, cumrot, landmarks, landmarks_xyz, ii, time_idx, int
         states_new = retract(states, dpose)
         est1 = landmark_project(states_new, landmarks_xyz, intrinsics, ii, jacobian=False)
         r_obs1 = (landmarks - est1) * w[:, None]
-        r_pred1 = dynamics_residual(states_new, cumrot, time_idx, initialize) * sq
+        r_pred1 = dynamics_residual(states_new, cumrot, time_idx, initialize, hop=hop) * sq
         residual = np.abs(np.concatenate([r_obs1.reshape(-1), r_pred1.reshape(-1)])).mean()
         n_trials += 1
         if debug is not None:

@@ -36,6 +36,18 @@ void hc_orbit(int n, const double* states, const int64_t* steps, double* xhat, d
     }
 }
 
+void hc_orbit_hop(int n, const double* x6, const int64_t* steps, double* xhat, double* Phi) {
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 6; ++c) {
+            double x[6], t[6] = {0, 0, 0, 0, 0, 0};
+            for (int r = 0; r < 6; ++r) x[r] = x6[6 * i + r];
+            t[c] = 1.0;
+            propagate_gap<true>(x, t, (int)steps[i], 1);
+            for (int r = 0; r < 6; ++r) Phi[36 * i + 6 * r + c] = t[r];
+            if (c == 0) for (int r = 0; r < 6; ++r) xhat[6 * i + r] = x[r];
+        }
+}
+
 void hc_orbit_fwd(int n, const double* states, const int64_t* steps, double* xhat) {
     for (int i = 0; i < n; ++i) {
         double x[6] = {states[10 * i], states[10 * i + 1], states[10 * i + 2], states[10 * i + 7], states[10 * i + 8], states[10 * i + 9]};

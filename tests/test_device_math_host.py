@@ -138,3 +138,14 @@ def test_retraction(hc, c2):
     out = np.zeros_like(st)
     hc.hc_retract(st.shape[0], _p(st), _p(dp), _p(out))
     assert rel_err(out, O.retract(st, dp)) < 1e-15
+
+
+def test_hop_integrator_device_math(hc):
+    from conftest import load_golden
+    g = load_golden("hop")
+    n = g["x"].shape[0]
+    steps = O.step_counts(g["times"])
+    xhat, Phi = np.zeros((n, 6)), np.zeros((n, 6, 6))
+    hc.hc_orbit_hop(n, _p(np.ascontiguousarray(g["x"])), _pi(steps), _p(xhat), _p(Phi))
+    assert rel_err(xhat, g["x_pred"]) < 1e-14
+    assert rel_err(Phi, g["Phi"]) < 1e-13

@@ -506,3 +506,30 @@ def test_unpivoted_fast_path_falls_back_when_a_pivot_check_fails(c2):
         st, lam, _, ntr, flags = eng.iterate(int(g["iters"][k]), bool(g["initialize"][k]), lam, st)
     assert eng.solver_fallbacks() == 0
     eng.close()
+
+
+def test_hop_integrator_mode_vs_oracle():
+    """vba_set_integrator(1): the <=100 s hop schedule of the reference's predict_gpu.  Two passes with gaps of
+    945 / 555 s; compared with the oracle run with the same integrator (itself pinned to the reference function)."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    det, orb = synth.make_two_pass_sequence()
+    win = od_pipe.prepare_window(det, orb)
+    n, m = win.time_idx.size, win.ii.size
+    eng = BAEngine(n, m)
+    eng.set_integrator(True)
+    eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+    eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+    st, lam = od_pipe.initial_guess(win), 1e-4
+    ref, lam_ref = st.copy(), lam
+    for it, init in ((0, True), (1, True), (2, True), (3, True), (10, False), (11, False), (12, False)):
+        ref, lam_ref, hess_ref, ntr_ref = O.ba_iteration(it, ref, win.cumrot_last, win.landmarks_uv, win.landmarks_xyz, win.ii,
+                                                         win.time_idx, win.intrinsics, win.confidences, lam_ref,
+                                                         initialize=init, hop=True)
+        st, lam, hess, ntr, flags = eng.iterate(it, init, lam, st)
+        assert ntr == ntr_ref and lam == lam_ref
+        assert rel_err(st, ref) < 1e-7
+    # the state-transition blocks of the last call against the oracle's (same integrator)
+    x_in = eng.debug("dpose")          # exercised for shape only
+    assert x_in.shape == (n, 9)
+    eng.close()

@@ -79,3 +79,15 @@ def test_solver_variants_agree(c2):
     xb = O.solve_tridiag(A, b, "banded")
     assert rel_err(xb, xd) < 1e-7
     assert rel_err(xd, c2[f"dpose_{k}"][0].reshape(-1, 9)) < 1e-7
+
+
+def test_hop_integrator_matches_reference_function():
+    """The coarse integrator (<=100 s hops) of the reference's predict_gpu: oracle vs outputs of
+    propagate_orbit_dynamics_skip (BA_utils.py:52-71) and its autograd Jacobian (tests/golden/hop.npz)."""
+    g = load_golden("hop")
+    assert g["offdiag_max"] == 0.0
+    steps = O.step_counts(g["times"])
+    xh, Phi = O.propagate_orbit(g["x"], steps, stm=True, hop=True)
+    assert rel_err(xh, g["x_pred"]) < 1e-14
+    assert rel_err(Phi, g["Phi"]) < 1e-13
+    assert np.array_equal(O.propagate_orbit(g["x"], steps, stm=False, hop=True), xh)

@@ -263,6 +263,33 @@ def run_config(name, od_pipe, baf, full_iters, store_inputs, store_states):
           f"final err {float(errors[-1]):.4f} km -> {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def run_hop(od_pipe, baf):
+    """Golden vectors of the coarse integrator: outputs of the reference's propagate_orbit_dynamics_skip
+    (BA_utils.py:52-71) and its autograd Jacobian, for gaps below, at and above the 100 s hop."""
+    import BA.BA_utils as bu
+    gaps = np.array([3, 100, 250, 99, 101, 1, 400, 37, 200, 945, 555])
+    times = np.concatenate([[10], 10 + np.cumsum(gaps)]).astype(np.int64)
+    traj = synth.integrate_orbit(int(times[-1]) + 2)
+    rng = np.random.default_rng(7)
+    x = traj[times] + np.concatenate([rng.normal(0, 5.0, (len(times), 3)), rng.normal(0, 0.01, (len(times), 3))], 1)
+    xt = torch.tensor(x)
+
+    def f(xx):
+        p, v = bu.propagate_orbit_dynamics_skip(xx[None, :, :3], xx[None, :, 3:], times, 1)
+        return torch.cat([p[0], v[0]], -1)
+
+    out = f(xt)
+    J = torch.autograd.functional.jacobian(f, xt)            # [n,6,n,6]
+    n = len(times)
+    Phi = np.stack([J[i, :, i, :].numpy() for i in range(n)])
+    off = J.clone()
+    for i in range(n):
+        off[i, :, i, :] = 0
+    path = os.path.join(REPO, "tests", "golden", "hop.npz")
+    np.savez_compressed(path, times=times, x=x, x_pred=out.numpy(), Phi=Phi, offdiag_max=float(off.abs().max()))
+    print(f"[HOP] n={n} gaps={gaps.tolist()} -> {path}")
+
+
 PLAN = {
     "C1": dict(full_iters=range(20), store_inputs=True, store_states="all"),
     "C2": dict(full_iters=(0, 9, 10, 19), store_inputs=True, store_states="all"),
@@ -276,7 +303,10 @@ def main():
     names = sys.argv[1:] or ["C1", "C2"]
     od_pipe, baf = load_reference()
     for name in names:
-        run_config(name, od_pipe, baf, **PLAN[name])
+        if name == "HOP":
+            run_hop(od_pipe, baf)
+        else:
+            run_config(name, od_pipe, baf, **PLAN[name])
 
 
 if __name__ == "__main__":

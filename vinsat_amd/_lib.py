@@ -26,6 +26,7 @@ SIGNATURES = {
     "vba_set_solver": (c_int, [c_void_p, c_int]),
     "vba_set_pivoting": (c_int, [c_void_p, c_int]),
     "vba_set_accumulate_lanes": (c_int, [c_void_p, c_int]),
+    "vba_set_integrator": (c_int, [c_void_p, c_int]),
     "vba_solver_fallbacks": (c_int, [c_void_p, POINTER(c_int)]),
     "vba_upload_observations": (c_int, [c_void_p, c_int, c_int, c_int64, PD, PD, PD, PI64]),
     "vba_upload_window": (c_int, [c_void_p, c_int, c_int, PD, PD, PI64]),

@@ -195,6 +195,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.cL = A.take<double>(W * PM * 171); V.cR = A.take<double>(W * PM * 171);
     V.rXs = A.take<double>(W * PM * 81); V.rzs = A.take<double>(W * PM * 9); V.rx = A.take<double>(W * PM * 9);
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
+    V.hop = 0; V.pivot = 0;
     {   // solver choice: many windows supply their own parallelism; otherwise cut the chain into ~sqrt(n) chunks
         int cs = (int)std::ceil(std::sqrt((double)n_max));
         cs = std::min(std::max(cs, 2), 60);
@@ -256,6 +257,12 @@ int vba_set_solver(vba_handle h, int chunk) {
     }
     if (chunk == 1 || chunk > 60) return fail(VBA_EINVAL, "chunk must be 0 (sequential) or in [2, 60]");
     h->V.chunk = chunk;
+    return VBA_OK;
+}
+
+int vba_set_integrator(vba_handle h, int hop100) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    h->V.hop = hop100 ? 1 : 0;
     return VBA_OK;
 }
 

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_dynamics(DevView V) {
         double t[6] = {0, 0, 0, 0, 0, 0};
         t[c] = 1.0;
         const int steps = V.steps[pb];
-        for (int q = 0; q < steps; ++q) rk4_step<true>(x, t);
+        propagate_gap<true>(x, t, steps, V.hop);
         double* Phi = V.Phi + pb * 36;
 #pragma unroll
         for (int r = 0; r < 6; ++r) Phi[6 * r + c] = t[r];

@@ -134,11 +134,10 @@ VBA_HD void accel_jvp(const double* p, const double* tp, double* a, double* da, 
     da[2] = -k3 * tp[2] + c3 * p[2] - c9 * u2 * p[2] + k7 * (du2 * p[2] + u2 * tp[2]);
 }
 
-// One RK4 step (h = 1 s) of x = [p, v] and, optionally, of one tangent vector t (forward mode); this is
-// RK4 at BA_utils.py:901-912 and, chained over the gap, propagate_orbit_dynamics :73-87.
+// One RK4 step of length h of x = [p, v] and, optionally, of one tangent vector t (forward mode); this is
+// RK4 at BA_utils.py:901-912 and, chained over the gap, propagate_orbit_dynamics :73-87 (h = 1 s).
 template <bool TANGENT>
-VBA_HD void rk4_step(double* x /*[6]*/, double* t /*[6]*/) {
-    const double h = 1.0;
+VBA_HD void rk4_step(double* x /*[6]*/, double* t /*[6]*/, double h = 1.0) {
     double k1[6], k2[6], k3[6], k4[6], d1[6], d2[6], d3[6], d4[6], xs[6], ts[6];
     for (int i = 0; i < 3; ++i) { k1[i] = x[3 + i]; if (TANGENT) d1[i] = t[3 + i]; }
     accel_jvp(x, t, k1 + 3, d1 + 3, TANGENT);
@@ -155,6 +154,21 @@ VBA_HD void rk4_step(double* x /*[6]*/, double* t /*[6]*/) {
         x[i] = x[i] + (h / 6.0) * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
         if (TANGENT) t[i] = t[i] + (h / 6.0) * (d1[i] + 2 * d2[i] + 2 * d3[i] + d4[i]);
     }
+}
+
+// Propagation over a gap of `steps` seconds.  hop == 0: `steps` one-second RK4 steps (the reference's CPU branch
+// `predict`, BA_utils.py:73-87, the parity default).  hop != 0: the schedule of `propagate_orbit_dynamics_skip`
+// (BA_utils.py:52-71) that the reference's `predict_gpu` uses: floor(steps/100) steps of 100 s, then one step of
+// steps % 100 s (a zero-length last step leaves the state untouched and is skipped).
+template <bool TANGENT>
+VBA_HD void propagate_gap(double* x, double* t, int steps, int hop) {
+    if (!hop) {
+        for (int q = 0; q < steps; ++q) rk4_step<TANGENT>(x, t, 1.0);
+        return;
+    }
+    const int nfull = steps / 100, rem = steps % 100;
+    for (int q = 0; q < nfull; ++q) rk4_step<TANGENT>(x, t, 100.0);
+    if (rem) rk4_step<TANGENT>(x, t, (double)rem);
 }
 
 // ------------------------------------------------------------------------------------------------ attitude

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             const double* sn = st + 10;
             double x[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
             const int steps = V.steps[sb + i];
-            for (int q = 0; q < steps; ++q) rk4_step<false>(x, nullptr);
+            propagate_gap<false>(x, nullptr, steps, V.hop);
             s = fabs(x[0] - sn[0]) + fabs(x[1] - sn[1]) + fabs(x[2] - sn[2]) +
                 fabs((x[3] - sn[7]) * kVelCoeff) + fabs((x[4] - sn[8]) * kVelCoeff) + fabs((x[5] - sn[9]) * kVelCoeff);
             s += fabs(attitude_residual(st + 3, V.cumrot + (sb + i) * 4, sn + 3));

@@ -50,6 +50,10 @@ class BAEngine:
         """0 = sequential chain, 2..60 = partitioned with that chunk size, <0 = default."""
         _lib.check(self.lib.vba_set_solver(self.h, int(chunk)), self.lib)
 
+    def set_integrator(self, hop100):
+        """False: 1 s RK4 steps (reference CPU branch, default); True: <=100 s hops (the reference's predict_gpu)."""
+        _lib.check(self.lib.vba_set_integrator(self.h, int(bool(hop100))), self.lib)
+
     def set_accumulate_lanes(self, lanes):
         """Lanes per pose of the accumulation kernel (0 = automatic)."""
         _lib.check(self.lib.vba_set_accumulate_lanes(self.h, int(lanes)), self.lib)
