@@ -533,3 +533,28 @@ def test_hop_integrator_mode_vs_oracle():
     x_in = eng.debug("dpose")          # exercised for shape only
     assert x_in.shape == (n, 9)
     eng.close()
+
+
+def test_c5_full_orbit_window_vs_oracle():
+    """BASELINE config 5: 2000 poses / 500 000 observations (3 s stride, ~1 orbit).  The reference cannot run this
+    size (dense (9n)^2 objects, >100 GB); parity is against the oracle, which is pinned to the reference at C1-C4."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    det, orb = synth.make_sequence("C5")
+    win = od_pipe.prepare_window(det, orb)
+    n, m = win.time_idx.size, win.ii.size
+    assert (n, m) == (2004, 500000)      # 2000 frames + 4 knot poses (2000, 3000, 5000, 6000 s are not frame times)
+    eng = BAEngine(n, m)
+    eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+    eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+    st, lam = od_pipe.initial_guess(win), 1e-4
+    ref, lam_ref = st.copy(), lam
+    for it, init in ((0, True), (3, True), (10, False), (11, False)):
+        ref, lam_ref, hess_ref, ntr_ref = O.ba_iteration(it, ref, win.cumrot_last, win.landmarks_uv, win.landmarks_xyz, win.ii,
+                                                         win.time_idx, win.intrinsics, win.confidences, lam_ref, initialize=init)
+        st, lam, hess, ntr, flags = eng.iterate(it, init, lam, st)
+        assert ntr == ntr_ref and lam == lam_ref and flags == 0
+        assert np.abs(st[:, :3] - ref[:, :3]).max() / np.abs(ref[:, :3]).max() < 1e-6
+        assert rel_err(st, ref) < 1e-6
+    assert eng.solver_fallbacks() == 0
+    eng.close()
