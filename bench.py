@@ -56,8 +56,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--windows", type=int, default=256, help="windows per launch of the batched series (0 = skip)")
+    ap.add_argument("--windows", type=int, default=1024, help="windows per launch of the batched series (0 = skip)")
     ap.add_argument("--batched-steps", type=int, default=40)
+    ap.add_argument("--profile-tag", default="r01", help="profiles/<tag>_w1_traffic.json supplies roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-sharded", action="store_true")
     return ap.parse_args()
@@ -156,11 +157,19 @@ def main():
     dom = max(share, key=share.get)
     alg = float(ALG_BYTES[dom](n, m))
     achieved = alg / (kernels_ms[dom] * 1e-3) / 1e9
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_pmc.sh + tools/summarize_pmc.py:
+    # 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); a kernel class sums its kernels
+    KERNELS_OF = {"solve": ["k_solve_chunks<false>", "k_solve_reduced<false>", "k_solve_recover", "k_solve_blockdiag<false>", "k_solve<false>"],
+                  "select": ["k_select_pass<1, false>", "k_select_pass<2, true>", "k_select_final"]}
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", f"{args.profile_tag}_w1_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_" + dom, {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            names = KERNELS_OF.get(dom, [k for k in tj if k.startswith("k_" + dom) or k.startswith("k_obs_" + dom)])
+            calls = max([tj[k].get("calls", 0) for k in names if k in tj] or [0])
+            vals = [tj[k]["hbm_bytes_per_launch"] * tj[k].get("calls", calls) / max(calls, 1) for k in names if k in tj and "hbm_bytes_per_launch" in tj[k]]
+            traffic = float(sum(vals)) if vals else None
         except Exception:
             traffic = None
     roofline = {"kernel": "k_" + dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

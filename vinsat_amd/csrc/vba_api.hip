@@ -387,10 +387,8 @@ int vba_set_states(vba_handle h, int window, const double* states, double lamda)
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemcpy(h->V.states, states, (size_t)n * 80, hipMemcpyHostToDevice));
-        for (int w = 1; w < h->W; ++w)
-            HIPCHK(hipMemcpyAsync(h->V.states + (size_t)w * h->n_max * 10, h->V.states, (size_t)n * 80, hipMemcpyDeviceToDevice, h->stream));
-        std::vector<double> lam(h->W, lamda);
-        HIPCHK(hipMemcpy2DAsync(&h->V.sc[0].lamda, sizeof(WinScalars), lam.data(), 8, 8, h->W, hipMemcpyHostToDevice, h->stream));
+        launch_broadcast_states(h->V, n, lamda, h->stream);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(h->stream));
         for (int w = 0; w < h->W; ++w) h->have_state[w] = 1;
         return VBA_OK;

@@ -313,6 +313,20 @@ __global__ __launch_bounds__(kObsBlock) void k_debug_project(DevView V, int w, d
     wt[k] = (V.wraw[ob + k] / bits_f64(V.sc[w].wmax_bits)) * V.oconf[ob + k];
 }
 
+// window 0's states and damping copied to every other window (vba_set_states with window == -1)
+__global__ __launch_bounds__(256) void k_broadcast_states(DevView V, int n, double lamda) {
+    const int w = blockIdx.y;
+    const double* src = V.states;
+    double* dst = V.states + (size_t)w * V.n_max * 10;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (w > 0 && k < n * 10) dst[k] = src[k];
+    if (k == 0) V.sc[w].lamda = lamda;
+}
+
+void launch_broadcast_states(const DevView& V, int n, double lamda, hipStream_t s) {
+    hipLaunchKernelGGL(k_broadcast_states, dim3((n * 10 + 255) / 256, V.W), dim3(256), 0, s, V, n, lamda);
+}
+
 // ---------------------------------------------------------------------------------------------- launchers
 
 void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s) {
