@@ -80,8 +80,9 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external);
 
 /* Choice of the block-tridiagonal solve: chunk = 0 one wavefront walks the whole pose chain (work optimal, used
  * when many windows are batched); chunk in [2,60] cuts the chain into chunks of that many poses that are
- * eliminated in parallel plus a reduced system over the separators; chunk < 0 restores the default
- * (~sqrt(n_max), or 0 for >= 128 windows).  Both give the same answer to rounding. */
+ * eliminated in parallel plus a reduced system over the separators; chunk = -1 restores the default
+ * (~sqrt(n_max), or 0 for >= 128 windows).  With chunk = 0 and equal pose counts three windows share one
+ * wavefront; chunk = -2 is chunk = 0 with one window per wavefront.  All variants agree to rounding. */
 int vba_set_solver(vba_handle h, int chunk);
 
 /* Orbit integrator of the dynamics factor.  0 (default): one-second RK4 steps, the reference's CPU branch `predict`

@@ -558,3 +558,38 @@ def test_c5_full_orbit_window_vs_oracle():
         assert rel_err(st, ref) < 1e-6
     assert eng.solver_fallbacks() == 0
     eng.close()
+
+
+@pytest.mark.parametrize("pivot", [False, True], ids=["unpivoted", "pivoted"])
+def test_packed_sequential_solve_three_windows_per_wave(pivot):
+    """Sequential driver with equal pose counts: three windows share a wavefront (k_solve_packed).  Five windows
+    (3 + a partial group of 2) with different data must reproduce the one-window-per-wave results bit for bit."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    cfg = synth.WindowConfig("pk", 48, 25, 5)
+    wins = [od_pipe.prepare_window(*synth.make_sequence(cfg, seed=s)) for s in range(5)]
+    n, m = wins[0].time_idx.size, wins[0].ii.size
+    sched = [(0, True), (1, True), (10, False), (11, False), (12, False)]
+
+    def run(solver, W):
+        outs = []
+        groups = [list(enumerate(wins))] if W == 5 else [[(k, w)] for k, w in enumerate(wins)]
+        for grp in groups:
+            e = BAEngine(n, m, windows=len(grp))
+            e.set_solver(solver)
+            e.set_pivoting(pivot)
+            e.set_accumulate_lanes(8)
+            for k, (seed, w) in enumerate(grp):
+                e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, n, window=k)
+                e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx, window=k)
+                e.set_states(od_pipe.initial_guess(w, seed=seed), 1e-4, window=k)
+            for it, init in sched:
+                e.step(it, init)
+            outs += [e.get_states(window=k) for k in range(len(grp))]
+            e.close()
+        return outs
+
+    packed = run(0, 5)          # 5 windows, chunk 0 -> packed kernel
+    single = run(-2, 1)         # one window per handle, one window per wavefront
+    for a, b in zip(packed, single):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[3] == b[3]

@@ -62,6 +62,7 @@ struct vba_context {
     float last_ms = 0.f;
     bool stepped = false;
     int last_iter = 0, last_init = 0;
+    int no_pack = 0;                        // diagnostic: force one window per wavefront in the sequential driver
     int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
@@ -251,12 +252,18 @@ int vba_destroy(vba_handle h) {
 
 int vba_set_solver(vba_handle h, int chunk) {
     if (!h) return fail(VBA_EINVAL, "null handle");
-    if (chunk < 0) {
+    if (chunk == -1) {
         int cs = (int)std::ceil(std::sqrt((double)h->n_max));
         chunk = (h->W >= 128 || h->n_max < 8) ? 0 : std::min(std::max(cs, 2), 60);
     }
+    if (chunk == -2) {      // sequential, one window per wavefront (no packing): diagnostic / comparison
+        h->V.chunk = 0;
+        h->no_pack = 1;
+        return VBA_OK;
+    }
     if (chunk == 1 || chunk > 60) return fail(VBA_EINVAL, "chunk must be 0 (sequential) or in [2, 60]");
     h->V.chunk = chunk;
+    h->no_pack = 0;
     return VBA_OK;
 }
 
@@ -459,6 +466,11 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
     // LM loop (BA_filtering.py:52-77): lamda 1e-4 .. 1e4 in decades, at most 9 trials
     int rc_out = VBA_OK;
     V.pivot = h->pivot_mode;
+    V.pack = 0;
+    if (V.chunk <= 0 && h->W >= 3 && !h->no_pack) {
+        V.pack = 1;
+        for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
+    }
     for (int trial = 0; trial < 24; ++trial) {
         launch_solve(V, initialize, s);
         if (trial == 0) mark(7);

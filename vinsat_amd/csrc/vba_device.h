@@ -104,6 +104,7 @@ struct DevView {
     double* dpose;                  // [9]
     // partitioned solve: chunk size (0 = one wave walks the whole chain), separators per window <= p_max
     int chunk, p_max;
+    int pack;                       // sequential driver: 1 = three windows per wavefront (needs equal pose counts)
     int hop;                        // orbit integrator: 0 = 1 s RK4 steps (reference CPU branch), 1 = <=100 s hops (predict_gpu)
     int pivot;                      // 1: row pivoting inside the 9x9 blocks (safe path); 0: SPD fast path with a pivot check
     double* csol;                   // [W][n_max][19][9]  chunk solutions for the 19 right-hand sides

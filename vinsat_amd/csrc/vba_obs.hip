@@ -80,14 +80,16 @@ __global__ __launch_bounds__(kObsBlock) void k_obs_residual(DevView V, double* a
 
 // ---------------------------------------------------------------------------------------------- A3a: select
 // COMPACT: additionally append the keys that match the digits known so far to the short list V.ckeys.
-template <int P, bool COMPACT>
+// ITEMS keys per thread: 8 keeps a single window spread over many blocks (latency), 32 amortises the per-block
+// prologue (histogram scan, LDS clear, flush) when many windows are batched.
+template <int P, bool COMPACT, int ITEMS>
 __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     __shared__ unsigned lh[kSelBins];
     __shared__ unsigned lds_u[260];
     const int w = blockIdx.y;
     const double* keys = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
     const int64_t count = V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w];
-    if ((int64_t)blockIdx.x * 256 * kSelItems >= count) return;
+    if ((int64_t)blockIdx.x * 256 * ITEMS >= count) return;
     unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
     constexpr int nbins = 1 << sel_width(P);
     for (int b = threadIdx.x; b < nbins; b += 256) lh[b] = 0u;
@@ -105,9 +107,9 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
         V.sc[w].sel_prefix[P] = prefix;
         V.sc[w].sel_rank[P] = rank;
     }
-#pragma unroll
-    for (int it = 0; it < kSelItems; ++it) {
-        const int64_t idx = ((int64_t)blockIdx.x * kSelItems + it) * 256 + threadIdx.x;
+#pragma unroll 8
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * ITEMS + it) * 256 + threadIdx.x;
         if (idx < count) {
             const unsigned long long key = f64_bits(keys[idx]);
             bool match = true;
@@ -337,11 +339,19 @@ void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s) {
 
 void launch_select(const DevView& V, hipStream_t s) {
     const int64_t count = V.abs_all ? V.abs_all_count : 2 * V.m_max;
-    const int nb = (int)((count + 256 * kSelItems - 1) / (256 * kSelItems));
-    const dim3 g(nb > 0 ? nb : 1, V.W), b(256);
-    if (V.abs_all) hipLaunchKernelGGL((k_select_pass<0, false>), g, b, 0, s, V);   // sharded: digit 0 over the gathered keys
-    hipLaunchKernelGGL((k_select_pass<1, false>), g, b, 0, s, V);
-    hipLaunchKernelGGL((k_select_pass<2, true>), g, b, 0, s, V);
+    const dim3 b(256);
+    if (V.W >= 16) {
+        const int nb = (int)((count + 256 * 32 - 1) / (256 * 32));
+        const dim3 g(nb > 0 ? nb : 1, V.W);
+        hipLaunchKernelGGL((k_select_pass<1, false, 32>), g, b, 0, s, V);
+        hipLaunchKernelGGL((k_select_pass<2, true, 32>), g, b, 0, s, V);
+    } else {
+        const int nb = (int)((count + 256 * kSelItems - 1) / (256 * kSelItems));
+        const dim3 g(nb > 0 ? nb : 1, V.W);
+        if (V.abs_all) hipLaunchKernelGGL((k_select_pass<0, false, kSelItems>), g, b, 0, s, V);   // sharded: digit 0 over the gathered keys
+        hipLaunchKernelGGL((k_select_pass<1, false, kSelItems>), g, b, 0, s, V);
+        hipLaunchKernelGGL((k_select_pass<2, true, kSelItems>), g, b, 0, s, V);
+    }
     hipLaunchKernelGGL(k_select_final, dim3(V.W), dim3(256), 0, s, V);
 }
 

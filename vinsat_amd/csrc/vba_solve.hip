@@ -71,9 +71,23 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // SPARSE_L: L_i of the assembled system has the pattern [pp 0 pv; 0 rr 0; vp 0 vv] over (position, rotation,
 // velocity) (the orbit factor does not touch the rotation slots and the attitude term touches nothing else),
 // so 45 instead of 81 multiply-adds; not valid for the reduced system.
-template <int DB, int NRHS, bool PIVOT, bool SPARSE_L>
+// GROUPED: the wave holds several independent chains side by side (19 lanes each, `lane` is the lane inside the
+// group, `gbase` the group's first lane); broadcasts then come from the group's own pivot lane through the LDS
+// crossbar (ds_bpermute) instead of v_readlane, and the pivot row index is a per-lane value.
+template <bool GROUPED>
+__device__ __forceinline__ double bcast_f64(double v, int src) {
+    if (GROUPED) return __shfl(v, src, kWave);
+    return readlane_f64(v, src);
+}
+template <bool GROUPED>
+__device__ __forceinline__ int bcast_i32(int v, int src) {
+    if (GROUPED) return __shfl(v, src, kWave);
+    return __builtin_amdgcn_readlane(v, src);
+}
+
+template <int DB, int NRHS, bool PIVOT, bool SPARSE_L, bool GROUPED = false>
 __device__ __forceinline__ void forward_step(const double* Lmat, const double (&base)[9], double (&a)[9], int lane,
-                                             bool& bad) {
+                                             bool& bad, int gbase = 0) {
     using R = Roles<DB, NRHS>;
     const bool carry = R::isD(lane) || R::isR(lane);
     double xp[9];
@@ -118,8 +132,8 @@ __device__ __forceinline__ void forward_step(const double* Lmat, const double (&
                 }
             }
             const double inv_l = fast_rcp(cs[0]);
-            const int p = __builtin_amdgcn_readlane(ci[0], pl);
-            inv = readlane_f64(inv_l, pl);
+            const int p = bcast_i32<GROUPED>(ci[0], gbase + pl);
+            inv = bcast_f64<GROUPED>(inv_l, gbase + pl);
             if (!(fabs(inv) <= 1.79e308)) bad = true;
             const double ak = a[k];
             double nk = ak;
@@ -134,11 +148,11 @@ __device__ __forceinline__ void forward_step(const double* Lmat, const double (&
         } else {
             // pivot on the diagonal; it must stay a healthy fraction of the diagonal entry it started from
             if (lane == pl && !(a[k] > 1e-10 * base[k])) bad = true;
-            inv = readlane_f64(fast_rcp(a[k]), pl);
+            inv = bcast_f64<GROUPED>(fast_rcp(a[k]), gbase + pl);
         }
         double f[9];
 #pragma unroll
-        for (int r = 0; r < 9; ++r) f[r] = (r != k) ? readlane_f64(a[r], pl) : 0.0;
+        for (int r = 0; r < 9; ++r) f[r] = (r != k) ? bcast_f64<GROUPED>(a[r], gbase + pl) : 0.0;
         a[k] = a[k] * inv;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
@@ -298,6 +312,140 @@ __global__ __launch_bounds__(64) void k_solve(DevView V) {
     const bool bad = retract_range(V, sb, n, lane, 64);
     const unsigned long long anybad = __ballot(bad);
     if (lane == 0 && anybad) atomicOr(&sc.flags, 2u);
+}
+
+// ---------------------------------------------------------------------------------------------- packed
+// Many batched windows: three chains per wavefront (19 lanes each: 9 D' + 9 U + 1 right-hand side), so the ~550
+// instructions of a block step serve three windows.  All windows of the handle must have the same pose count
+// (checked by the host); windows that are already done ride along without storing.
+constexpr int kPack = 3;
+
+template <bool PIVOT>
+__global__ __launch_bounds__(64) void k_solve_packed(DevView V) {
+    __shared__ double blk[2][kPack][256];
+    const int lane = threadIdx.x;
+    const int g = lane / 19 < kPack ? lane / 19 : kPack - 1;
+    const bool lane_ok = lane < 19 * kPack;
+    const int ll = lane_ok ? lane - 19 * g : 19;          // 19 = no role
+    const int gbase = 19 * g;
+    const int w0 = blockIdx.x * kPack;
+    const int wg = min(w0 + g, V.W - 1);
+    const bool w_ok = w0 + g < V.W;
+    const int n = V.n[w0];
+    WinScalars& sc = V.sc[wg];
+    const bool active = lane_ok && w_ok && !sc.done;
+    const size_t sb = (size_t)wg * V.n_max;
+    const double lam32 = (double)(float)sc.lamda;
+    if (active && ll == 0) {
+        sc.lam32 = lam32;
+        if (PIVOT) atomicAnd(&sc.flags, ~8u);
+    }
+    double a[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) a[j] = 0.0;
+    bool badp = false;
+    double pre[kPack][4];
+    auto fetch = [&](int i) {
+#pragma unroll
+        for (int q3 = 0; q3 < kPack; ++q3) {
+            const size_t s3 = (size_t)min(w0 + q3, V.W - 1) * V.n_max + i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = lane + 64 * q;
+                pre[q3][q] = e < 243 ? V.bands[s3 * 243 + e] : (e < 252 ? V.rhs[s3 * 9 + (e - 243)] : 0.0);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q3 = 0; q3 < kPack; ++q3)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) blk[buf][q3][lane + 64 * q] = pre[q3][q];
+    };
+    auto load_base = [&](const double* b, int db, double (&base)[9]) {
+        const int ub = 9 - db;
+        const bool isD = ll >= db && ll < db + 9, isU = ll >= ub && ll < ub + 9, isY = ll == 18;
+        const int cc = isD ? ll - db : (isU ? ll - ub : 0);
+        const double* p = isD ? b + 81 + cc : (isU ? b + 162 + cc : b + 243);
+        const int stride = isY ? 1 : 9;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = (isD || isU || isY) ? p[r * stride] : 0.0;
+            if (isD && r == cc) v += lam32;
+            base[r] = v;
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        const int buf = i & 1;
+        if (i + 1 < n) fetch(i + 1);
+        double base[9];
+        const double* mine = blk[buf][g];
+        if (buf == 0) {
+            load_base(mine, 0, base);
+            forward_step<0, 1, PIVOT, true, true>(i > 0 ? mine : nullptr, base, a, ll, badp, gbase);
+        } else {
+            load_base(mine, 9, base);
+            forward_step<9, 1, PIVOT, true, true>(mine, base, a, ll, badp, gbase);
+        }
+        const int ub = buf == 0 ? 9 : 0;
+        if (active) {
+            if (ll >= ub && ll < ub + 9) {
+                double* X = V.Xs + (sb + i) * 81 + (ll - ub);
+#pragma unroll
+                for (int r = 0; r < 9; ++r) X[r * 9] = a[r];
+            } else if (ll == 18) {
+                double* z = V.zs + (sb + i) * 9;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) z[r] = a[r];
+            }
+        }
+        if (i + 1 < n) stash(buf ^ 1);
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    // backward sweep: lane ll < 9 of each group owns row ll
+    const int r = ll < 9 ? ll : 0;
+    double x = V.zs[(sb + n - 1) * 9 + r];
+    if (active && ll < 9) V.dpose[(sb + n - 1) * 9 + r] = x;
+    double Xrow[9], zr = 0.0;
+    auto fetch_row = [&](int i) {
+        const double* X = V.Xs + (sb + i) * 81 + r * 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) Xrow[j] = X[j];
+        zr = V.zs[(sb + i) * 9 + r];
+    };
+    if (n > 1) fetch_row(n - 2);
+    for (int i = n - 2; i >= 0; --i) {
+        double cur[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) cur[j] = Xrow[j];
+        double v = zr;
+        if (i > 0) fetch_row(i - 1);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) v -= cur[j] * __shfl(x, gbase + j, kWave);
+        x = v;
+        if (active && ll < 9) V.dpose[(sb + i) * 9 + r] = x;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // flags + retraction, one window after the other with the whole wave
+    const unsigned long long badmask = __ballot(badp && active);
+#pragma unroll
+    for (int q3 = 0; q3 < kPack; ++q3) {
+        const int w = w0 + q3;
+        if (w >= V.W) break;
+        WinScalars& s3 = V.sc[w];
+        if (s3.done) continue;
+        const unsigned long long gm = ((1ull << 19) - 1ull) << (19 * q3);
+        if (lane == 0 && (badmask & gm)) atomicOr(&s3.flags, PIVOT ? 4u : 8u);
+        const bool bad = retract_range(V, (size_t)w * V.n_max, n, lane, 64);
+        const unsigned long long anybad = __ballot(bad);
+        if (lane == 0 && anybad) atomicOr(&s3.flags, 2u);
+    }
 }
 
 // ================================================================================================== partitioned
@@ -719,6 +867,12 @@ void launch_solve(const DevView& V, int initialize, hipStream_t s) {
         return;
     }
     if (V.chunk <= 0) {
+        if (V.pack) {       // equal pose counts: three windows per wavefront
+            const dim3 g((V.W + kPack - 1) / kPack);
+            if (pv) hipLaunchKernelGGL(k_solve_packed<true>, g, dim3(64), 0, s, V);
+            else hipLaunchKernelGGL(k_solve_packed<false>, g, dim3(64), 0, s, V);
+            return;
+        }
         if (pv) hipLaunchKernelGGL(k_solve<true>, dim3(V.W), dim3(64), 0, s, V);
         else hipLaunchKernelGGL(k_solve<false>, dim3(V.W), dim3(64), 0, s, V);
         return;
