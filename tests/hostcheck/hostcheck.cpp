@@ -19,7 +19,7 @@ void hc_project(int64_t m, const double* states, const double* K, const double* 
 
 void hc_weights(int64_t m, const double* r, double c, double alpha, double* w) {
     RobustParams rp;
-    rp.c = c; rp.inv_c2 = 1.0 / (c * c); rp.am2 = fabs(alpha - 2); rp.expo = alpha / 2 - 1; rp.alpha_is_2 = alpha == 2.0; rp.expo_is_mhalf = rp.expo == -0.5;
+    rp.c = c; rp.inv_c = 1.0 / c; rp.inv_c2 = 1.0 / (c * c); rp.am2 = fabs(alpha - 2); rp.inv_am2 = 1.0 / rp.am2; rp.expo = alpha / 2 - 1; rp.alpha_is_2 = alpha == 2.0; rp.expo_is_mhalf = rp.expo == -0.5;
     for (int64_t k = 0; k < m; ++k) w[k] = robust_weight_raw(rp, r[2 * k], r[2 * k + 1]);
 }
 

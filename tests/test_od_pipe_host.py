@@ -67,3 +67,24 @@ def test_two_pass_sequence_matches_reference_run():
     assert rel_err(errors.numpy(), g["errors"]) < 1e-6
     assert int(first_det) == int(g["first_detection"])
     assert np.array_equal(np.concatenate([np.atleast_1d(t) for t in times]), g["times"])
+
+
+def test_result_files_round_trip(tmp_path):
+    """errors.npy / times.npy as the reference's __main__ writes them (od_pipe.py:1085-1086) and errors_eval reads
+    them (errors_eval.py:19-31), produced from on-disk *_all_detections.npy / *_orbit_eci_zyxvecs.npy inputs."""
+    from vinsat_amd import errors_eval
+    folder = tmp_path / "dets_and_poses"
+    (folder / "tmp_dets").mkdir(parents=True)
+    (folder / "tmp_pose").mkdir()
+    for sid, seed in (("00092", 0), ("00093", 1)):
+        det, orb = synth.make_sequence("C1", seed=seed)
+        np.save(folder / "tmp_dets" / f"{sid}_all_detections.npy", det)
+        np.save(folder / "tmp_pose" / f"{sid}_orbit_eci_zyxvecs.npy", orb)
+    errors, times = errors_eval.run_folder(str(folder), ba=_oracle_ba)
+    e = np.load(folder / "errors.npy", allow_pickle=True)
+    t = np.load(folder / "times.npy", allow_pickle=True)
+    assert len(e) == 2 and len(t) == 2
+    assert np.allclose(e[0], load_golden("c1")["errors"], rtol=1e-6)
+    tt = errors_eval.time_to_error(e, t, threshold_km=5.0)
+    assert tt.shape == (2,) and tt[0] == t[0][np.argmax(e[0] < 5.0)]
+    assert np.isnan(errors_eval.time_to_error([np.array([9.0, 8.0])], [np.array([1, 2])])[0])

@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvinsat_ba.so")
+# VBA_LIB selects another build of the same library (A/B timing of two builds on one device)
+LIB_PATH = os.environ.get("VBA_LIB") or os.path.join(_HERE, "libvinsat_ba.so")
 
 PD = POINTER(c_double)
 PI64 = POINTER(c_int64)

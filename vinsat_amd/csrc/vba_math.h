@@ -84,22 +84,37 @@ VBA_HD void project_jacobian(const PoseCam& pc, const double* cam, double d, dou
 // ------------------------------------------------------------------------------------------------ weights
 struct RobustParams {
     double c;           // lower median of |r| (BA_filtering.py:23)
+    double inv_c;       // 1/c
     double inv_c2;      // 1/c^2
+    double inv_am2;     // 1/|alpha-2| (inf at alpha == 2, unused there)
     double am2;         // |alpha-2|
     double expo;        // alpha/2 - 1
     int alpha_is_2;     // alpha == 2: ((r/c)^2/0 + 1)^0 == 1 by IEEE inf**0 / nan**0 (BA_filtering.py:24)
     int expo_is_mhalf;  // alpha == 1 (every call from iter 3 on): x^(-1/2) = 1/sqrt(x), no pow() needed
 };
 
+// x^(-1/2) for x >= 1: on the device v_rsq_f64 refined by two Newton steps (~1 ulp); the IEEE sqrt + divide
+// sequence is ~8x as many instructions and this sits in the per-observation loop of an issue-bound kernel
+VBA_HD double inv_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y;
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
 // mean over the two pixel components of the Barron-style weight (BA_filtering.py:24), before /max and *conf
 VBA_HD double robust_weight_raw(const RobustParams& rp, double ru, double rv) {
     if (rp.alpha_is_2) return rp.inv_c2;
-    const double su = ru / rp.c, sv = rv / rp.c;
-    const double xu = su * su / rp.am2 + 1.0, xv = sv * sv / rp.am2 + 1.0;
+    const double su = ru * rp.inv_c, sv = rv * rp.inv_c;
+    const double xu = su * su * rp.inv_am2 + 1.0, xv = sv * sv * rp.inv_am2 + 1.0;
     double wu, wv;
     if (rp.expo_is_mhalf) {
-        wu = (1.0 / sqrt(xu)) * rp.inv_c2;
-        wv = (1.0 / sqrt(xv)) * rp.inv_c2;
+        wu = inv_sqrt(xu) * rp.inv_c2;
+        wv = inv_sqrt(xv) * rp.inv_c2;
     } else {
         wu = pow(xu, rp.expo) * rp.inv_c2;
         wv = pow(xv, rp.expo) * rp.inv_c2;

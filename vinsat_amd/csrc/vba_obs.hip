@@ -194,8 +194,10 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     const StepParams& prm = V.prm;
     RobustParams rp;
     rp.c = sc.c_obs;
+    rp.inv_c = 1.0 / rp.c;
     rp.inv_c2 = 1.0 / (rp.c * rp.c);
     rp.am2 = prm.am2;
+    rp.inv_am2 = 1.0 / prm.am2;
     rp.expo = prm.expo;
     rp.alpha_is_2 = prm.alpha_is_2;
     rp.expo_is_mhalf = prm.expo == -0.5;
@@ -213,15 +215,29 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
         pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
         const int* ptr = V.pose_ptr + (size_t)w * (V.n_max + 1);
         const int beg = ptr[i], end = ptr[i + 1];
-        for (int k = beg + sub; k < end; k += G) {
+        // software pipelined: the loads of observation k + G are in flight while k is processed
+        struct Obs { double x, y, z, u, v, c; };
+        auto load = [&](int k) {
+            Obs o;
+            o.x = V.ox[ob + k]; o.y = V.oy[ob + k]; o.z = V.oz[ob + k];
+            o.u = V.ou[ob + k]; o.v = V.ov[ob + k]; o.c = V.oconf[ob + k];
+            return o;
+        };
+        int k = beg + sub;
+        Obs cur = {0, 0, 0, 0, 0, 0};
+        if (k < end) cur = load(k);
+        while (k < end) {
+            const int kn = k + G;
+            Obs nxt = cur;
+            if (kn < end) nxt = load(kn);
             double u, v, cam[3], d, J[12];
-            project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
+            project(pc, cur.x, cur.y, cur.z, u, v, cam, d);
             project_jacobian(pc, cam, d, J);
-            const double ru = V.ou[ob + k] - u, rv = V.ov[ob + k] - v;
+            const double ru = cur.u - u, rv = cur.v - v;
             const double wr = robust_weight_raw(rp, ru, rv);
             V.wraw[ob + k] = wr;
             wmax_l = fmax(wmax_l, wr);
-            const double wc = wr * V.oconf[ob + k];
+            const double wc = wr * cur.c;
             int q = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -230,6 +246,8 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
                 for (int b = a; b < 6; ++b) { acc[q] += ja * J[b] + jb * J[6 + b]; ++q; }
                 acc[21 + a] += ja * ru + jb * rv;
             }
+            cur = nxt;
+            k = kn;
         }
     }
 #pragma unroll
