@@ -129,6 +129,13 @@ int vba_get_states(vba_handle h, int window, double* states, double* lamda, doub
  * `initialize` != 0 is the landmark-only phase (BA_utils.py:463-466).  Synchronous. */
 int vba_step(vba_handle h, int iter, int initialize);
 
+/* ncalls consecutive BA() calls on every window -- the driver's loop `for iter in range(20): BA(iter, ...)`
+ * (od_pipe.py:1036-1040) -- issued as one host call: iters[c] / inits[c] are the `iter` and `initialize` arguments
+ * of call c.  The calls are chained on the device (a window that needs further LM trials in some call stalls there
+ * and is finished by the host before the rest is re-issued); the results are bit-identical to ncalls vba_step
+ * calls.  *trials_total (optional) receives the number of LM trials issued.  Synchronous. */
+int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* inits, int* trials_total);
+
 /* Convenience: set_states(window 0) + step + get_states(window 0); the exact shape of one BA() call. */
 int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in,
                 double* states_out, double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags);

@@ -593,3 +593,50 @@ def test_packed_sequential_solve_three_windows_per_wave(pivot):
     single = run(-2, 1)         # one window per handle, one window per wavefront
     for a, b in zip(packed, single):
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[3] == b[3]
+
+
+def test_run_schedule_equals_step_by_step(c2):
+    """vba_run_schedule chains the 20 calls on the device; it must give the same bits as 20 vba_step calls --
+    also when some windows need several LM trials (confidence 3 -> lamda exhaustion) or the pivoted fallback
+    (negative confidences) in the middle of the chain while others sail through."""
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    confs = [inp["conf"], np.full_like(inp["conf"], 3.0), np.where(inp["ii"] % 3 == 0, -0.5, inp["conf"]), inp["conf"] * 0.9]
+    iters = list(range(20))
+    inits = [k < 10 for k in range(20)]
+
+    def make(W):
+        e = BAEngine(n, m, windows=W)
+        e.set_accumulate_lanes(8)
+        return e
+
+    # reference: one engine per window, stepped call by call
+    ref = []
+    for conf in confs:
+        e = make(1)
+        e.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
+        e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+        e.set_states(g["states0"][0], 1e-4)
+        for it, init in zip(iters, inits):
+            e.step(it, init)
+        ref.append(e.get_states())
+        e.close()
+    # all four windows in one handle, one chained call
+    e = make(4)
+    for w, conf in enumerate(confs):
+        e.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n, window=w)
+        e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"], window=w)
+        e.set_states(g["states0"][0], 1e-4, window=w)
+    trials = e.run_schedule(iters, inits)
+    assert trials > 20
+    for w in range(4):
+        s, lam, hess, ntr, flags = e.get_states(window=w)
+        assert np.array_equal(s, ref[w][0]) and lam == ref[w][1] and np.array_equal(hess, ref[w][2]), w
+    assert rel_err(e.get_states(window=0)[0], g["states_out_19"][0]) < 1e-7
+    # a second run on the same handle (state of the call counters is reset)
+    for w in range(4):
+        e.set_states(g["states0"][0], 1e-4, window=w)
+    e.run_schedule(iters, inits)
+    assert np.array_equal(e.get_states(window=3)[0], ref[3][0])
+    e.close()

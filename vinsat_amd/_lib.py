@@ -34,6 +34,7 @@ SIGNATURES = {
     "vba_set_states": (c_int, [c_void_p, c_int, PD, c_double]),
     "vba_get_states": (c_int, [c_void_p, c_int, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
     "vba_step": (c_int, [c_void_p, c_int, c_int]),
+    "vba_run_schedule": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "vba_iterate": (c_int, [c_void_p, c_int, c_int, c_double, PD, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
     "vba_debug_fetch": (c_int, [c_void_p, c_int, c_int, PD, c_int64, PI64]),
     "vba_last_step_ms": (c_int, [c_void_p, POINTER(c_float)]),

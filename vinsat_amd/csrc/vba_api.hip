@@ -196,7 +196,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.cL = A.take<double>(W * PM * 171); V.cR = A.take<double>(W * PM * 171);
     V.rXs = A.take<double>(W * PM * 81); V.rzs = A.take<double>(W * PM * 9); V.rx = A.take<double>(W * PM * 9);
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
-    V.hop = 0; V.pivot = 0;
+    V.hop = 0; V.pivot = 0; V.call = -1;
     {   // solver choice: many windows supply their own parallelism; otherwise cut the chain into ~sqrt(n) chunks
         int cs = (int)std::ceil(std::sqrt((double)n_max));
         cs = std::min(std::max(cs, 2), 60);
@@ -488,8 +488,8 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
             all = all && head(h, w)->done;
             repeat = repeat || (head(h, w)->flags & 8u);
         }
-        if (repeat && !V.pivot) {       // a pivot check failed on the fast path: same trial again with row pivoting
-            V.pivot = 1;
+        if (repeat && V.pivot == 0) {   // a pivot check failed on the fast path: those windows repeat the trial with row pivoting
+            V.pivot = 2;
             h->fallbacks++;
             continue;
         }
@@ -511,6 +511,83 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
 }
 
 int vba_step(vba_handle h, int iter, int initialize) { return step_impl(h, iter, initialize, nullptr); }
+
+// The 20-call loop of the driver (od_pipe.py:1036-1040) as ONE host call.  The kernels of every call are enqueued
+// back to back with a single LM trial each; a window whose first trial is rejected (or whose unpivoted solve
+// fails its check) does not advance its device-side call counter, all later kernels skip it, and the host
+// finishes that call the ordinary way before re-enqueuing the rest.  Results are identical to ncalls vba_step calls.
+int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* inits, int* trials_total) {
+    if (!h || !iters || !inits || ncalls < 1) return fail(VBA_EINVAL, "bad argument");
+    if (int rc = ready(h)) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    DevView V = h->V;
+    V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
+    V.pack = 0;
+    if (V.chunk <= 0 && h->W >= 3 && !h->no_pack) {
+        V.pack = 1;
+        for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
+    }
+    launch_reset_calls(V, s);
+    for (int w = 0; w < h->W; ++w) { h->h_head[w].call_idx = 0; h->h_head[w].done = 0; h->h_head[w].flags = 0; }
+    long trials = 0;
+    int next = 0;
+    for (int guard = 0; guard <= ncalls; ++guard) {
+        // speculative part: calls next .. ncalls-1, one trial each
+        for (int c = next; c < ncalls; ++c) {
+            V.call = c;
+            V.pivot = h->pivot_mode;
+            fill_params(V.prm, iters[c], inits[c]);
+            const bool dyn = !inits[c];
+            if (dyn) {
+                HIPCHK(hipEventRecord(h->ev_fork, s));
+                HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+                launch_dynamics(V, h->aux_stream);
+                HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
+            }
+            launch_obs_residual(V, nullptr, s);
+            launch_select(V, s);
+            launch_obs_accumulate(V, s);
+            if (dyn) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+            launch_assemble(V, s);
+            launch_solve(V, inits[c], s);
+            launch_trial(V, s);
+            launch_decide(V, nullptr, 0, s);
+        }
+        HIPCHK(hipGetLastError());
+        if (int rc = read_heads(h)) return rc;
+        int minc = ncalls;
+        for (int w = 0; w < h->W; ++w) minc = std::min(minc, (int)head(h, w)->call_idx);
+        trials += (long)(ncalls - next);
+        if (minc >= ncalls) break;
+        // call `minc` is unfinished for at least one window: finish it with the ordinary LM loop
+        V.call = minc;
+        V.pivot = h->pivot_mode;
+        fill_params(V.prm, iters[minc], inits[minc]);
+        for (int trial = 0; trial < 24; ++trial) {
+            bool repeat = false, all = true;
+            for (int w = 0; w < h->W; ++w) {
+                if (head(h, w)->call_idx != minc) continue;
+                all = false;
+                repeat = repeat || (head(h, w)->flags & 8u);
+            }
+            if (all) break;
+            if (repeat && V.pivot == 0) { V.pivot = 2; h->fallbacks++; }
+            launch_solve(V, inits[minc], s);
+            launch_trial(V, s);
+            launch_decide(V, nullptr, 0, s);
+            HIPCHK(hipGetLastError());
+            if (int rc = read_heads(h)) return rc;
+            ++trials;
+        }
+        next = minc + 1;
+    }
+    if (trials_total) *trials_total = (int)trials;
+    h->stepped = true;
+    h->last_iter = iters[ncalls - 1];
+    h->last_init = inits[ncalls - 1];
+    return VBA_OK;
+}
 
 int vba_step_profiled(vba_handle h, int iter, int initialize, float* ms) {
     if (!ms) return fail(VBA_EINVAL, "null ms");

@@ -42,6 +42,8 @@ struct WinScalars {
     int n_trials;
     unsigned flags;
     unsigned sel_cnt;               // keys appended to the compacted select list
+    int call_idx;                   // calls of the current vba_run_schedule completed by this window
+    int pad2;
     unsigned long long sel_prefix[kSelPasses + 1];
     long long sel_rank[kSelPasses + 1];
     double last_hessian[81];
@@ -55,12 +57,13 @@ struct WinHead {
     int done;
     int n_trials;
     unsigned flags;
-    int pad;
+    int call_idx;
 };
 
 // Everything a kernel needs; passed by value.  Arrays of W windows use the *_max strides.
 struct DevView {
     int W, n_max;
+    int call;                       // >= 0: this launch belongs to call `call` of a schedule, windows elsewhere in it skip
     int64_t m_max;
     int nblk_obs;                   // ceil(m_max / kObsBlock)
     const int* n;                   // [W]
@@ -106,7 +109,7 @@ struct DevView {
     int chunk, p_max;
     int pack;                       // sequential driver: 1 = three windows per wavefront (needs equal pose counts)
     int hop;                        // orbit integrator: 0 = 1 s RK4 steps (reference CPU branch), 1 = <=100 s hops (predict_gpu)
-    int pivot;                      // 1: row pivoting inside the 9x9 blocks (safe path); 0: SPD fast path with a pivot check
+    int pivot;                      // which solver variants are launched: 0 unpivoted (checked) only, 1 pivoted only for every window, 2 both (per-window sticky choice)
     double* csol;                   // [W][n_max][19][9]  chunk solutions for the 19 right-hand sides
     double *cL, *cR;                // [W][p_max][19][9]  L_j / U_j times the neighbouring chunk solutions
     double *rXs, *rzs, *rx;         // reduced system over the separators, [W][p_max][81 | 9 | 9]
@@ -116,6 +119,11 @@ struct DevView {
     const double* abs_all;          // gathered |r| of all ranks or nullptr
     int64_t abs_all_count;
 };
+
+// Speculatively chained calls (vba_run_schedule): the kernels of call c are enqueued before call c-1 is known to
+// have finished with its first LM trial; a window that needs more trials (or a pivoted repeat) simply does not
+// advance its call counter, and every later kernel leaves it alone until the host has finished that call.
+#define VBA_SKIP_CALL(V, w) do { if ((V).call >= 0 && (V).sc[(w)].call_idx != (V).call) return; } while (0)
 
 // ------------------------------------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, kWave); }

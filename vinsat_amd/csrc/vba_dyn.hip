@@ -12,6 +12,7 @@ namespace vba {
 
 __global__ __launch_bounds__(256) void k_dynamics(DevView V) {
     const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
     const int n = V.n[w];
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int i = gid / kDynLanes, c = gid % kDynLanes;
@@ -69,6 +70,7 @@ constexpr int kAsmIn = 21 + 6 + 36 + 6 + 3 + 27;     // Hraw, braw, Phi, rorb, q
 __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     __shared__ double in[(kAsmPoses + 1) * kAsmIn];
     const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
     const int n = V.n[w];
     const int i0 = blockIdx.x * kAsmPoses;
     if (i0 >= n) return;

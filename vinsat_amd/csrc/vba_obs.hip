@@ -38,6 +38,7 @@ __global__ __launch_bounds__(kObsBlock) void k_obs_residual(DevView V, double* a
     __shared__ double red[kObsBlock / 64];
     __shared__ unsigned lh[HIST0 ? 1024 : 1];
     const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
     const int m = V.m[w];
     const size_t ob = (size_t)w * V.m_max;
     const int k = blockIdx.x * kObsBlock + threadIdx.x;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     __shared__ unsigned lh[kSelBins];
     __shared__ unsigned lds_u[260];
     const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
     const double* keys = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
     const int64_t count = V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w];
     if ((int64_t)blockIdx.x * 256 * ITEMS >= count) return;
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256) void k_select_final(DevView V) {
     __shared__ unsigned lh[kSelBins];
     __shared__ unsigned lds_u[260];
     const int w = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
     unsigned long long prefix;
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     __shared__ double wmx[4];
     constexpr int PPB = 256 / G;            // poses per block
     const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
     const int n = V.n[w];
     if (blockIdx.x * PPB >= n) return;
     WinScalars& sc = V.sc[w];
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     __shared__ double red[kObsBlock / 64];
     const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
     const WinScalars& sc = V.sc[w];
     if (sc.done) return;
     const int n = V.n[w], m = V.m[w];
@@ -341,6 +346,15 @@ __global__ __launch_bounds__(256) void k_broadcast_states(DevView V, int n, doub
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (w > 0 && k < n * 10) dst[k] = src[k];
     if (k == 0) V.sc[w].lamda = lamda;
+}
+
+__global__ void k_reset_calls(DevView V) {
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    if (w < V.W) V.sc[w].call_idx = 0;
+}
+
+void launch_reset_calls(const DevView& V, hipStream_t s) {
+    hipLaunchKernelGGL(k_reset_calls, dim3((V.W + 63) / 64), dim3(64), 0, s, V);
 }
 
 void launch_broadcast_states(const DevView& V, int n, double lamda, hipStream_t s) {

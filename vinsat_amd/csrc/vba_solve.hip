@@ -162,11 +162,21 @@ __device__ __forceinline__ void forward_step(const double* Lmat, const double (&
 }
 
 // A failed pivot check: with row pivoting it is a numerically singular block (flag 4, result kept as in the
-// reference); without it the host is asked to repeat this solve with pivoting (internal flag 8).
+// reference); without it the host is asked to repeat this solve with pivoting (internal flag 8) and the window
+// stays on the pivoted kernels for the rest of the call (internal flag 16).  The choice is per window, so what one
+// window of a batch needs never changes the arithmetic of another.
+// V.pivot: 0 = only the unpivoted kernels are launched, 1 = only the pivoted ones and they take every window,
+// 2 = both are launched and each takes the windows whose sticky bit matches.
+template <bool PIVOT>
+__device__ __forceinline__ bool solver_mine(const DevView& V, const WinScalars& sc) {
+    if (V.pivot == 1) return PIVOT;
+    return ((sc.flags & 16u) != 0) == PIVOT;
+}
+
 template <bool PIVOT>
 __device__ __forceinline__ void report_pivot(bool bad, WinScalars& sc, int lane) {
     const unsigned long long any = __ballot(bad);
-    if (lane == 0 && any) atomicOr(&sc.flags, PIVOT ? 4u : 8u);
+    if (lane == 0 && any) atomicOr(&sc.flags, PIVOT ? 4u : (8u | 16u));
 }
 
 // ================================================================================================== sequential
@@ -295,8 +305,9 @@ template <bool PIVOT>
 __global__ __launch_bounds__(64) void k_solve(DevView V) {
     __shared__ double blk[2][256];
     const int w = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
-    if (sc.done) return;
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
     const int n = V.n[w];
     const int lane = threadIdx.x;
     const size_t sb = (size_t)w * V.n_max;
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(64) void k_solve_packed(DevView V) {
     const bool w_ok = w0 + g < V.W;
     const int n = V.n[w0];
     WinScalars& sc = V.sc[wg];
-    const bool active = lane_ok && w_ok && !sc.done;
+    const bool active = lane_ok && w_ok && !sc.done && (V.call < 0 || sc.call_idx == V.call) && solver_mine<PIVOT>(V, sc);
     const size_t sb = (size_t)wg * V.n_max;
     const double lam32 = (double)(float)sc.lamda;
     if (active && ll == 0) {
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(64) void k_solve_packed(DevView V) {
         const int w = w0 + q3;
         if (w >= V.W) break;
         WinScalars& s3 = V.sc[w];
-        if (s3.done) continue;
+        if (s3.done || (V.call >= 0 && s3.call_idx != V.call) || !solver_mine<PIVOT>(V, s3)) continue;
         const unsigned long long gm = ((1ull << 19) - 1ull) << (19 * q3);
         if (lane == 0 && (badmask & gm)) atomicOr(&s3.flags, PIVOT ? 4u : 8u);
         const bool bad = retract_range(V, (size_t)w * V.n_max, n, lane, 64);
@@ -464,8 +475,9 @@ template <bool PIVOT>
 __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int w = blockIdx.y, c = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
-    if (sc.done) return;
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
     const int n = V.n[w];
     if (c * s >= n) return;
     int a0, b0;
@@ -632,8 +644,9 @@ template <bool PIVOT>
 __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s) {
     __shared__ double blk[2][256];
     const int w = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
-    if (sc.done) return;
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
     const int n = V.n[w];
     const int P = (n + s - 1) / s;
     const int ns = P - 1;
@@ -652,6 +665,7 @@ __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s) {
 // s == 0: dpose already holds the solution (block-diagonal phase), only the retraction is done.
 __global__ __launch_bounds__(64) void k_solve_recover(DevView V, int s) {
     const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     if (sc.done) return;
     const int n = V.n[w];
@@ -703,8 +717,9 @@ template <bool PIVOT>
 __global__ __launch_bounds__(64) void k_solve_blockdiag(DevView V, int PB) {
     __shared__ double blk[2][128];
     const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
-    if (sc.done) return;
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
     const int n = V.n[w];
     const int i0 = blockIdx.x * PB;
     if (i0 >= n) return;
@@ -762,6 +777,7 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
     __shared__ double red[4];
     __shared__ double bc[2];
     const int w = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     if (sc.done) return;
     if (sc.flags & 8u) {            // the un-pivoted solve failed its check: the host repeats it with pivoting
@@ -840,6 +856,7 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
         sc.n_trials += 1;
         if (stop) {
             sc.done = 1;
+            if (V.call >= 0) sc.call_idx = V.call + 1;
             if (!accept) sc.flags |= 1u;
             if (!(residual == residual)) sc.flags |= 2u;
             sc.lamda = fmax(fmin(1e-1, lam * 0.01), 1e-4);
@@ -852,34 +869,31 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
         hh.n_trials = sc.n_trials;
         hh.flags = sc.flags;
         hh.done = stop ? 1 : 0;
+        hh.call_idx = sc.call_idx;
         __threadfence_system();
     }
 }
 
-void launch_solve(const DevView& V, int initialize, hipStream_t s) {
-    const bool pv = V.pivot != 0;
+template <bool PIVOT>
+static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s) {
     if (initialize) {       // block diagonal: independent poses
         const int PB = V.W >= 64 ? 8 : 2;
-        const dim3 g((V.n_max + PB - 1) / PB, V.W);
-        if (pv) hipLaunchKernelGGL(k_solve_blockdiag<true>, g, dim3(64), 0, s, V, PB);
-        else hipLaunchKernelGGL(k_solve_blockdiag<false>, g, dim3(64), 0, s, V, PB);
-        hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, 0);
+        hipLaunchKernelGGL(k_solve_blockdiag<PIVOT>, dim3((V.n_max + PB - 1) / PB, V.W), dim3(64), 0, s, V, PB);
         return;
     }
     if (V.chunk <= 0) {
-        if (V.pack) {       // equal pose counts: three windows per wavefront
-            const dim3 g((V.W + kPack - 1) / kPack);
-            if (pv) hipLaunchKernelGGL(k_solve_packed<true>, g, dim3(64), 0, s, V);
-            else hipLaunchKernelGGL(k_solve_packed<false>, g, dim3(64), 0, s, V);
-            return;
-        }
-        if (pv) hipLaunchKernelGGL(k_solve<true>, dim3(V.W), dim3(64), 0, s, V);
-        else hipLaunchKernelGGL(k_solve<false>, dim3(V.W), dim3(64), 0, s, V);
+        if (V.pack) hipLaunchKernelGGL(k_solve_packed<PIVOT>, dim3((V.W + kPack - 1) / kPack), dim3(64), 0, s, V);   // equal pose counts: three windows per wavefront
+        else hipLaunchKernelGGL(k_solve<PIVOT>, dim3(V.W), dim3(64), 0, s, V);
         return;
     }
     const int cs = V.chunk;
     const int P = (V.n_max + cs - 1) / cs;
     const size_t lds = (512 + (size_t)cs * 81 + (size_t)cs * 171 + 162) * sizeof(double);
+    hipLaunchKernelGGL(k_solve_chunks<PIVOT>, dim3(P, V.W), dim3(64), lds, s, V, cs);
+    hipLaunchKernelGGL(k_solve_reduced<PIVOT>, dim3(V.W), dim3(64), 0, s, V, cs);
+}
+
+void launch_solve(const DevView& V, int initialize, hipStream_t s) {
     static bool lds_attr_set = false;
     if (!lds_attr_set) {     // chunks above ~30 poses need more than the default 64 KiB of dynamic LDS
         const int cap = (int)((512 + 60 * 252 + 162) * sizeof(double));
@@ -887,14 +901,11 @@ void launch_solve(const DevView& V, int initialize, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         lds_attr_set = true;
     }
-    if (pv) {
-        hipLaunchKernelGGL(k_solve_chunks<true>, dim3(P, V.W), dim3(64), lds, s, V, cs);
-        hipLaunchKernelGGL(k_solve_reduced<true>, dim3(V.W), dim3(64), 0, s, V, cs);
-    } else {
-        hipLaunchKernelGGL(k_solve_chunks<false>, dim3(P, V.W), dim3(64), lds, s, V, cs);
-        hipLaunchKernelGGL(k_solve_reduced<false>, dim3(V.W), dim3(64), 0, s, V, cs);
-    }
-    hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, cs);
+    if (V.pivot != 1) launch_solve_variant<false>(V, initialize, s);
+    if (V.pivot != 0) launch_solve_variant<true>(V, initialize, s);
+    // interiors / retraction: shared by both variants (k_solve and k_solve_packed retract themselves)
+    if (initialize) hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, 0);
+    else if (V.chunk > 0) hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, V.chunk);
 }
 
 void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStream_t s) {

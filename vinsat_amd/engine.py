@@ -102,6 +102,15 @@ class BAEngine:
     def step(self, it, initialize):
         _lib.check(self.lib.vba_step(self.h, int(it), int(bool(initialize))), self.lib)
 
+    def run_schedule(self, iters, inits):
+        """len(iters) consecutive BA() calls chained on the device (one host call); returns the LM trials issued."""
+        n = len(iters)
+        a = (c_int * n)(*[int(x) for x in iters])
+        b = (c_int * n)(*[int(bool(x)) for x in inits])
+        t = c_int()
+        _lib.check(self.lib.vba_run_schedule(self.h, n, a, b, byref(t)), self.lib)
+        return t.value
+
     def iterate(self, it, initialize, lamda, states):
         """One ``BA()`` call on window 0: returns (states_new, lamda_out, last_hessian, n_trials, flags)."""
         s = _f64(states).reshape(-1, 10)
