@@ -7,6 +7,7 @@ One "step" is one call of BA() (reference estimation/BA/BA_filtering.py:4-98) th
 input already resident in HBM.  The steps walk the reference driver's own schedule (od_pipe.py:1036-1040):
 20 calls per window -- 10 landmark-only (initialize=True) then 10 full -- restarting from the perturbed
 initial guess after each 20, so the mix of kernels is the one the reference's 20-iteration loop executes.
+The 20 calls of a schedule are issued with one host call (vba_run_schedule) and chained on the device.
 
 N = 1 : one window (BASELINE.json configs[2], the headline config) on one GPU -- a latency-bound chain.
 N > 1 : one process per GPU (torchrun / torch.distributed, backend nccl = RCCL); every rank runs its own
@@ -70,11 +71,16 @@ def schedule(k):
 
 
 def run_steps(eng, st0, nsteps, windows=1):
-    for k in range(nsteps):
-        it, init = schedule(k)
-        if it == 0:
-            eng.set_states(st0, 1e-4, window=-1 if windows > 1 else 0)
-        eng.step(it, init)
+    """nsteps BA() calls walking the 20-call schedule; each schedule is issued through vba_run_schedule, i.e. the
+    driver's loop `for iter in range(20): BA(iter, ...)` (od_pipe.py:1036-1040) as one host call whose calls are
+    chained on the device (bit-identical to call-by-call stepping, tests/test_gpu_parity.py)."""
+    k = 0
+    while k < nsteps:
+        cnt = min(20, nsteps - k)
+        eng.set_states(st0, 1e-4, window=-1 if windows > 1 else 0)
+        calls = [schedule(j) for j in range(cnt)]
+        eng.run_schedule([c[0] for c in calls], [c[1] for c in calls])
+        k += cnt
 
 
 def cpu_baseline(win, st0, budget_s):

@@ -84,6 +84,9 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external);
  * (~sqrt(n_max), or 0 for >= 128 windows).  With chunk = 0 and equal pose counts three windows share one
  * wavefront; chunk = -2 is chunk = 0 with one window per wavefront.  All variants agree to rounding. */
 int vba_set_solver(vba_handle h, int chunk);
+/* Explicit two-level partition: chunks of `chunk` poses, the reduced system over their separators cut again into
+ * chunks of `chunk2` separators (0 = single level).  The default (-1) uses two levels of ~n^(1/3) from 128 poses on. */
+int vba_set_solver2(vba_handle h, int chunk, int chunk2);
 
 /* Orbit integrator of the dynamics factor.  0 (default): one-second RK4 steps, the reference's CPU branch `predict`
  * (BA_utils.py:73-87) -- the parity target.  1: the coarse schedule of `propagate_orbit_dynamics_skip`

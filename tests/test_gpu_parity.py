@@ -23,14 +23,17 @@ def eng_c1(c1, request):
     e.close()
 
 
-@pytest.fixture(scope="module", params=[(-1, False), (0, False), (7, False), (-1, True), (0, True)],
-                ids=["partitioned", "sequential", "chunk7", "partitioned-pivot", "sequential-pivot"])
+@pytest.fixture(scope="module", params=[(-1, False), (0, False), (7, False), (-1, True), (0, True), ((5, 4), False), ((3, 2), True)],
+                ids=["partitioned", "sequential", "chunk7", "partitioned-pivot", "sequential-pivot", "two-level-5-4", "two-level-3-2-pivot"])
 def eng_c2(c2, request):
     from vinsat_amd.engine import BAEngine
     inp = golden_inputs(c2)
     n, m = inp["K"].shape[0], inp["xyz"].shape[0]
     e = BAEngine(n, m)
-    e.set_solver(request.param[0])
+    if isinstance(request.param[0], tuple):
+        e.set_solver(*request.param[0])
+    else:
+        e.set_solver(request.param[0])
     e.set_pivoting(request.param[1])
     e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
     e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])

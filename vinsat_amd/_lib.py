@@ -25,6 +25,7 @@ SIGNATURES = {
     "vba_destroy": (c_int, [c_void_p]),
     "vba_set_stream": (c_int, [c_void_p, c_void_p, c_int]),
     "vba_set_solver": (c_int, [c_void_p, c_int]),
+    "vba_set_solver2": (c_int, [c_void_p, c_int, c_int]),
     "vba_set_pivoting": (c_int, [c_void_p, c_int]),
     "vba_set_accumulate_lanes": (c_int, [c_void_p, c_int]),
     "vba_set_integrator": (c_int, [c_void_p, c_int]),

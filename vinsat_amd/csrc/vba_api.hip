@@ -115,6 +115,7 @@ int ready(vba_handle h) {
 extern "C" {
 
 int vba_set_accumulate_lanes(vba_handle h, int lanes);
+int vba_set_solver(vba_handle h, int chunk);
 
 int vba_version(void) { return 100; }
 
@@ -158,7 +159,8 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     const size_t per_pose = 21 + 6 + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
     need(W * N * per_pose * 8 + 16 * 256);
     need(W * N * 171 * 8);
-    need(W * N * (171 + 171 + 81 + 9 + 9) * 8 + 6 * 256);     // reduced system (p_max <= n_max / 2 + 1)
+    need(W * N * (171 + 171 + 81 + 9 + 9) * 8 + 6 * 256);
+    need(W * N * (171 * 3 + 9) * 8 + 6 * 256);              // second level (over-sized: p_max <= n_max / 2 + 1)
     bytes += 1 << 16;
     if (hipMalloc(&h->arena.base, bytes) != hipSuccess) {
         delete h;
@@ -195,18 +197,16 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.csol = A.take<double>(W * N * 171);
     V.cL = A.take<double>(W * PM * 171); V.cR = A.take<double>(W * PM * 171);
     V.rXs = A.take<double>(W * PM * 81); V.rzs = A.take<double>(W * PM * 9); V.rx = A.take<double>(W * PM * 9);
+    V.csol2 = A.take<double>(W * PM * 171); V.cL2 = A.take<double>(W * PM * 171); V.cR2 = A.take<double>(W * PM * 171);
+    V.rx2 = A.take<double>(W * PM * 9);
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
     V.hop = 0; V.pivot = 0; V.call = -1;
-    {   // solver choice: many windows supply their own parallelism; otherwise cut the chain into ~sqrt(n) chunks
-        int cs = (int)std::ceil(std::sqrt((double)n_max));
-        cs = std::min(std::max(cs, 2), 60);
-        V.chunk = (windows >= 128 || n_max < 8) ? 0 : cs;
-    }
+    V.chunk = 0; V.chunk2 = 0;      // set after construction by vba_set_solver(h, -1)
     {   // every device array a kernel may touch must have been carved: a null here would fault on the GPU
         const void* must[] = {V.n, V.m, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
                               V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.absr, V.wraw, V.ckeys, V.part_init,
                               V.part_trial, V.hist, V.Hraw, V.braw, V.xhat, V.Phi, V.rorb, V.fatt, V.qgrad, V.Hd, V.Hu, V.Hl,
-                              V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx};
+                              V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx, V.csol2, V.cL2, V.cR2, V.rx2};
         bool ok = A.used <= A.size;
         for (const void* q : must) ok = ok && q != nullptr;
         if (!ok) {
@@ -230,6 +230,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     h->have_obs.assign(W, 0); h->have_win.assign(W, 0); h->have_state.assign(W, 0);
     h->perm.resize(W);
     vba_set_accumulate_lanes(h, 0);
+    vba_set_solver(h, -1);
     *out = h;
     return VBA_OK;
 }
@@ -250,18 +251,37 @@ int vba_destroy(vba_handle h) {
     return VBA_OK;
 }
 
+int vba_set_solver2(vba_handle h, int chunk, int chunk2) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (chunk < 2 || chunk > 60 || (chunk2 != 0 && (chunk2 < 2 || chunk2 > 60)))
+        return fail(VBA_EINVAL, "chunk sizes must be in [2, 60] (chunk2 = 0: single level)");
+    h->V.chunk = chunk;
+    h->V.chunk2 = chunk2;
+    h->no_pack = 0;
+    return VBA_OK;
+}
+
 int vba_set_solver(vba_handle h, int chunk) {
     if (!h) return fail(VBA_EINVAL, "null handle");
-    if (chunk == -1) {
-        int cs = (int)std::ceil(std::sqrt((double)h->n_max));
-        chunk = (h->W >= 128 || h->n_max < 8) ? 0 : std::min(std::max(cs, 2), 60);
+    h->V.chunk2 = 0;
+    if (chunk == -1) {      // default: many windows supply their own parallelism; a long chain is cut on two levels
+        h->no_pack = 0;     // (~n^(1/3) poses per chunk), a short one on one level (~sqrt(n))
+        if (h->W >= 128 || h->n_max < 8) { h->V.chunk = 0; return VBA_OK; }
+        if (h->n_max >= 128) {
+            const int c3 = std::min(std::max((int)std::ceil(std::cbrt((double)h->n_max)), 2), 60);
+            h->V.chunk = c3;
+            h->V.chunk2 = c3;
+        } else {
+            h->V.chunk = std::min(std::max((int)std::ceil(std::sqrt((double)h->n_max)), 2), 60);
+        }
+        return VBA_OK;
     }
     if (chunk == -2) {      // sequential, one window per wavefront (no packing): diagnostic / comparison
         h->V.chunk = 0;
         h->no_pack = 1;
         return VBA_OK;
     }
-    if (chunk == 1 || chunk > 60) return fail(VBA_EINVAL, "chunk must be 0 (sequential) or in [2, 60]");
+    if (chunk < 0 || chunk == 1 || chunk > 60) return fail(VBA_EINVAL, "chunk must be -2, -1, 0 or in [2, 60]");
     h->V.chunk = chunk;
     h->no_pack = 0;
     return VBA_OK;

@@ -107,12 +107,14 @@ struct DevView {
     double* dpose;                  // [9]
     // partitioned solve: chunk size (0 = one wave walks the whole chain), separators per window <= p_max
     int chunk, p_max;
+    int chunk2;                     // > 0: the reduced system over the separators is partitioned again with this chunk size
     int pack;                       // sequential driver: 1 = three windows per wavefront (needs equal pose counts)
     int hop;                        // orbit integrator: 0 = 1 s RK4 steps (reference CPU branch), 1 = <=100 s hops (predict_gpu)
     int pivot;                      // which solver variants are launched: 0 unpivoted (checked) only, 1 pivoted only for every window, 2 both (per-window sticky choice)
     double* csol;                   // [W][n_max][19][9]  chunk solutions for the 19 right-hand sides
     double *cL, *cR;                // [W][p_max][19][9]  L_j / U_j times the neighbouring chunk solutions
     double *rXs, *rzs, *rx;         // reduced system over the separators, [W][p_max][81 | 9 | 9]
+    double *csol2, *cL2, *cR2, *rx2;  // second level: chunk solutions over the level-1 separators, [W][p_max][...]
     int nblk_dyn;                   // ceil(n_max / kObsBlock)
     // sharded mode: number of observation rows over all ranks (0 = not sharded) and external key buffer
     int64_t m_total;

@@ -469,53 +469,62 @@ __device__ __forceinline__ void chunk_range(int c, int s, int n, int& a, int& b,
     b = has_sep ? end - 2 : end - 1;            // last interior block
 }
 
-// Eliminates the interior of one chunk with 19 right-hand sides: column 0 = g, 1..9 = L_a (coupling to the left
-// separator), 10..18 = U_b (coupling to the right separator).  sol[i][col][r] receives T^{-1} of them.
-template <bool PIVOT>
-__global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int w = blockIdx.y, c = blockIdx.x;
-    VBA_SKIP_CALL(V, w);
-    WinScalars& sc = V.sc[w];
-    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
-    const int n = V.n[w];
-    if (c * s >= n) return;
+// Reduced system over the separators of a chain given by `Inner`: row q couples separators q-1, q, q+1 (block
+// j = (q+1) s - 1 of the inner chain):
+//   sub = -L_j Vhat_{j-1},  diag = D_j - L_j What_{j-1} - U_j Vhat_{j+1},  super = -U_j What_{j+1},
+//   rhs = g_j - L_j yhat_{j-1} - U_j yhat_{j+1};   the products were left in cL / cR by the chunk waves.
+// It is again a block source, so the same chunk elimination can be applied to it (second level).
+template <class Inner>
+struct ReducedSource {
+    Inner inner;
+    const double* cL;       // [ns][19][9]
+    const double* cR;
+    int s;
+    __device__ double operator()(int q, int e) const {
+        const int j = (q + 1) * s - 1;
+        const double* l = cL + (size_t)q * 171;
+        const double* r_ = cR + (size_t)q * 171;
+        if (e >= 243) {
+            const int r = e - 243;
+            return inner(j, e) - l[r] - r_[r];
+        }
+        const int which = e / 81, r = (e % 81) / 9, cc = e % 9;
+        if (which == 0) return -l[(1 + cc) * 9 + r];
+        if (which == 2) return -r_[(10 + cc) * 9 + r];
+        return inner(j, e) - l[(10 + cc) * 9 + r] - r_[(1 + cc) * 9 + r];
+    }
+};
+
+// Eliminates the interior of chunk c of a chain of n blocks with 19 right-hand sides: column 0 = g, 1..9 = L_a
+// (coupling to the left separator), 10..18 = U_b (coupling to the right separator).  csol[i][col][r] receives
+// T^{-1} of them for every interior block i; cL[c] / cR[c-1] receive L_j / U_j times the solutions next to the
+// chunk's two separators (what the reduced system needs).
+template <bool PIVOT, bool SPARSE_L, class Src>
+__device__ __forceinline__ void chunk_eliminate(const Src& src, int n, int s, int c, double lam32, double* csol, double* cL,
+                                                double* cR, double* smem, int lane, bool& zero_pivot) {
     int a0, b0;
     bool has_sep;
     chunk_range(c, s, n, a0, b0, has_sep);
     const int len = b0 - a0 + 1;
-    const int lane = threadIdx.x;
-    const size_t sb = (size_t)w * V.n_max;
-    const double lam32 = (double)(float)sc.lamda;
-    if (c == 0 && lane == 0) {
-        sc.lam32 = lam32;
-        if (PIVOT) atomicAnd(&sc.flags, ~8u);
-    }
     double (*blk)[256] = reinterpret_cast<double (*)[256]>(smem);           // [2][256]
     double* Xb = smem + 512;                                                 // [s][81]
     double* Zb = Xb + (size_t)s * 81;                                        // [s][19][9]
     double* Cm = Zb + (size_t)s * 171;                                       // [2][81]: L of the right separator, U of the left one
-    const double* bands = V.bands + sb * 243;
-    const double* rhs = V.rhs + sb * 9;
     for (int e = lane; e < 162; e += 64) {
         double v = 0.0;
-        if (e < 81) { if (has_sep) v = bands[(size_t)(b0 + 1) * 243 + e]; }
-        else if (c > 0) v = bands[(size_t)(a0 - 1) * 243 + 162 + (e - 81)];
+        if (e < 81) { if (has_sep) v = src(b0 + 1, e); }
+        else if (c > 0) v = src(a0 - 1, 162 + (e - 81));
         Cm[e] = v;
     }
-
     double a[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) a[j] = 0.0;
-    bool zero_pivot = false;
     double pre[4];
     auto fetch = [&](int i) {
-        const double* src = bands + (size_t)i * 243;
-        const double* rsrc = rhs + (size_t)i * 9;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = lane + 64 * q;
-            pre[q] = e < 243 ? src[e] : (e < 252 ? rsrc[e - 243] : 0.0);
+            pre[q] = e < 252 ? src(i, e) : 0.0;
         }
     };
     auto stash = [&](int buf) {
@@ -548,10 +557,10 @@ __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
         double base[9];
         if (buf == 0) {
             load_base(blk[0], 0, t == 0, t == len - 1, base);
-            forward_step<0, 19, PIVOT, true>(t > 0 ? blk[0] : nullptr, base, a, lane, zero_pivot);
+            forward_step<0, 19, PIVOT, SPARSE_L>(t > 0 ? blk[0] : nullptr, base, a, lane, zero_pivot);
         } else {
             load_base(blk[1], 9, false, t == len - 1, base);
-            forward_step<9, 19, PIVOT, true>(blk[1], base, a, lane, zero_pivot);
+            forward_step<9, 19, PIVOT, SPARSE_L>(blk[1], base, a, lane, zero_pivot);
         }
         const int ub = buf == 0 ? 9 : 0;
         if (lane >= ub && lane < ub + 9) {
@@ -569,14 +578,14 @@ __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
     double x[9];
 #pragma unroll
     for (int r = 0; r < 9; ++r) x[r] = Zb[((size_t)(len - 1) * 19 + col) * 9 + r];
-    double* out = V.csol + (sb + a0) * 171;
+    double* out = csol + (size_t)a0 * 171;
     if (lane < 19) {
 #pragma unroll
         for (int r = 0; r < 9; ++r) out[((size_t)(len - 1) * 19 + col) * 9 + r] = x[r];
     }
     // contribution of this chunk to its right separator j = b+1:  L_j [yhat_b | Vhat_b | What_b]
     if (has_sep && lane < 19) {
-        double* cl = V.cL + ((size_t)w * V.p_max + c) * 171 + (size_t)col * 9;
+        double* cl = cL + (size_t)c * 171 + (size_t)col * 9;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             double v = 0.0;
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
     }
     // contribution to the left separator j = a-1:  U_j [yhat_a | Vhat_a | What_a]
     if (c > 0 && lane < 19) {
-        double* cr = V.cR + ((size_t)w * V.p_max + c - 1) * 171 + (size_t)col * 9;
+        double* cr = cR + (size_t)(c - 1) * 171 + (size_t)col * 9;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             double v = 0.0;
@@ -612,57 +621,129 @@ __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
             cr[r] = v;
         }
     }
-    report_pivot<PIVOT>(zero_pivot, sc, lane);
 }
 
-// Reduced system over the separators: row q couples separators q-1, q, q+1 (block j = (q+1) s - 1 of the chain):
-//   sub = -L_j Vhat_{j-1},  diag = D_j - L_j What_{j-1} - U_j Vhat_{j+1},  super = -U_j What_{j+1},
-//   rhs = g_j - L_j yhat_{j-1} - U_j yhat_{j+1};   the products were left in cL / cR by the chunk waves.
-struct ReducedSource {
-    const double* bands;    // of the window
-    const double* rhs;
-    const double* cL;       // [ns][19][9]
-    const double* cR;
-    int s;
-    __device__ double operator()(int q, int e) const {
-        const int j = (q + 1) * s - 1;
-        const double* l = cL + (size_t)q * 171;
-        const double* r_ = cR + (size_t)q * 171;
-        if (e >= 243) {
-            const int r = e - 243;
-            return rhs[(size_t)j * 9 + r] - l[r] - r_[r];
-        }
-        const int which = e / 81, r = (e % 81) / 9, cc = e % 9;
-        if (which == 0) return -l[(1 + cc) * 9 + r];
-        if (which == 2) return -r_[(10 + cc) * 9 + r];
-        return bands[(size_t)j * 243 + 81 + r * 9 + cc] - l[(10 + cc) * 9 + r] - r_[(1 + cc) * 9 + r];
-    }
-};
+// number of separators of a chain of n blocks cut into chunks of s
+__device__ __forceinline__ int n_separators(int n, int s) { return (n + s - 1) / s - 1; }
 
-// Solves the reduced block-tridiagonal system over the separators (one wave per window).
+// level 1: chunks of the window's own chain
 template <bool PIVOT>
-__global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s) {
+__global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int w = blockIdx.y, c = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n = V.n[w];
+    if (c * s >= n) return;
+    const int lane = threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lamda;
+    if (c == 0 && lane == 0) {
+        sc.lam32 = lam32;
+        if (PIVOT) atomicAnd(&sc.flags, ~8u);
+    }
+    bool bad = false;
+    const BandSource src{V.bands + sb * 243, V.rhs + sb * 9};
+    chunk_eliminate<PIVOT, true>(src, n, s, c, lam32, V.csol + sb * 171, V.cL + rb * 171, V.cR + rb * 171, smem, lane, bad);
+    report_pivot<PIVOT>(bad, sc, lane);
+}
+
+// level 2: the reduced system over the level-1 separators is itself cut into chunks of s2
+template <bool PIVOT>
+__global__ __launch_bounds__(64) void k_solve_chunks2(DevView V, int s, int s2) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int w = blockIdx.y, c = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n1 = n_separators(V.n[w], s);
+    if (n1 <= 0 || c * s2 >= n1) return;
+    const int lane = threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lamda;
+    bool bad = false;
+    const ReducedSource<BandSource> src{BandSource{V.bands + sb * 243, V.rhs + sb * 9}, V.cL + rb * 171, V.cR + rb * 171, s};
+    chunk_eliminate<PIVOT, false>(src, n1, s2, c, lam32, V.csol2 + rb * 171, V.cL2 + rb * 171, V.cR2 + rb * 171, smem, lane, bad);
+    report_pivot<PIVOT>(bad, sc, lane);
+}
+
+// Solves the last reduced block-tridiagonal system (one wave per window): over the level-1 separators (s2 == 0)
+// or over the level-2 separators.
+template <bool PIVOT>
+__global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s, int s2) {
     __shared__ double blk[2][256];
     const int w = blockIdx.x;
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
-    const int n = V.n[w];
-    const int P = (n + s - 1) / s;
-    const int ns = P - 1;
-    if (ns <= 0) return;
+    const int n1 = n_separators(V.n[w], s);
+    if (n1 <= 0) return;
     const int lane = threadIdx.x;
     const size_t sb = (size_t)w * V.n_max;
     const size_t rb = (size_t)w * V.p_max;
     const double lam32 = (double)(float)sc.lamda;
-    const ReducedSource src{V.bands + sb * 243, V.rhs + sb * 9, V.cL + rb * 171, V.cR + rb * 171, s};
+    const ReducedSource<BandSource> src1{BandSource{V.bands + sb * 243, V.rhs + sb * 9}, V.cL + rb * 171, V.cR + rb * 171, s};
     bool zero_pivot = false;
-    chain_solve<PIVOT, false>(src, ns, lam32, V.rXs + rb * 81, V.rzs + rb * 9, V.rx + rb * 9, blk, lane, zero_pivot);
+    if (s2 == 0) {
+        chain_solve<PIVOT, false>(src1, n1, lam32, V.rXs + rb * 81, V.rzs + rb * 9, V.rx + rb * 9, blk, lane, zero_pivot);
+    } else {
+        const int n2 = n_separators(n1, s2);
+        if (n2 > 0) {
+            const ReducedSource<ReducedSource<BandSource>> src2{src1, V.cL2 + rb * 171, V.cR2 + rb * 171, s2};
+            chain_solve<PIVOT, false>(src2, n2, lam32, V.rXs + rb * 81, V.rzs + rb * 9, V.rx2 + rb * 9, blk, lane, zero_pivot);
+        }
+    }
     report_pivot<PIVOT>(zero_pivot, sc, lane);
 }
 
-// x_i = yhat_i - Vhat_i x_left - What_i x_right for interior blocks, separators copied; then the retraction.
-// s == 0: dpose already holds the solution (block-diagonal phase), only the retraction is done.
+// Recovery of a partitioned chain: x_i = yhat_i - Vhat_i x_left - What_i x_right for interior blocks, separators
+// copied from the reduced solution.
+__device__ __forceinline__ void recover_block(int i, int n, int s, const double* csol, const double* xsep, double (&d9)[9]) {
+    const int c = i / s;
+    const int P = (n + s - 1) / s;
+    const bool is_sep = (c < P - 1) && (i == (c + 1) * s - 1);
+    if (is_sep) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) d9[r] = xsep[(size_t)c * 9 + r];
+        return;
+    }
+    const double* so = csol + (size_t)i * 171;
+    double xl[9], xr[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        xl[r] = c > 0 ? xsep[(size_t)(c - 1) * 9 + r] : 0.0;
+        xr[r] = c < P - 1 ? xsep[(size_t)c * 9 + r] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        double v = so[r];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v -= so[(1 + k) * 9 + r] * xl[k] + so[(10 + k) * 9 + r] * xr[k];
+        d9[r] = v;
+    }
+}
+
+// level 2 -> level 1: the solution of every level-1 separator
+__global__ __launch_bounds__(64) void k_solve_recover2(DevView V, int s, int s2) {
+    const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done) return;
+    const int n1 = n_separators(V.n[w], s);
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= n1) return;
+    const size_t rb = (size_t)w * V.p_max;
+    double d9[9];
+    recover_block(q, n1, s2, V.csol2 + rb * 171, V.rx2 + rb * 9, d9);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) V.rx[(rb + q) * 9 + r] = d9[r];
+}
+
+// x_i for every block of the window (s == 0: dpose already holds the solution, block-diagonal phase), then the
+// retraction (BA_filtering.py:56-60).
 __global__ __launch_bounds__(64) void k_solve_recover(DevView V, int s) {
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
@@ -674,31 +755,12 @@ __global__ __launch_bounds__(64) void k_solve_recover(DevView V, int s) {
     const size_t rb = (size_t)w * V.p_max;
     bool bad = false;
     if (i < n) {
-        const int c = s > 0 ? i / s : 0;
-        const int P = s > 0 ? (n + s - 1) / s : 1;
-        const bool is_sep = s > 0 && (c < P - 1) && (i == (c + 1) * s - 1);
         double d9[9];
         if (s == 0) {
 #pragma unroll
             for (int r = 0; r < 9; ++r) d9[r] = V.dpose[(sb + i) * 9 + r];
-        } else if (is_sep) {
-#pragma unroll
-            for (int r = 0; r < 9; ++r) d9[r] = V.rx[(rb + c) * 9 + r];
         } else {
-            const double* so = V.csol + (sb + i) * 171;
-            double xl[9], xr[9];
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                xl[r] = c > 0 ? V.rx[(rb + c - 1) * 9 + r] : 0.0;
-                xr[r] = c < P - 1 ? V.rx[(rb + c) * 9 + r] : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                double v = so[r];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) v -= so[(1 + k) * 9 + r] * xl[k] + so[(10 + k) * 9 + r] * xr[k];
-                d9[r] = v;
-            }
+            recover_block(i, n, s, V.csol + sb * 171, V.rx + rb * 9, d9);
         }
         double o[10];
 #pragma unroll
@@ -886,11 +948,16 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
         else hipLaunchKernelGGL(k_solve<PIVOT>, dim3(V.W), dim3(64), 0, s, V);
         return;
     }
-    const int cs = V.chunk;
+    const int cs = V.chunk, cs2 = V.chunk2;
     const int P = (V.n_max + cs - 1) / cs;
-    const size_t lds = (512 + (size_t)cs * 81 + (size_t)cs * 171 + 162) * sizeof(double);
+    const size_t lds = (512 + (size_t)cs * 252 + 162) * sizeof(double);
     hipLaunchKernelGGL(k_solve_chunks<PIVOT>, dim3(P, V.W), dim3(64), lds, s, V, cs);
-    hipLaunchKernelGGL(k_solve_reduced<PIVOT>, dim3(V.W), dim3(64), 0, s, V, cs);
+    if (cs2 > 0) {      // second level over the P-1 separators
+        const int P2 = (P - 1 + cs2 - 1) / cs2;
+        const size_t lds2 = (512 + (size_t)cs2 * 252 + 162) * sizeof(double);
+        hipLaunchKernelGGL(k_solve_chunks2<PIVOT>, dim3(P2 > 0 ? P2 : 1, V.W), dim3(64), lds2, s, V, cs, cs2);
+    }
+    hipLaunchKernelGGL(k_solve_reduced<PIVOT>, dim3(V.W), dim3(64), 0, s, V, cs, cs2);
 }
 
 void launch_solve(const DevView& V, int initialize, hipStream_t s) {
@@ -899,13 +966,18 @@ void launch_solve(const DevView& V, int initialize, hipStream_t s) {
         const int cap = (int)((512 + 60 * 252 + 162) * sizeof(double));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         lds_attr_set = true;
     }
     if (V.pivot != 1) launch_solve_variant<false>(V, initialize, s);
     if (V.pivot != 0) launch_solve_variant<true>(V, initialize, s);
     // interiors / retraction: shared by both variants (k_solve and k_solve_packed retract themselves)
     if (initialize) hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, 0);
-    else if (V.chunk > 0) hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, V.chunk);
+    else if (V.chunk > 0) {
+        if (V.chunk2 > 0) hipLaunchKernelGGL(k_solve_recover2, dim3((V.p_max + 63) / 64, V.W), dim3(64), 0, s, V, V.chunk, V.chunk2);
+        hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, V.chunk);
+    }
 }
 
 void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStream_t s) {

@@ -46,9 +46,13 @@ class BAEngine:
         except Exception:
             pass
 
-    def set_solver(self, chunk):
-        """0 = sequential chain, 2..60 = partitioned with that chunk size, <0 = default."""
-        _lib.check(self.lib.vba_set_solver(self.h, int(chunk)), self.lib)
+    def set_solver(self, chunk, chunk2=None):
+        """0 = sequential chain, 2..60 = partitioned with that chunk size (chunk2: second-level chunk size),
+        -1 = default, -2 = sequential without packing."""
+        if chunk2 is None:
+            _lib.check(self.lib.vba_set_solver(self.h, int(chunk)), self.lib)
+        else:
+            _lib.check(self.lib.vba_set_solver2(self.h, int(chunk), int(chunk2)), self.lib)
 
     def set_integrator(self, hop100):
         """False: 1 s RK4 steps (reference CPU branch, default); True: <=100 s hops (the reference's predict_gpu)."""
