@@ -481,7 +481,9 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
     if (!initialize && !overlap) launch_dynamics(V, s);
     if (overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     mark(5);
-    launch_assemble(V, s);
+    // landmark-only phase on the unpivoted path: the first trial's per-pose 6x6 solve + retraction ride in k_assemble
+    const bool fuse = initialize && h->pivot_mode == 0;
+    launch_assemble(V, fuse, s);
     mark(6);
     // LM loop (BA_filtering.py:52-77): lamda 1e-4 .. 1e4 in decades, at most 9 trials
     int rc_out = VBA_OK;
@@ -492,7 +494,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
         for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
     }
     for (int trial = 0; trial < 24; ++trial) {
-        launch_solve(V, initialize, s);
+        if (!(trial == 0 && fuse)) launch_solve(V, initialize, s);
         if (trial == 0) mark(7);
         launch_trial(V, s);
         if (trial == 0) mark(8);
@@ -569,8 +571,9 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             launch_select(V, s);
             launch_obs_accumulate(V, s);
             if (dyn) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
-            launch_assemble(V, s);
-            launch_solve(V, inits[c], s);
+            const bool fuse = inits[c] && h->pivot_mode == 0;
+            launch_assemble(V, fuse, s);
+            if (!fuse) launch_solve(V, inits[c], s);
             launch_trial(V, s);
             launch_decide(V, nullptr, 0, s);
         }
@@ -779,7 +782,7 @@ int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* 
         if (ranks < 1) return fail(VBA_EINVAL, "ranks must be >= 1");
         launch_shard_reduce(V, d_partial_all, ranks, s);
         if (!h->last_init) launch_dynamics(V, s);
-        launch_assemble(V, s);
+        launch_assemble(V, 0, s);
     }
     V.pivot = 1;        // sharded mode: every rank must take the same path without a host round trip
     launch_solve(V, h->last_init, s);

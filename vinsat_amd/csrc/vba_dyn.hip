@@ -67,6 +67,22 @@ __global__ __launch_bounds__(256) void k_dynamics(DevView V) {
 constexpr int kAsmPoses = 4;
 constexpr int kAsmIn = 21 + 6 + 36 + 6 + 3 + 27;     // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl
 
+// 1/x to ~1 ulp (same sequence as the chain solver's): v_rcp_f64 plus two Newton steps
+__device__ __forceinline__ double asm_fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+
+// FUSE (landmark-only phase, first LM trial, unpivoted path): the system is block diagonal and, inside a pose,
+// the velocity rows carry only the damping, so the step of a pose is a 6x6 solve of (H_i / w_max + lamda I) x = b_i /
+// w_max.  One thread per pose does it in registers straight from the staged inputs, retracts and writes the trial
+// state -- the separate solve and recover launches of that trial are not needed.  The pivots are checked exactly as
+// in the chain solver; a failed check hands the window to the pivoted kernels.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     __shared__ double in[(kAsmPoses + 1) * kAsmIn];
     const int w = blockIdx.y;
@@ -121,6 +137,53 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
         if (t < 243) V.bands[(sb + i) * 243 + t] = band_entry(R, t / 81, (t % 81) / 9, t % 9);
         else V.rhs[(sb + i) * 9 + (t - 243)] = rhs_entry(R, t - 243);
     }
+    if (FUSE) {
+        WinScalars& sc = V.sc[w];
+        const double lam32 = (double)(float)sc.lamda;      // torch.eye() is float32 (BA_filtering.py:54)
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc.lam32 = lam32;
+        bool badpiv = false, badnum = false;
+        if ((int)threadIdx.x < cnt) {
+            const int i = i0 + threadIdx.x;
+            const double* me = in + (threadIdx.x + 1) * kAsmIn;
+            double A[6][7], d0[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int b = 0; b < 6; ++b) A[a][b] = me[sym6(a, b)] * inv_wmax + (a == b ? lam32 : 0.0);
+                A[a][6] = me[21 + a] * inv_wmax;
+                d0[a] = A[a][a];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (!(A[k][k] > 1e-10 * d0[k])) badpiv = true;
+                const double inv = asm_fast_rcp(A[k][k]);
+#pragma unroll
+                for (int c = 0; c < 7; ++c) A[k][c] *= inv;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    if (r != k) {
+                        const double f = A[r][k];
+#pragma unroll
+                        for (int c = 0; c < 7; ++c) A[r][c] -= f * A[k][c];
+                    }
+                }
+            }
+            double d9[9], o[10];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                d9[r] = r < 6 ? A[r][6] : 0.0;
+                badnum |= !(fabs(d9[r]) <= 1.79e308);
+                V.dpose[(sb + i) * 9 + r] = d9[r];
+            }
+            retract(V.states + (sb + i) * 10, d9, o);
+#pragma unroll
+            for (int r = 0; r < 10; ++r) V.states_new[(sb + i) * 10 + r] = o[r];
+        }
+        if (threadIdx.x < 64) {
+            const unsigned long long bp = __ballot(badpiv), bn = __ballot(badnum);
+            if (threadIdx.x == 0 && (bp || bn)) atomicOr(&sc.flags, (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
+        }
+    }
 }
 
 void launch_dynamics(const DevView& V, hipStream_t s) {
@@ -128,8 +191,10 @@ void launch_dynamics(const DevView& V, hipStream_t s) {
     hipLaunchKernelGGL(k_dynamics, dim3(nb, V.W), dim3(256), 0, s, V);
 }
 
-void launch_assemble(const DevView& V, hipStream_t s) {
-    hipLaunchKernelGGL(k_assemble, dim3((V.n_max + kAsmPoses - 1) / kAsmPoses, V.W), dim3(256), 0, s, V);
+void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s) {
+    const dim3 g((V.n_max + kAsmPoses - 1) / kAsmPoses, V.W);
+    if (fuse_init_solve) hipLaunchKernelGGL(k_assemble<true>, g, dim3(256), 0, s, V);
+    else hipLaunchKernelGGL(k_assemble<false>, g, dim3(256), 0, s, V);
 }
 
 }  // namespace vba

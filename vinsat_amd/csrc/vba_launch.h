@@ -17,7 +17,7 @@ void launch_debug_project(const DevView& V, int w, int m, double* est, double* J
 
 // vba_dyn.hip
 void launch_dynamics(const DevView& V, hipStream_t s);
-void launch_assemble(const DevView& V, hipStream_t s);
+void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s);
 
 // vba_solve.hip
 void launch_solve(const DevView& V, int initialize, hipStream_t s);

@@ -835,8 +835,10 @@ __global__ __launch_bounds__(64) void k_solve_blockdiag(DevView V, int PB) {
 // ================================================================================================== accept test
 // LM accept test (BA_filtering.py:51, 66-79).  ranks == 0: sum this window's block partials; ranks > 0: the
 // observation part is the rank-ordered sum of the gathered per-rank sums (sharded mode).
-__global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_all, int ranks) {
-    __shared__ double red[4];
+constexpr int kDecideThreads = 1024;
+
+__global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const double* trial_all, int ranks) {
+    __shared__ double red[kDecideThreads / 64];
     __shared__ double bc[2];
     const int w = blockIdx.x;
     VBA_SKIP_CALL(V, w);
@@ -865,18 +867,18 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
         if (V.m_total == 0) {
             double s = 0.0;
             const double* pi = V.part_init + (size_t)w * V.nblk_obs;
-            for (int b = t; b < V.nblk_obs; b += 256) s += pi[b];
-            so = block_sum<256>(s, red);
+            for (int b = t; b < V.nblk_obs; b += kDecideThreads) s += pi[b];
+            so = block_sum<kDecideThreads>(s, red);
         } else {
             so = sc.sum_abs_robs;
         }
         double sp = 0.0;
         if (!prm.initialize) {
-            for (int i = t; i < n - 1; i += 256) {
+            for (int i = t; i < n - 1; i += kDecideThreads) {
                 const double* ro = V.rorb + (sb + i) * 6;
                 sp += fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]) + fabs(V.fatt[sb + i]);
             }
-            sp = block_sum<256>(sp, red) * prm.sqrt_sigma;
+            sp = block_sum<kDecideThreads>(sp, red) * prm.sqrt_sigma;
         }
         if (t == 0) {
             init_residual = (so + sp) / denom;
@@ -895,8 +897,8 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
     } else {
         const double* pt = V.part_trial + (size_t)w * (V.nblk_obs + V.nblk_dyn);
         double s = 0.0;
-        for (int b = t; b < V.nblk_obs + V.nblk_dyn; b += 256) s += pt[b];
-        s = block_sum<256>(s, red);
+        for (int b = t; b < V.nblk_obs + V.nblk_dyn; b += kDecideThreads) s += pt[b];
+        s = block_sum<kDecideThreads>(s, red);
         if (t == 0) bc[1] = s;
         __syncthreads();
         S = bc[1];
@@ -909,7 +911,7 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
         const double* s_new = V.states_new + sb * 10;
         double* s_cur = V.states + sb * 10;
         double* s_prev = V.states_prev + sb * 10;
-        for (int k = t; k < n * 10; k += 256) { s_prev[k] = s_cur[k]; s_cur[k] = s_new[k]; }
+        for (int k = t; k < n * 10; k += kDecideThreads) { s_prev[k] = s_cur[k]; s_cur[k] = s_new[k]; }
         const double* D = V.bands + (sb + n - 1) * 243 + 81;
         if (t < 81) sc.last_hessian[t] = D[t] + ((t / 9 == t % 9) ? lam32 : 0.0);
     }
@@ -981,7 +983,7 @@ void launch_solve(const DevView& V, int initialize, hipStream_t s) {
 }
 
 void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(V.W), dim3(256), 0, s, V, trial_all, ranks);
+    hipLaunchKernelGGL(k_decide, dim3(V.W), dim3(kDecideThreads), 0, s, V, trial_all, ranks);
 }
 
 }  // namespace vba
