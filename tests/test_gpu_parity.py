@@ -592,7 +592,7 @@ def test_packed_sequential_solve_three_windows_per_wave(pivot):
             e.close()
         return outs
 
-    packed = run(0, 5)          # 5 windows, chunk 0 -> packed kernel
+    packed = run(-3, 5)         # 5 windows, sequential with packing forced -> k_solve_packed
     single = run(-2, 1)         # one window per handle, one window per wavefront
     for a, b in zip(packed, single):
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[3] == b[3]

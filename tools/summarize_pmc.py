@@ -15,7 +15,8 @@ def main():
     tag, windows = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1
     root = os.path.join("gpurun_out", tag)
     out = {}
-    ks = glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    newest = lambda files: sorted(files, key=os.path.getmtime)[-1:]     # gpurun_out accumulates older runs
+    ks = newest(glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True))
     stats = {}
     if ks:
         rows = list(csv.DictReader(open(ks[0])))
@@ -26,7 +27,7 @@ def main():
             stats[short(r["Name"])] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, pct=float(r["Percentage"]))
     pmc = {}
     for what in ("fetch", "write"):
-        files = glob.glob(os.path.join(root, what, "**", "*counter_collection.csv"), recursive=True)
+        files = newest(glob.glob(os.path.join(root, what, "**", "*counter_collection.csv"), recursive=True))
         acc = defaultdict(list)
         for fn in files:
             for r in csv.DictReader(open(fn)):

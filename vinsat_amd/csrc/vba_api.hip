@@ -62,6 +62,7 @@ struct vba_context {
     float last_ms = 0.f;
     bool stepped = false;
     int last_iter = 0, last_init = 0;
+    int pack_min = 2048;                    // windows from which three chains share a wavefront (below, one wave per window fills the SIMDs)
     int no_pack = 0;                        // diagnostic: force one window per wavefront in the sequential driver
     int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
@@ -281,7 +282,13 @@ int vba_set_solver(vba_handle h, int chunk) {
         h->no_pack = 1;
         return VBA_OK;
     }
-    if (chunk < 0 || chunk == 1 || chunk > 60) return fail(VBA_EINVAL, "chunk must be -2, -1, 0 or in [2, 60]");
+    if (chunk == -3) {      // sequential, three windows per wavefront whenever the pose counts allow it
+        h->V.chunk = 0;
+        h->no_pack = 0;
+        h->pack_min = 3;
+        return VBA_OK;
+    }
+    if (chunk < 0 || chunk == 1 || chunk > 60) return fail(VBA_EINVAL, "chunk must be -3, -2, -1, 0 or in [2, 60]");
     h->V.chunk = chunk;
     h->no_pack = 0;
     return VBA_OK;
@@ -489,7 +496,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
     int rc_out = VBA_OK;
     V.pivot = h->pivot_mode;
     V.pack = 0;
-    if (V.chunk <= 0 && h->W >= 3 && !h->no_pack) {
+    if (V.chunk <= 0 && h->W >= h->pack_min && !h->no_pack) {
         V.pack = 1;
         for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
     }
@@ -546,7 +553,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     DevView V = h->V;
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
     V.pack = 0;
-    if (V.chunk <= 0 && h->W >= 3 && !h->no_pack) {
+    if (V.chunk <= 0 && h->W >= h->pack_min && !h->no_pack) {
         V.pack = 1;
         for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
     }
