@@ -106,14 +106,24 @@ def cpu_baseline(win, st0, budget_s):
 
 def main():
     args = parse()
+    # Libraries (RCCL prints a version banner at init) must not add lines to stdout: everything written to fd 1
+    # during the run goes to stderr, the ONE JSON line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    # VBA_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, collectives, sharded window) even with a
+    # single rank -- the only way to rehearse it on a one-GPU box
+    force_dist = os.environ.get("VBA_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from vinsat_amd import od_pipe, synth
     from vinsat_amd.engine import BAEngine
@@ -226,7 +236,7 @@ def main():
 
     # ---- observation-sharded mode (N > 1): ONE window whose rows are split over the ranks
     sharded = None
-    if world > 1 and not args.no_sharded:
+    if (world > 1 or force_dist) and not args.no_sharded:
       try:
         from vinsat_amd.dist import ShardedBA
         cfg_s = synth.WindowConfig("sharded", cfg.n_poses, cfg.obs_per_pose * world, cfg.stride)
@@ -297,7 +307,7 @@ def main():
             "batched": batched,
             "sharded": sharded,
         }
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
