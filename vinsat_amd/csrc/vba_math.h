@@ -124,14 +124,28 @@ VBA_HD double robust_weight_raw(const RobustParams& rp, double ru, double rv) {
 
 // ------------------------------------------------------------------------------------------------ orbit
 // J2 two-body acceleration (BA_utils.py:883-899) and its directional derivative along tp.
+// On the device 1/r comes from v_rsq_f64 refined by two Newton steps (~1 ulp) and the powers of 1/r by
+// multiplication: the IEEE sqrt + three divisions of the plain formula are ~100 instructions on the critical path
+// of every stage of every RK4 step (a 1000 s gap is 4000 dependent evaluations).
 VBA_HD void accel_jvp(const double* p, const double* tp, double* a, double* da, bool with_tangent) {
     const double px2 = p[0] * p[0], py2 = p[1] * p[1], pz2 = p[2] * p[2];
     const double r2 = px2 + py2 + pz2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double ir = __builtin_amdgcn_rsq(r2);
+    ir = ir * fma(-0.5 * r2 * ir, ir, 1.5);
+    ir = ir * fma(-0.5 * r2 * ir, ir, 1.5);
+    const double ir2 = ir * ir;
+    const double ir3 = ir2 * ir;
+    const double k3 = kMu * ir3;
+    const double k7 = kJ2c * (ir3 * ir3 * ir);
+#else
     const double r = sqrt(r2);
     const double r3 = r * r * r;
     const double r7 = r3 * r3 * r;
     const double k3 = kMu / r3;
     const double k7 = kJ2c / r7;
+    const double ir2 = 1.0 / r2;
+#endif
     const double u0 = 6.0 * px2 - 1.5 * py2 - 1.5 * pz2;
     const double u2 = 3.0 * px2 - 4.5 * py2 - 4.5 * pz2;
     a[0] = -k3 * p[0] + k7 * u0 * p[0];
@@ -139,7 +153,6 @@ VBA_HD void accel_jvp(const double* p, const double* tp, double* a, double* da, 
     a[2] = -k3 * p[2] + k7 * u2 * p[2];
     if (!with_tangent) return;
     const double pt = p[0] * tp[0] + p[1] * tp[1] + p[2] * tp[2];
-    const double ir2 = 1.0 / r2;
     const double du0 = 2.0 * (6.0 * p[0] * tp[0] - 1.5 * p[1] * tp[1] - 1.5 * p[2] * tp[2]);
     const double du2 = 2.0 * (3.0 * p[0] * tp[0] - 4.5 * p[1] * tp[1] - 4.5 * p[2] * tp[2]);
     const double c3 = 3.0 * k3 * ir2 * pt;      // 3 mu (p.t)/r^5
