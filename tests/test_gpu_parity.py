@@ -366,6 +366,8 @@ def test_sharded_stage_kernels_on_one_gpu(c2, ranks):
     m = inp["xyz"].shape[0] - 3
     xyz, uv, conf, ii = inp["xyz"][:m], inp["uv"][:m], inp["conf"][:m].copy(), inp["ii"][:m]
     conf[::7] = 2.5
+    if ranks == 3:
+        conf[ii % 5 == 0] = -0.4       # indefinite blocks: the unpivoted path must fall back on every emulated rank alike
     b = shard_bounds(m, ranks)
     m_pad = -(-m // ranks)
     engs = []
@@ -408,13 +410,15 @@ def test_sharded_stage_kernels_on_one_gpu(c2, ranks):
             assert trials < 12
         ref, lam_ref, hess_ref, ntr_ref, flags_ref = single.iterate(it, init, lam_ref, ref)
         outs = [e.get_states() for e in engs]
-        assert trials == ntr_ref == outs[0][3]
+        assert ntr_ref == outs[0][3] and trials >= ntr_ref      # a fallback round repeats a trial without counting it
         saw_multi |= trials > 1
         for o in outs:
             assert np.array_equal(o[0], outs[0][0]) and o[1] == outs[0][1]
         assert outs[0][1] == lam_ref
         assert rel_err(outs[0][0], ref) < 1e-9
         assert rel_err(outs[0][2], hess_ref) < 1e-7     # different accumulation tree (handle geometry differs)
+    if ranks == 3:
+        assert all(e.eng.solver_fallbacks() > 0 for e in engs)
     for e in engs:
         e.close()
     single.close()

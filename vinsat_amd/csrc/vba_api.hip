@@ -62,6 +62,7 @@ struct vba_context {
     float last_ms = 0.f;
     bool stepped = false;
     int last_iter = 0, last_init = 0;
+    int sh_pivot = 0;                       // sharded mode: solver variant of the current call (0 unpivoted, 2 mixed after a failed check)
     int pack_min = 2048;                    // windows from which three chains share a wavefront (below, one wave per window fills the SIMDs)
     int no_pack = 0;                        // diagnostic: force one window per wavefront in the sequential driver
     int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
@@ -791,7 +792,10 @@ int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* 
         if (!h->last_init) launch_dynamics(V, s);
         launch_assemble(V, 0, s);
     }
-    V.pivot = 1;        // sharded mode: every rank must take the same path without a host round trip
+    // every rank holds bit-identical systems (rank-ordered reductions), so the checked unpivoted path and its
+    // fallback are taken by all ranks alike: stage4 reports the failed check and the caller's loop repeats stage3
+    if (d_partial_all) h->sh_pivot = h->pivot_mode;
+    V.pivot = h->sh_pivot;
     launch_solve(V, h->last_init, s);
     launch_trial(V, s);
     launch_shard_trial_sum(V, d_trial_local, s);
@@ -807,6 +811,10 @@ int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done)
     HIPCHK(hipGetLastError());
     if (int rc = read_heads(h)) return rc;
     *done = head(h, 0)->done;
+    if (!*done && (head(h, 0)->flags & 8u) && h->sh_pivot == 0) {   // pivot check failed: next stage3 uses the pivoted kernels
+        h->sh_pivot = 2;
+        h->fallbacks++;
+    }
     if (*done) { h->stepped = true; h->V.m_total = 0; }
     return VBA_OK;
 }
