@@ -861,6 +861,7 @@ __global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const doub
     const bool first = sc.n_trials == 0;
     double init_residual = sc.init_residual;
     const double lam_in = sc.lamda, lam32 = sc.lam32;
+    __syncthreads();        // every thread has read the scalars that thread 0 rewrites at the end
     if (first) {
         // init_residual = mean |[r_obs ; sqrt(Sigma) r_pred]| with UNweighted r_obs (BA_filtering.py:51)
         double so;
