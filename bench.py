@@ -201,7 +201,7 @@ def main():
 
     # ---- batched windows: W independent windows per launch
     batched = None
-    if args.windows > 0 and rank == 0:
+    if args.windows > 0 and rank == 0 and world == 1 and not force_dist:
         W = args.windows
         be = BAEngine(n, m, windows=W, device=local)
         for w in range(W):
