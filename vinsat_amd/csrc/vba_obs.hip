@@ -148,36 +148,54 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
 __global__ __launch_bounds__(256) void k_select_final(DevView V) {
     __shared__ unsigned lh[kSelBins];
     __shared__ unsigned lds_u[260];
+    __shared__ unsigned long long skeys[1024];
     const int w = blockIdx.x;
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
-    unsigned long long prefix;
-    long long rank;
-    select_resolve(hist + 2 * kSelBins, 1 << sel_width(2), sel_width(2), sc.sel_prefix[2], sc.sel_rank[2], prefix, rank, lds_u);
     unsigned cnt = sc.sel_cnt;
     const double* ck = V.ckeys + 2 * (size_t)w * V.m_max;
-    if ((int64_t)cnt > 2 * V.m_max) {       // list overflowed: fall back to the full key array
-        ck = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
-        cnt = (unsigned)(V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w]);
-    }
-#pragma unroll
-    for (int P = 3; P < 6; ++P) {
-        const int nbins = 1 << sel_width(P);
-        for (int b = threadIdx.x; b < kSelBins; b += 256) lh[b] = 0u;
+    if (cnt <= 1024u) {
+        // usual case, a handful of candidates: every key of the list matches the 21 known bits and the wanted key is
+        // the one of rank sel_rank[2] among them -- rank each key by counting (ties broken by position)
+        const long long want = sc.sel_rank[2];
+        for (unsigned q = threadIdx.x; q < cnt; q += 256) skeys[q] = f64_bits(ck[q]);
         __syncthreads();
         for (unsigned q = threadIdx.x; q < cnt; q += 256) {
-            const unsigned long long key = f64_bits(ck[q]);
-            if ((key >> sel_shift(P - 1)) == prefix) atomicAdd(&lh[(unsigned)(key >> sel_shift(P)) & (nbins - 1)], 1u);
+            const unsigned long long key = skeys[q];
+            long long below = 0;
+            for (unsigned j = 0; j < cnt; ++j) {
+                const unsigned long long o = skeys[j];
+                below += (o < key) || (o == key && j < q);
+            }
+            if (below == want) sc.c_obs = bits_f64(key);
         }
-        __syncthreads();
-        unsigned long long np;
-        long long nr;
-        select_resolve(lh, nbins, sel_width(P), prefix, rank, np, nr, lds_u);
-        prefix = np;
-        rank = nr;
+    } else {
+        if ((int64_t)cnt > 2 * V.m_max) {       // list overflowed: fall back to the full key array
+            ck = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
+            cnt = (unsigned)(V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w]);
+        }
+        unsigned long long prefix;
+        long long rank;
+        select_resolve(hist + 2 * kSelBins, 1 << sel_width(2), sel_width(2), sc.sel_prefix[2], sc.sel_rank[2], prefix, rank, lds_u);
+#pragma unroll
+        for (int P = 3; P < 6; ++P) {
+            const int nbins = 1 << sel_width(P);
+            for (int b = threadIdx.x; b < kSelBins; b += 256) lh[b] = 0u;
+            __syncthreads();
+            for (unsigned q = threadIdx.x; q < cnt; q += 256) {
+                const unsigned long long key = f64_bits(ck[q]);
+                if ((key >> sel_shift(P - 1)) == prefix) atomicAdd(&lh[(unsigned)(key >> sel_shift(P)) & (nbins - 1)], 1u);
+            }
+            __syncthreads();
+            unsigned long long np;
+            long long nr;
+            select_resolve(lh, nbins, sel_width(P), prefix, rank, np, nr, lds_u);
+            prefix = np;
+            rank = nr;
+        }
+        if (threadIdx.x == 0) sc.c_obs = bits_f64(prefix);
     }
-    if (threadIdx.x == 0) sc.c_obs = bits_f64(prefix);
     for (int b = threadIdx.x; b < 3 * kSelBins; b += 256) hist[b] = 0u;     // clean for the next step
 }
 
