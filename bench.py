@@ -199,6 +199,22 @@ def main():
                 "note": "single window = a latency-bound chain (two-level partitioned 9x9 block elimination, ~24 sequential "
                         "block steps); see 'batched' for the bandwidth regime"}
 
+    # ---- the same calls through vba_iterate: states cross PCIe both ways on every call (never the headline value)
+    host_roundtrip = None
+    if rank == 0:
+        stt, lam = st0, 1e-4
+        eng.iterate(0, True, lam, stt)
+        th = time.perf_counter()
+        nh = 100
+        for k in range(nh):
+            it, init = schedule(k)
+            if it == 0:
+                stt, lam = st0, 1e-4
+            stt, lam, _, _, _ = eng.iterate(it, init, lam, stt)
+        dth = time.perf_counter() - th
+        host_roundtrip = {"value": nh / dth, "unit": "BA iterations/s", "ms_per_call": 1e3 * dth / nh,
+                          "note": "vba_iterate: 40 kB of states host->device and back, one host synchronisation per call"}
+
     # ---- batched windows: W independent windows per launch
     batched = None
     if args.windows > 0 and rank == 0 and world == 1 and not force_dist:
@@ -302,6 +318,7 @@ def main():
             "phase_ms": {k: float(np.mean(v)) if v else None for k, v in phase.items()},
             "kernels_ms": kernels_ms,
             "roofline": roofline,
+            "host_roundtrip": host_roundtrip,
             "accuracy": accuracy,
             "cpu_baseline": cpu,
             "batched": batched,
