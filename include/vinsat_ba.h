@@ -153,7 +153,9 @@ int vba_last_step_ms(vba_handle h, float* ms);
 
 /* Same work as vba_step, with every kernel class bracketed by HIP events on the handle's stream (first LM
  * trial only).  ms[VBA_NKERNELS] receives the durations in the order of the VBA_K_* enum; a class that did
- * not run (dynamics in the landmark-only phase) reports 0. */
+ * not run (dynamics in the landmark-only phase) reports 0.  VBA_K_BEGIN has no kernel any more: it is the
+ * interval between two back-to-back event records, i.e. the measurement overhead contained in every class.
+ * In the landmark-only phase the first trial's solve rides in the assemble class (k_assemble<true>). */
 enum { VBA_K_BEGIN = 0, VBA_K_RESIDUAL, VBA_K_SELECT, VBA_K_ACCUMULATE, VBA_K_DYNAMICS, VBA_K_ASSEMBLE, VBA_K_SOLVE,
        VBA_K_TRIAL, VBA_K_DECIDE, VBA_NKERNELS };
 int vba_step_profiled(vba_handle h, int iter, int initialize, float* ms);

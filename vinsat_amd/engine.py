@@ -126,6 +126,7 @@ class BAEngine:
                                         _p(hess), byref(nt), byref(fl)), self.lib)
         return out, lam.value, hess, nt.value, fl.value
 
+    # "begin" = two back-to-back event records (the overhead every class contains), no kernel
     KERNELS = ("begin", "residual", "select", "accumulate", "dynamics", "assemble", "solve", "trial", "decide")
 
     def step_profiled(self, it, initialize):
