@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--windows", type=int, default=1024, help="windows per launch of the batched series (0 = skip)")
+    ap.add_argument("--windows", type=int, default=4096, help="windows per launch of the batched series (0 = skip)")
     ap.add_argument("--batched-steps", type=int, default=40)
     ap.add_argument("--profile-tag", default="r01", help="profiles/<tag>_w1_traffic.json supplies roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
