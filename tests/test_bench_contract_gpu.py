@@ -1,0 +1,36 @@
+"""bench.py contract on the GPU box: exactly one JSON line on stdout with the keys the driver reads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "20",
+                          "--windows", "8", "--batched-steps", "20", "--cpu-seconds", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 20 and d["higher_is_better"] is True
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["scaling"] == "weak"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 100 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["accuracy"]["max_rel_pos_err_vs_ref"] < 1e-6
+    assert d["batched"]["windows"] == 8 and d["batched"]["value"] > d["value"]
