@@ -703,3 +703,15 @@ def test_randomised_windows_vs_oracle(seed):
     eng.run_schedule([c[0] for c in sched], [c[1] for c in sched])
     assert np.array_equal(eng.get_states()[0], st)
     eng.close()
+
+
+def test_driver_with_chained_window_calls_matches_call_by_call():
+    """streaming_version's default path issues the 20 calls of a batch as one chained device call (BA_window); the
+    errors must equal the call-by-call path (forced by passing a record list) bit for bit."""
+    from vinsat_amd import od_pipe, synth
+    det, orb = synth.make_two_pass_sequence()
+    rec = []
+    e1, f1, t1 = od_pipe.streaming_version(detections=det, orbit_np=orb, record=rec)      # call by call
+    e2, f2, t2 = od_pipe.streaming_version(detections=det, orbit_np=orb)                  # chained
+    assert np.array_equal(e1.numpy(), e2.numpy()) and f1 == f2
+    assert all(np.array_equal(a, b) for a, b in zip(t1, t2))

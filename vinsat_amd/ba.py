@@ -86,3 +86,32 @@ def BA(iter, states, velocities, imu_meas, landmarks, landmarks_xyz, ii, time_id
 
 
 BA.last = {}
+
+
+def BA_window(iters, initializes, states, velocities, imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences,
+              lamda_init, device=0):
+    """The driver's loop ``for iter in range(num_iters): states, ... = BA(iter, states, ...)`` (reference
+    ``od_pipe.py:1036-1040``) as ONE call: the states stay on the device between the calls and the calls are chained
+    there (``vba_run_schedule``).  Bit-identical to calling :func:`BA` ``len(iters)`` times.
+
+    Returns ``(states_new, velocities, lamda, last_hessian)`` of the last call, shaped like ``BA``'s.
+    """
+    import torch
+    st = _np(states)
+    if st.ndim != 3 or st.shape[0] != 1 or st.shape[2] != 10:
+        raise ValueError("states must be [1, n, 10]")
+    n = st.shape[1]
+    cum = np.ascontiguousarray(_np(imu_meas)[0, :, -1, 6:10])
+    uv = _np(landmarks).reshape(-1, 2)
+    xyz = _np(landmarks_xyz).reshape(-1, 3)
+    K = _np(intrinsics).reshape(-1, 4)
+    conf = _np(confidences).reshape(-1)
+    ii = np.ascontiguousarray(np.asarray(ii), dtype=np.int64).reshape(-1)
+    t = np.ascontiguousarray(np.asarray(time_idx), dtype=np.int64).reshape(-1)
+    eng = _engine_for(xyz, uv, conf, ii, K, cum, t, device)
+    eng.set_states(st[0], float(lamda_init))
+    eng.run_schedule(list(iters), list(initializes))
+    out, lam, hess, n_trials, flags = eng.get_states()
+    if flags & 1:
+        print("lamda too large")
+    return (torch.from_numpy(out)[None], velocities, lam, torch.from_numpy(hess)[None])

@@ -193,12 +193,16 @@ def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, dete
     """Drop-in for the reference's ``streaming_version`` (od_pipe.py:911-1062).
 
     ``ba`` defaults to the HIP-backed :func:`vinsat_amd.ba.BA`; tests may inject another
-    callable with the reference signature.
+    callable with the reference signature.  With the default ``ba`` and no ``record`` list the ``num_iters`` calls
+    of a batch are issued as one chained device call (:func:`vinsat_amd.ba.BA_window`, same bits).
     """
     import torch
     from .synth import rk4_step
+    ba_window = None
     if ba is None:
         from .ba import BA as ba
+        if record is None:
+            from .ba import BA_window as ba_window
     if detections is None:
         detections = np.load(detections_file_name, allow_pickle=True)
     if orbit_np is None:
@@ -244,7 +248,11 @@ def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, dete
             times.append(time_idx[t - prop.shape[1]:t][:-1])
             errors.append(err_prop)
         lam = 1e-4
-        for it in range(num_iters):
+        if ba_window is not None:
+            inits = [(it < 10) if patch == 0 else False for it in range(num_iters)]
+            states_t, vel_t, lam, last_h = ba_window(range(num_iters), inits, states_t, vel_t, imu[:, :t], uv[:, :i], xyz[:, :i],
+                                                     ii[:i], time_idx[:t], intr[:, :t], conf[:i], lam)
+        for it in range(num_iters if ba_window is None else 0):
             init = (it < 10) if patch == 0 else False
             states_t, vel_t, lam, last_h = ba(it, states_t, vel_t, imu[:, :t], uv[:, :i], xyz[:, :i], ii[:i],
                                               time_idx[:t], intr[:, :t], conf[:i], 1e-3, 1e-3, lam,
