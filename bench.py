@@ -37,6 +37,8 @@ HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 
 
 # Algorithmic bytes per unit, per kernel class (SURVEY.md section 8d itemisation):
 #   per observation: inputs 56 B (xyz 24 + uv 16 + conf 8 + ii 8), |r| 16 B, weight 8 B
+#   "residual" runs only on a call whose states were replaced by the host; otherwise the previous call's trial
+#   kernel has left the keys behind (trial = 56 in + 8 weight + 16 keys out)
 #   per pose: see DESIGN.md table (bands 1944, rhs 72, X/z 1440 written+read, ...)
 ALG_BYTES = {
     "residual": lambda n, m: 72 * m,
@@ -45,7 +47,7 @@ ALG_BYTES = {
     "dynamics": lambda n, m: (80 + 32 + 8 + 288 + 48 + 48 + 8 + 24 + 216) * n,
     "assemble": lambda n, m: (216 + 2 * 288 + 96 + 24 + 216 + 1944 + 72) * n,
     "solve": lambda n, m: (1944 + 72 + 2 * 1440 + 144 + 160) * n,
-    "trial": lambda n, m: 64 * m + (80 + 32 + 8) * n,
+    "trial": lambda n, m: 80 * m + (80 + 32 + 8) * n,
     "decide": lambda n, m: 160 * n,
     "begin": lambda n, m: 160 * n,
 }
@@ -241,12 +243,15 @@ def main():
         per_kernel = {k: {"ms": bms[k], "GBps": (ALG_BYTES[k](n, m) * W / (bms[k] * 1e-3) / 1e9) if bms[k] > 0 else 0.0}
                       for k in bms}
         bdom = max(bms, key=lambda k: bms[k] * len(bk[k]))
-        step_bytes = sum(ALG_BYTES[k](n, m) for k in ALG_BYTES) * W
+        # bytes and time of the average call of the 20-call schedule (a class counts for the calls it ran in)
+        step_bytes = sum(ALG_BYTES[k](n, m) * len(bk[k]) / 20.0 for k in ALG_BYTES) * W
+        step_ms = sum(bms[k] * len(bk[k]) / 20.0 for k in bms)
         batched = {"windows": W, "value": W * args.batched_steps / dtb, "unit": "BA iterations/s", "steps": args.batched_steps,
                    "ms_per_step": 1e3 * dtb / args.batched_steps, "dominant_kernel": "k_" + bdom,
                    "roofline": {"kernel": "k_" + bdom, "bound": "hbm", "achieved": per_kernel[bdom]["GBps"], "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": per_kernel[bdom]["GBps"] / HBM_PEAK_GBS},
-                   "whole_step_GBps": step_bytes / (1e-3 * sum(bms.values())) / 1e9,
+                   "whole_step_GBps": step_bytes / (1e-3 * step_ms) / 1e9,
+                   "whole_step_bytes_per_window": step_bytes / W,
                    "kernels": per_kernel}
         be.close()
 

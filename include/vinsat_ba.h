@@ -100,6 +100,13 @@ int vba_set_integrator(vba_handle h, int hop100);
  * reduction tree, i.e. results are bit-reproducible for equal settings. */
 int vba_set_accumulate_lanes(vba_handle h, int lanes);
 
+/* Carried keys (default on).  The trial residual of an accepted LM trial (BA_filtering.py:61-66) is evaluated at
+ * exactly the states the next BA call starts from (BA_filtering.py:12-21), so the trial kernel also leaves the |r|
+ * keys, their exponent histogram and sum |r| of the next call on the device, and a call that follows another one
+ * without vba_set_states / uploads in between starts at the median select instead of re-reading every observation.
+ * on == 0: every call recomputes them (same bits; for comparison). */
+int vba_set_key_carry(vba_handle h, int on);
+
 /* Row pivoting inside the 9x9 diagonal blocks.  always == 0 (default): the blocks are eliminated without row
  * exchanges (the damped normal equations are positive definite up to a ~1e-6 non-symmetric term) while every pivot
  * is checked against the diagonal entry it started from; a failed check repeats that solve with pivoting, so the

@@ -715,3 +715,115 @@ def test_driver_with_chained_window_calls_matches_call_by_call():
     e2, f2, t2 = od_pipe.streaming_version(detections=det, orbit_np=orb)                  # chained
     assert np.array_equal(e1.numpy(), e2.numpy()) and f1 == f2
     assert all(np.array_equal(a, b) for a, b in zip(t1, t2))
+
+
+# ------------------------------------------------------------------------------------------------ carried keys
+def _carry_engine(inp, n, m, conf, carry, windows=1):
+    from vinsat_amd.engine import BAEngine
+    e = BAEngine(n, m, windows=windows)
+    e.set_accumulate_lanes(8)
+    e.set_key_carry(carry)
+    for w in range(windows):
+        e.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n, window=w)
+        e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"], window=w)
+    return e
+
+
+@pytest.mark.parametrize("confmode", ["golden", "rejections", "pivot-fallback"])
+def test_carried_keys_give_the_bits_of_recomputed_keys(c2, confmode):
+    """An accepted trial leaves the next call's |r| keys, exponent histogram and sum |r| behind (k_trial<true>);
+    a call that starts from them must produce the bits of a call that recomputes them (k_obs_residual), call by
+    call, also through rejected trials, lamda exhaustion and the pivoted repeat."""
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    conf = {"golden": inp["conf"], "rejections": np.full_like(inp["conf"], 3.0),
+            "pivot-fallback": np.where(inp["ii"] % 3 == 0, -0.5, inp["conf"])}[confmode]
+    outs = {}
+    for carry in (False, True):
+        e = _carry_engine(inp, n, m, conf, carry)
+        e.set_states(g["states0"][0], 1e-4)
+        seq = []
+        for k in range(20):
+            e.step(k, k < 10)
+            s, lam, hess, ntr, flags = e.get_states()
+            seq.append((s.copy(), lam, hess.copy(), ntr, flags))
+        outs[carry] = seq
+        e.close()
+    for k, (a, b) in enumerate(zip(outs[False], outs[True])):
+        assert np.array_equal(a[0], b[0]), k
+        assert a[1] == b[1] and np.array_equal(a[2], b[2]) and a[3] == b[3] and a[4] == b[4], k
+    if confmode == "golden":
+        assert rel_err(outs[True][-1][0], g["states_out_19"][0]) < 1e-7
+    if confmode == "rejections":
+        assert max(o[3] for o in outs[True]) > 1
+
+
+def test_carried_keys_are_dropped_when_the_states_are_replaced(c2):
+    """vba_set_states / uploads / vba_iterate between two calls invalidate what the last trial left behind
+    (including its half-consumed histogram); the following call must equal a call on a fresh handle."""
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    fresh = _carry_engine(inp, n, m, inp["conf"], False)
+    e = _carry_engine(inp, n, m, inp["conf"], True)
+
+    def fresh_call(st, lam, it, init):
+        fresh.set_states(st, lam)
+        fresh.step(it, init)
+        return fresh.get_states()
+
+    e.set_states(g["states0"][0], 1e-4)
+    e.step(0, True)
+    e.step(1, True)                                  # carried
+    st, lam = g["states_out_9"][0], 1e-3
+    e.set_states(st, lam)                            # drops the carry, leaves a dirty histogram
+    e.step(10, False)
+    a, b = e.get_states(), fresh_call(st, lam, 10, False)
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[3] == b[3]
+    e.step(11, False)                                # carried again
+    b2 = (fresh.step(11, False), fresh.get_states())[1]
+    assert np.array_equal(e.get_states()[0], b2[0])
+    # host round-trip call in the middle (does not emit), then stepping again
+    out, lam_o, hess, ntr, flags = e.iterate(3, True, 1e-4, g["states_out_2"][0])
+    ref = fresh_call(g["states_out_2"][0], 1e-4, 3, True)
+    assert np.array_equal(out, ref[0]) and lam_o == ref[1]
+    e.step(4, True)
+    fresh.step(4, True)
+    assert np.array_equal(e.get_states()[0], fresh.get_states()[0])
+    # new observation rows: carry dropped
+    conf2 = inp["conf"] * 0.8
+    e.upload_observations(inp["xyz"], inp["uv"], conf2, inp["ii"], n)
+    fresh.upload_observations(inp["xyz"], inp["uv"], conf2, inp["ii"], n)
+    e.step(5, True)
+    fresh.step(5, True)
+    assert np.array_equal(e.get_states()[0], fresh.get_states()[0])
+    # chained schedule after single steps, and single steps after a schedule
+    e.run_schedule(list(range(6, 12)), [k < 10 for k in range(6, 12)])
+    for k in range(6, 12):
+        fresh.step(k, k < 10)
+    assert np.array_equal(e.get_states()[0], fresh.get_states()[0])
+    e.step(12, False)
+    fresh.step(12, False)
+    assert np.array_equal(e.get_states()[0], fresh.get_states()[0])
+    e.close()
+    fresh.close()
+
+
+def test_carried_keys_in_a_batch_with_stalling_windows(c2):
+    """Four windows in one handle, some needing several trials: schedule with carried keys == without."""
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    confs = [inp["conf"], np.full_like(inp["conf"], 3.0), np.where(inp["ii"] % 3 == 0, -0.5, inp["conf"]), inp["conf"] * 0.9]
+    iters, inits = list(range(20)), [k < 10 for k in range(20)]
+    res = {}
+    for carry in (False, True):
+        e = _carry_engine(inp, n, m, inp["conf"], carry, windows=4)
+        for w, conf in enumerate(confs):
+            e.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n, window=w)
+            e.set_states(g["states0"][0], 1e-4, window=w)
+        e.run_schedule(iters[:7], inits[:7])
+        e.run_schedule(iters[7:], inits[7:])          # second chain starts from carried keys
+        res[carry] = [e.get_states(window=w) for w in range(4)]
+        e.close()
+    for w in range(4):
+        a, b = res[False][w], res[True][w]
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2]), w

@@ -22,6 +22,7 @@ def main():
             e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n, window=w)
             e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx, window=w)
         acc = {k: [] for k in e.KERNELS}
+        by_phase = {True: {k: [] for k in e.KERNELS}, False: {k: [] for k in e.KERNELS}}
         for rep in range(2):
             for k in range(20):
                 it, init = schedule(k)
@@ -30,7 +31,9 @@ def main():
                 ms = e.step_profiled(it, init)
                 if rep:
                     for name, v in ms.items():
-                        if v > 0: acc[name].append(v)
+                        if v > 0:
+                            acc[name].append(v)
+                            by_phase[init][name].append(v)
         t0 = time.perf_counter()
         for k in range(20):
             it, init = schedule(k)
@@ -40,6 +43,8 @@ def main():
         dt = time.perf_counter() - t0
         out = {"W": W, "it_per_s": 20 * W / dt, "ms_per_step": 1e3 * dt / 20,
                "kernels": {k: {"ms": round(float(np.mean(v)), 4), "GBps": round(ALG_BYTES[k](n, m) * W / (np.mean(v) * 1e-3) / 1e9, 1)} for k, v in acc.items() if v}}
+        out["landmark_only_ms"] = {k: round(float(np.mean(v)), 4) for k, v in by_phase[True].items() if v}
+        out["full_ms"] = {k: round(float(np.mean(v)), 4) for k, v in by_phase[False].items() if v}
         print(json.dumps(out), flush=True)
         e.close()
 

@@ -61,6 +61,9 @@ struct vba_context {
     std::vector<std::vector<int64_t>> perm; // sorted position -> input row
     float last_ms = 0.f;
     bool stepped = false;
+    bool carry_ok = false;          // every window's keys / histogram / sum |r| for its current states are on the device (k_trial<true>)
+    bool carry_enabled = true;
+    bool hist_dirty = false;        // a k_trial<true> has left an exponent histogram behind that nobody consumed
     int last_iter = 0, last_init = 0;
     int sh_pivot = 0;                       // sharded mode: solver variant of the current call (0 unpivoted, 2 mixed after a failed check)
     int pack_min = 2048;                    // windows from which three chains share a wavefront (below, one wave per window fills the SIMDs)
@@ -156,7 +159,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     need(W * M * 4); need(W * (N + 1) * 4);
     need(W * N * 10 * 8); need(W * N * 10 * 8); need(W * N * 10 * 8);
     need(W * N * 4 * 8); need(W * N * 4 * 8); need(W * N * 4);
-    need(W * 2 * M * 8); need(W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * (nblk_obs + nblk_dyn) * 8);
+    need(W * 2 * M * 8); need(W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * (nblk_obs + nblk_dyn) * 8); need(W * nblk_obs * 8);
     need(W * kSelPasses * kSelBins * 4);
     const size_t per_pose = 21 + 6 + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
     need(W * N * per_pose * 8 + 16 * 256);
@@ -187,6 +190,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.absr = A.take<double>(W * 2 * M); V.wraw = A.take<double>(W * M); V.ckeys = A.take<double>(W * 2 * M);
     V.acc_lanes = 8;    // set after construction by vba_set_accumulate_lanes(h, 0)
     V.part_init = A.take<double>(W * nblk_obs); V.part_trial = A.take<double>(W * (nblk_obs + nblk_dyn));
+    V.part_next = A.take<double>(W * nblk_obs);
     V.hist = A.take<unsigned>(W * kSelPasses * kSelBins);
     V.Hraw = A.take<double>(W * N * 21); V.braw = A.take<double>(W * N * 6);
     V.xhat = A.take<double>(W * N * 6); V.Phi = A.take<double>(W * N * 36); V.rorb = A.take<double>(W * N * 6);
@@ -202,11 +206,11 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.csol2 = A.take<double>(W * PM * 171); V.cL2 = A.take<double>(W * PM * 171); V.cR2 = A.take<double>(W * PM * 171);
     V.rx2 = A.take<double>(W * PM * 9);
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
-    V.hop = 0; V.pivot = 0; V.call = -1;
+    V.hop = 0; V.pivot = 0; V.call = -1; V.emit = 0; V.carry = 0;
     V.chunk = 0; V.chunk2 = 0;      // set after construction by vba_set_solver(h, -1)
     {   // every device array a kernel may touch must have been carved: a null here would fault on the GPU
         const void* must[] = {V.n, V.m, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
-                              V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.absr, V.wraw, V.ckeys, V.part_init,
+                              V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.absr, V.wraw, V.ckeys, V.part_init, V.part_next,
                               V.part_trial, V.hist, V.Hraw, V.braw, V.xhat, V.Phi, V.rorb, V.fatt, V.qgrad, V.Hd, V.Hu, V.Hl,
                               V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx, V.csol2, V.cL2, V.cR2, V.rx2};
         bool ok = A.used <= A.size;
@@ -316,6 +320,13 @@ int vba_set_accumulate_lanes(vba_handle h, int lanes) {
     return VBA_OK;
 }
 
+int vba_set_key_carry(vba_handle h, int on) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    h->carry_enabled = on != 0;
+    h->carry_ok = false;
+    return VBA_OK;
+}
+
 int vba_set_pivoting(vba_handle h, int always) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     h->pivot_mode = always ? 1 : 0;
@@ -339,6 +350,7 @@ int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const do
                             const double* conf, const int64_t* ii) {
     if (int rc = check_window(h, window)) return rc;
     if (!xyz || !uv || !conf || !ii) return fail(VBA_EINVAL, "null observation array");
+    h->carry_ok = false;
     if (n < 2 || n > h->n_max) return fail(VBA_EINVAL, "n out of range (need 2 <= n <= n_max)");
     if (m < 1 || m > h->m_max) return fail(VBA_EINVAL, "m out of range (need 1 <= m <= m_max)");
     if (h->have_win[window] && h->n[window] != n) { h->have_win[window] = 0; h->have_state[window] = 0; }   // a new window: re-upload its constants
@@ -389,6 +401,7 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
                       const int64_t* time_idx) {
     if (int rc = check_window(h, window)) return rc;
     if (!intrinsics || !cumrot_last || !time_idx) return fail(VBA_EINVAL, "null pose-constant array");
+    h->carry_ok = false;
     if (n < 2 || n > h->n_max) return fail(VBA_EINVAL, "n out of range (need 2 <= n <= n_max)");
     if (h->have_obs[window] && h->n[window] != n) { h->have_obs[window] = 0; h->have_state[window] = 0; }   // a new window: re-upload its rows
     HIPCHK(hipSetDevice(h->device));
@@ -413,6 +426,7 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
 int vba_set_states(vba_handle h, int window, const double* states, double lamda) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (!states) return fail(VBA_EINVAL, "null states");
+    h->carry_ok = false;
     if (window == -1) {     // the same states for every window (all windows must have the same number of poses)
         const int n = h->n[0];
         for (int w = 0; w < h->W; ++w) {
@@ -456,13 +470,18 @@ int vba_get_states(vba_handle h, int window, double* states, double* lamda, doub
     return VBA_OK;
 }
 
-static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
+static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool emit = true) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     DevView V = h->V;
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
+    V.emit = h->carry_enabled && emit ? 1 : 0;
+    V.carry = h->carry_enabled && h->carry_ok ? 1 : 0;
+    h->carry_ok = false;
+    if (!V.carry && h->hist_dirty) launch_clear_hist0(V, s);     // the states were replaced after the last trial
+    h->hist_dirty = V.emit != 0;
     fill_params(V.prm, iter, initialize);
     hipEvent_t ev[VBA_NKERNELS + 1] = {};
     if (prof) {
@@ -480,7 +499,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
         launch_dynamics(V, h->aux_stream);
         HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
     }
-    launch_obs_residual(V, nullptr, s);
+    if (!V.carry) launch_obs_residual(V, nullptr, s);
     mark(2);
     launch_select(V, s);
     mark(3);
@@ -531,9 +550,15 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof) {
             prof[k] = 0.f;
             if (rc_out == VBA_OK) (void)hipEventElapsedTime(&prof[k], ev[k], ev[k + 1]);
         }
+        if (V.carry) prof[VBA_K_RESIDUAL] = 0.f;        // not launched: the previous trial left the keys behind
         for (int k = 0; k <= VBA_NKERNELS; ++k) (void)hipEventDestroy(ev[k]);
     }
     if (rc_out != VBA_OK) return rc_out;
+    {
+        bool all = V.emit != 0;
+        for (int w = 0; w < h->W; ++w) all = all && head(h, w)->done;
+        h->carry_ok = all;
+    }
     h->stepped = true;
     h->last_iter = iter;
     h->last_init = initialize;
@@ -558,15 +583,24 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
         V.pack = 1;
         for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
     }
+    V.emit = h->carry_enabled ? 1 : 0;
+    bool carry = h->carry_enabled && h->carry_ok;
+    h->carry_ok = false;
+    if (!carry && h->hist_dirty) launch_clear_hist0(V, s);
+    h->hist_dirty = V.emit != 0;
     launch_reset_calls(V, s);
     for (int w = 0; w < h->W; ++w) { h->h_head[w].call_idx = 0; h->h_head[w].done = 0; h->h_head[w].flags = 0; }
     long trials = 0;
     int next = 0;
+    std::vector<char> call_carry((size_t)ncalls, 0);    // whether call c starts from carried keys
     for (int guard = 0; guard <= ncalls; ++guard) {
         // speculative part: calls next .. ncalls-1, one trial each
         for (int c = next; c < ncalls; ++c) {
             V.call = c;
             V.pivot = h->pivot_mode;
+            V.carry = carry ? 1 : 0;
+            call_carry[c] = (char)V.carry;
+            carry = h->carry_enabled;       // every later call starts from a trial of this chain
             fill_params(V.prm, iters[c], inits[c]);
             const bool dyn = !inits[c];
             if (dyn) {
@@ -575,7 +609,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
                 launch_dynamics(V, h->aux_stream);
                 HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
             }
-            launch_obs_residual(V, nullptr, s);
+            if (!V.carry) launch_obs_residual(V, nullptr, s);
             launch_select(V, s);
             launch_obs_accumulate(V, s);
             if (dyn) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
@@ -594,6 +628,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
         // call `minc` is unfinished for at least one window: finish it with the ordinary LM loop
         V.call = minc;
         V.pivot = h->pivot_mode;
+        V.carry = call_carry[minc];
         fill_params(V.prm, iters[minc], inits[minc]);
         for (int trial = 0; trial < 24; ++trial) {
             bool repeat = false, all = true;
@@ -614,6 +649,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
         next = minc + 1;
     }
     if (trials_total) *trials_total = (int)trials;
+    h->carry_ok = h->carry_enabled;
     h->stepped = true;
     h->last_iter = iters[ncalls - 1];
     h->last_init = inits[ncalls - 1];
@@ -628,7 +664,8 @@ int vba_step_profiled(vba_handle h, int iter, int initialize, float* ms) {
 int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in, double* states_out,
                 double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags) {
     if (int rc = vba_set_states(h, 0, states_in, lamda_in)) return rc;
-    if (int rc = vba_step(h, iter, initialize)) return rc;
+    // the next call of this kind replaces the states again: nothing to carry over
+    if (int rc = step_impl(h, iter, initialize, nullptr, false)) return rc;
     return vba_get_states(h, 0, states_out, lamda_out, last_hessian, n_trials, flags);
 }
 
@@ -731,7 +768,16 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
             *count = (int64_t)n * 27;
             return VBA_OK;
         }
-        case VBA_DBG_BANDS: return copy(V.bands + pb * 243, (int64_t)n * 243);
+        case VBA_DBG_BANDS: {
+            if (int rc = copy(V.bands + pb * 243, (int64_t)n * 243)) return rc;
+            if (h->last_init) {     // landmark-only phase: the off-diagonal blocks are zero and are not written
+                for (int i = 0; i < n; ++i) {
+                    std::memset(out + (size_t)i * 243, 0, 81 * 8);
+                    std::memset(out + (size_t)i * 243 + 162, 0, 81 * 8);
+                }
+            }
+            return VBA_OK;
+        }
         case VBA_DBG_RHS: return copy(V.rhs + pb * 9, (int64_t)n * 9);
         case VBA_DBG_DPOSE: return copy(V.dpose + pb * 9, (int64_t)n * 9);
         case VBA_DBG_SCALARS: {
@@ -758,6 +804,8 @@ int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, doubl
     hipStream_t s = h->stream;
     fill_params(h->V.prm, iter, initialize);
     h->V.m_total = m_total;
+    h->carry_ok = false;
+    if (h->hist_dirty) { launch_clear_hist0(h->V, s); h->hist_dirty = false; }
     launch_obs_residual(h->V, d_abs_local, s);
     HIPCHK(hipGetLastError());
     h->last_iter = iter;

@@ -38,6 +38,7 @@ struct WinScalars {
     double trial_residual;
     double sum_abs_robs;            // sum |r_obs| at the input states (sharded mode: local part)
     double sum_abs_rpred;           // sqrt(sigma) * sum |r_pred|
+    double next_sum_abs_robs;       // sum |r_obs| at the states the last accepted trial committed (carried keys)
     int done;
     int n_trials;
     unsigned flags;
@@ -89,6 +90,11 @@ struct DevView {
     int acc_lanes;                  // lanes per pose in k_obs_accumulate (4..64)
     double* part_init;              // [W][nblk_obs] block sums of |r_obs|
     double* part_trial;             // [W][nblk_obs + nblk_dyn]
+    double* part_next;              // [W][nblk_obs] block sums of |r_obs| at the trial states (carried keys)
+    // Carried keys: the trial residual of an accepted trial is evaluated at exactly the states the next call starts
+    // from, so k_trial<true> (emit) also leaves that call's |r| keys, their exponent histogram and sum |r| behind and
+    // the next call (carry) starts at the select without re-reading the observations.
+    int emit, carry;
     unsigned* hist;                 // [W][kSelPasses][kSelBins]
     double* Hraw;                   // [21]
     double* braw;                   // [6]

@@ -61,10 +61,10 @@ __global__ __launch_bounds__(256) void k_dynamics(DevView V) {
 }
 
 // Block-tridiagonal assembly (BA_filtering.py:40-48): 3 x 81 band entries + 9 right-hand-side entries per pose.
-// A block of 256 threads takes kAsmPoses consecutive poses: the per-pose inputs (141 doubles each, plus the
+// A block of 256 threads takes kAsmPoses consecutive poses (4 for a few windows: more blocks, shorter; 16 when
+// batched windows fill the chip anyway: the decode of an entry and the halo slot are amortised over more poses): the per-pose inputs (141 doubles each, plus the
 // transition matrix of the pose in front) are staged once in LDS with coalesced loads, then every thread forms
 // entries from LDS and the block writes its 252 * kAsmPoses outputs contiguously.
-constexpr int kAsmPoses = 4;
 constexpr int kAsmIn = 21 + 6 + 36 + 6 + 3 + 27;     // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl
 
 // 1/x to ~1 ulp (same sequence as the chain solver's): v_rcp_f64 plus two Newton steps
@@ -82,7 +82,7 @@ __device__ __forceinline__ double asm_fast_rcp(double x) {
 // w_max.  One thread per pose does it in registers straight from the staged inputs, retracts and writes the trial
 // state -- the separate solve and recover launches of that trial are not needed.  The pivots are checked exactly as
 // in the chain solver; a failed check hands the window to the pivoted kernels.
-template <bool FUSE>
+template <bool FUSE, int kAsmPoses>
 __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     __shared__ double in[(kAsmPoses + 1) * kAsmIn];
     const int w = blockIdx.y;
@@ -116,26 +116,36 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     __syncthreads();
     const double inv_wmax = 1.0 / bits_f64(V.sc[w].wmax_bits);
     const int cnt = min(kAsmPoses, n - i0);
-    for (int e = threadIdx.x; e < cnt * 252; e += 256) {
-        const int p = e / 252, t = e % 252;
-        const int i = i0 + p;
-        const double* me = in + (p + 1) * kAsmIn;
-        const double* pv = in + p * kAsmIn;
-        AsmRow R;
-        R.Hraw = me;
-        R.braw = me + 21;
-        R.inv_wmax = inv_wmax;
-        R.sigma = dyn ? prm.sigma : 0.0;
-        R.Phi_i = (dyn && i < n - 1) ? me + 27 : nullptr;
-        R.Phi_im1 = (dyn && i > 0) ? pv + 27 : nullptr;
-        R.rorb_i = (dyn && i < n - 1) ? me + 63 : nullptr;
-        R.rorb_im1 = (dyn && i > 0) ? pv + 63 : nullptr;
-        R.qgrad = me + 69;
-        R.Hd = me + 72;
-        R.Hu = me + 81;
-        R.Hl = me + 90;
-        if (t < 243) V.bands[(sb + i) * 243 + t] = band_entry(R, t / 81, (t % 81) / 9, t % 9);
-        else V.rhs[(sb + i) * 9 + (t - 243)] = rhs_entry(R, t - 243);
+    // thread t forms entry t of every pose of the block: which band / row / column it is (and with that every index
+    // into the staged inputs) is decoded once, and for a fixed pose the 252 threads write consecutive addresses
+    if (threadIdx.x < 252) {
+        const int t = threadIdx.x;
+        const bool is_rhs = t >= 243;
+        const int which = t / 81, a = is_rhs ? t - 243 : (t % 81) / 9, b = t % 9;
+#pragma unroll
+        for (int p = 0; p < kAsmPoses; ++p) {
+            if (p >= cnt) continue;
+            const int i = i0 + p;
+            const double* me = in + (p + 1) * kAsmIn;
+            const double* pv = in + p * kAsmIn;
+            AsmRow R;
+            R.Hraw = me;
+            R.braw = me + 21;
+            R.inv_wmax = inv_wmax;
+            R.sigma = dyn ? prm.sigma : 0.0;
+            R.Phi_i = (dyn && i < n - 1) ? me + 27 : nullptr;
+            R.Phi_im1 = (dyn && i > 0) ? pv + 27 : nullptr;
+            R.rorb_i = (dyn && i < n - 1) ? me + 63 : nullptr;
+            R.rorb_im1 = (dyn && i > 0) ? pv + 63 : nullptr;
+            R.qgrad = me + 69;
+            R.Hd = me + 72;
+            R.Hu = me + 81;
+            R.Hl = me + 90;
+            // landmark-only phase: the off-diagonal blocks are zero and nobody reads them (k_solve_blockdiag takes
+            // the diagonal block only; vba_debug_fetch reports them as zeros)
+            if (is_rhs) V.rhs[(sb + i) * 9 + a] = rhs_entry(R, a);
+            else if (dyn || which == 1) V.bands[(sb + i) * 243 + t] = band_entry(R, which, a, b);
+        }
     }
     if (FUSE) {
         WinScalars& sc = V.sc[w];
@@ -192,9 +202,19 @@ void launch_dynamics(const DevView& V, hipStream_t s) {
 }
 
 void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s) {
-    const dim3 g((V.n_max + kAsmPoses - 1) / kAsmPoses, V.W);
-    if (fuse_init_solve) hipLaunchKernelGGL(k_assemble<true>, g, dim3(256), 0, s, V);
-    else hipLaunchKernelGGL(k_assemble<false>, g, dim3(256), 0, s, V);
+#ifndef VBA_ASM_BATCHED
+#define VBA_ASM_BATCHED 16
+#endif
+    if (V.W >= 16) {
+        constexpr int P = VBA_ASM_BATCHED;
+        const dim3 g((V.n_max + P - 1) / P, V.W);
+        if (fuse_init_solve) hipLaunchKernelGGL((k_assemble<true, P>), g, dim3(256), 0, s, V);
+        else hipLaunchKernelGGL((k_assemble<false, P>), g, dim3(256), 0, s, V);
+    } else {
+        const dim3 g((V.n_max + 3) / 4, V.W);
+        if (fuse_init_solve) hipLaunchKernelGGL((k_assemble<true, 4>), g, dim3(256), 0, s, V);
+        else hipLaunchKernelGGL((k_assemble<false, 4>), g, dim3(256), 0, s, V);
+    }
 }
 
 }  // namespace vba

@@ -11,6 +11,7 @@ void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s);
 void launch_select(const DevView& V, hipStream_t s);
 void launch_obs_accumulate(const DevView& V, hipStream_t s);
 void launch_trial(const DevView& V, hipStream_t s);
+void launch_clear_hist0(const DevView& V, hipStream_t s);
 void launch_reset_calls(const DevView& V, hipStream_t s);
 void launch_broadcast_states(const DevView& V, int n, double lamda, hipStream_t s);
 void launch_debug_project(const DevView& V, int w, int m, double* est, double* J, double* wt, hipStream_t s);

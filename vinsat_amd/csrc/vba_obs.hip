@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     VBA_SKIP_CALL(V, w);
     const double* keys = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
     const int64_t count = V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w];
+    // carried keys: k_obs_residual did not run, this is the first kernel of the call and owns the scalar reset
+    if (P == 1 && V.carry && blockIdx.x == 0 && threadIdx.x == 0) reset_step_scalars(V.sc[w]);
     if ((int64_t)blockIdx.x * 256 * ITEMS >= count) return;
     unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
     constexpr int nbins = 1 << sel_width(P);
@@ -204,6 +206,11 @@ __global__ __launch_bounds__(256) void k_select_final(DevView V) {
 // keeps the 21 + 6 unique entries of sum(w J^T J), sum(w J^T r) in registers; a log2(G)-step xor butterfly
 // then gives the lanes of the group the totals.  The shape of the reduction is fixed, so results are bit
 // reproducible (no float atomics).  The raw (un-normalised) weight is stored per observation for the trials.
+#ifndef VBA_ACC_DEPTH
+#define VBA_ACC_DEPTH 2
+#endif
+constexpr int kAccDepth = VBA_ACC_DEPTH;
+
 template <int G>
 __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     __shared__ double wmx[4];
@@ -237,7 +244,9 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
         pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
         const int* ptr = V.pose_ptr + (size_t)w * (V.n_max + 1);
         const int beg = ptr[i], end = ptr[i + 1];
-        // software pipelined: the loads of observation k + G are in flight while k is processed
+        // software pipelined: the loads of observations k + G .. k + kAccDepth G are in flight while k is processed
+        // (the kernel sits at 2 waves per SIMD because of its accumulators either way; the registers between that
+        // and the next occupancy step are spent on memory-level parallelism)
         struct Obs { double x, y, z, u, v, c; };
         auto load = [&](int k) {
             Obs o;
@@ -246,12 +255,18 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             return o;
         };
         int k = beg + sub;
-        Obs cur = {0, 0, 0, 0, 0, 0};
-        if (k < end) cur = load(k);
+        Obs ring[kAccDepth];
+#pragma unroll
+        for (int d = 0; d < kAccDepth; ++d) {
+            ring[d] = Obs{0, 0, 0, 0, 0, 0};
+            if (k + d * G < end) ring[d] = load(k + d * G);
+        }
         while (k < end) {
             const int kn = k + G;
-            Obs nxt = cur;
-            if (kn < end) nxt = load(kn);
+            const Obs cur = ring[0];
+#pragma unroll
+            for (int d = 0; d + 1 < kAccDepth; ++d) ring[d] = ring[d + 1];
+            if (k + kAccDepth * G < end) ring[kAccDepth - 1] = load(k + kAccDepth * G);
             double u, v, cam[3], d, J[12];
             project(pc, cur.x, cur.y, cur.z, u, v, cam, d);
             project_jacobian(pc, cam, d, J);
@@ -268,7 +283,6 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
                 for (int b = a; b < 6; ++b) { acc[q] += ja * J[b] + jb * J[6 + b]; ++q; }
                 acc[21 + a] += ja * ru + jb * rv;
             }
-            cur = nxt;
             k = kn;
         }
     }
@@ -297,17 +311,27 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 // ---------------------------------------------------------------------------------------------- A8: trial residuals
 // blocks [0, nblk_obs): sum |w (uv - est')| over the observations (BA_filtering.py:61, 66);
 // blocks [nblk_obs, nblk_obs + nblk_dyn): sqrt(sigma) sum |r_pred'| over the pose edges (BA_filtering.py:65, 67).
+// EMIT: the observation blocks also write the |r| keys, their exponent histogram (select digit 0, zeroed by this
+// call's k_select_final) and the block sums of |r| at the trial states -- the input of the next call if this trial
+// is accepted (k_decide clears the histogram again if it is not).
+template <bool EMIT>
 __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     __shared__ double red[kObsBlock / 64];
+    __shared__ unsigned lh[EMIT ? 1024 : 1];
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
     const WinScalars& sc = V.sc[w];
     if (sc.done) return;
     const int n = V.n[w], m = V.m[w];
     const StepParams& prm = V.prm;
-    double s = 0.0;
+    double s = 0.0, s_raw = 0.0;
     const size_t sb = (size_t)w * V.n_max;
-    if ((int)blockIdx.x < V.nblk_obs) {
+    const bool obs_block = (int)blockIdx.x < V.nblk_obs;
+    if (EMIT && obs_block) {
+        for (int b = threadIdx.x; b < 1024; b += kObsBlock) lh[b] = 0u;
+        __syncthreads();
+    }
+    if (obs_block) {
         const int k = blockIdx.x * kObsBlock + threadIdx.x;
         if (k < m) {
             const size_t ob = (size_t)w * V.m_max;
@@ -317,7 +341,15 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             double u, v, cam[3], d;
             project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
             const double wk = (V.wraw[ob + k] / bits_f64(sc.wmax_bits)) * V.oconf[ob + k];
-            s = fabs((V.ou[ob + k] - u) * wk) + fabs((V.ov[ob + k] - v) * wk);
+            const double du = V.ou[ob + k] - u, dv = V.ov[ob + k] - v;
+            s = fabs(du * wk) + fabs(dv * wk);
+            if (EMIT) {
+                const double ru = fabs(du), rv = fabs(dv);
+                reinterpret_cast<double2*>(V.absr + 2 * ob)[k] = make_double2(ru, rv);
+                s_raw = ru + rv;
+                atomicAdd(&lh[(unsigned)(f64_bits(ru) >> 53) & 1023u], 1u);
+                atomicAdd(&lh[(unsigned)(f64_bits(rv) >> 53) & 1023u], 1u);
+            }
         }
     } else {
         const int db = blockIdx.x - V.nblk_obs;
@@ -336,6 +368,15 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     }
     const double t = block_sum<kObsBlock>(s, red);
     if (threadIdx.x == 0) V.part_trial[(size_t)w * (V.nblk_obs + V.nblk_dyn) + blockIdx.x] = t;
+    if (EMIT && obs_block) {
+        const double t_raw = block_sum<kObsBlock>(s_raw, red);
+        if (threadIdx.x == 0) V.part_next[(size_t)w * V.nblk_obs + blockIdx.x] = t_raw;
+        unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
+        for (int b = threadIdx.x; b < 1024; b += kObsBlock) {
+            const unsigned c = lh[b];
+            if (c) atomicAdd(&hist[b], c);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- debug
@@ -369,6 +410,15 @@ __global__ __launch_bounds__(256) void k_broadcast_states(DevView V, int n, doub
 __global__ void k_reset_calls(DevView V) {
     const int w = blockIdx.x * 64 + threadIdx.x;
     if (w < V.W) V.sc[w].call_idx = 0;
+}
+
+// exponent histogram left behind by a k_trial<true> whose states were replaced before anybody used it
+__global__ __launch_bounds__(1024) void k_clear_hist0(DevView V) {
+    V.hist[(size_t)blockIdx.x * kSelPasses * kSelBins + threadIdx.x] = 0u;
+}
+
+void launch_clear_hist0(const DevView& V, hipStream_t s) {
+    hipLaunchKernelGGL(k_clear_hist0, dim3(V.W), dim3(1024), 0, s, V);
 }
 
 void launch_reset_calls(const DevView& V, hipStream_t s) {
@@ -419,7 +469,9 @@ void launch_obs_accumulate(const DevView& V, hipStream_t s) {
 }
 
 void launch_trial(const DevView& V, hipStream_t s) {
-    hipLaunchKernelGGL(k_trial, dim3(V.nblk_obs + V.nblk_dyn, V.W), dim3(kObsBlock), 0, s, V);
+    const dim3 g(V.nblk_obs + V.nblk_dyn, V.W), b(kObsBlock);
+    if (V.emit) hipLaunchKernelGGL(k_trial<true>, g, b, 0, s, V);
+    else hipLaunchKernelGGL(k_trial<false>, g, b, 0, s, V);
 }
 
 void launch_debug_project(const DevView& V, int w, int m, double* est, double* J, double* wt, hipStream_t s) {

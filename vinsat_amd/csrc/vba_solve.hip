@@ -844,7 +844,9 @@ __global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const doub
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     if (sc.done) return;
+    unsigned* hist0 = V.hist + (size_t)w * kSelPasses * kSelBins;     // digit 0, filled by k_trial<true>
     if (sc.flags & 8u) {            // the un-pivoted solve failed its check: the host repeats it with pivoting
+        if (V.emit) for (int b = threadIdx.x; b < 1024; b += kDecideThreads) hist0[b] = 0u;
         if (threadIdx.x == 0) {
             V.host_head[w].flags = sc.flags;
             V.host_head[w].done = 0;
@@ -865,7 +867,9 @@ __global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const doub
     if (first) {
         // init_residual = mean |[r_obs ; sqrt(Sigma) r_pred]| with UNweighted r_obs (BA_filtering.py:51)
         double so;
-        if (V.m_total == 0) {
+        if (V.m_total == 0 && V.carry) {
+            so = sc.next_sum_abs_robs;      // the same block sums, added up the same way when that trial was accepted
+        } else if (V.m_total == 0) {
             double s = 0.0;
             const double* pi = V.part_init + (size_t)w * V.nblk_obs;
             for (int b = t; b < V.nblk_obs; b += kDecideThreads) s += pi[b];
@@ -916,7 +920,19 @@ __global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const doub
         const double* D = V.bands + (sb + n - 1) * 243 + 81;
         if (t < 81) sc.last_hessian[t] = D[t] + ((t / 9 == t % 9) ? lam32 : 0.0);
     }
+    double so_next = 0.0;
+    if (V.emit) {
+        if (stop) {     // the keys k_trial left behind are the next call's
+            const double* pn = V.part_next + (size_t)w * V.nblk_obs;
+            double s = 0.0;
+            for (int b = t; b < V.nblk_obs; b += kDecideThreads) s += pn[b];
+            so_next = block_sum<kDecideThreads>(s, red);
+        } else {        // rejected: the next trial histograms its own keys
+            for (int b = t; b < 1024; b += kDecideThreads) hist0[b] = 0u;
+        }
+    }
     if (t == 0) {
+        if (V.emit && stop) sc.next_sum_abs_robs = so_next;
         sc.trial_residual = residual;
         sc.n_trials += 1;
         if (stop) {

@@ -62,6 +62,10 @@ class BAEngine:
         """Lanes per pose of the accumulation kernel (0 = automatic)."""
         _lib.check(self.lib.vba_set_accumulate_lanes(self.h, int(lanes)), self.lib)
 
+    def set_key_carry(self, on):
+        """True (default): an accepted trial leaves the next call's |r| keys behind; False: every call recomputes them."""
+        _lib.check(self.lib.vba_set_key_carry(self.h, int(bool(on))), self.lib)
+
     def set_pivoting(self, always):
         """False (default): unpivoted fast path with checked pivots and automatic fallback; True: always pivot."""
         _lib.check(self.lib.vba_set_pivoting(self.h, int(bool(always))), self.lib)
