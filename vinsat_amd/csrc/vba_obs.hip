@@ -97,6 +97,17 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
     constexpr int nbins = 1 << sel_width(P);
     for (int b = threadIdx.x; b < nbins; b += 256) lh[b] = 0u;
+    // few keys per thread (single window, latency matters): their loads are issued before the histogram of the
+    // previous digit is resolved, not after
+    constexpr bool PRELOAD = ITEMS <= 8;
+    unsigned long long pk[PRELOAD ? ITEMS : 1];
+    if (PRELOAD) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int64_t idx = ((int64_t)blockIdx.x * ITEMS + it) * 256 + threadIdx.x;
+            pk[it] = idx < count ? f64_bits(keys[idx]) : 0ull;
+        }
+    }
     unsigned long long prefix = 0ull;
     // torch.median = lower median (BA_filtering.py:23); in sharded mode the gathered buffer may end in +inf padding
     long long rank = ((V.m_total ? 2 * V.m_total : count) - 1) / 2;
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     for (int it = 0; it < ITEMS; ++it) {
         const int64_t idx = ((int64_t)blockIdx.x * ITEMS + it) * 256 + threadIdx.x;
         if (idx < count) {
-            const unsigned long long key = f64_bits(keys[idx]);
+            const unsigned long long key = PRELOAD ? pk[it] : f64_bits(keys[idx]);
             bool match = true;
             if (P > 0) match = (key >> sel_shift(P > 0 ? P - 1 : 0)) == prefix;
             if (match) atomicAdd(&lh[(unsigned)(key >> sel_shift(P)) & (nbins - 1)], 1u);
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
                         const unsigned off = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
                         // the list has room for 2 m_max keys; if more match (massive ties) k_select_final sees
                         // sel_cnt > capacity and rescans the full key array instead
-                        if ((int64_t)base + off < 2 * V.m_max) V.ckeys[2 * (size_t)w * V.m_max + base + off] = keys[idx];
+                        if ((int64_t)base + off < 2 * V.m_max) V.ckeys[2 * (size_t)w * V.m_max + base + off] = bits_f64(key);
                     }
                 }
             }
@@ -155,13 +166,26 @@ __global__ __launch_bounds__(256) void k_select_final(DevView V) {
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
+    // latency chain of one block: the list length, the wanted rank and the first 1024 list entries are loaded together
+    // (the entries speculatively: the list is almost always that short)
     unsigned cnt = sc.sel_cnt;
+    const long long want = sc.sel_rank[2];
     const double* ck = V.ckeys + 2 * (size_t)w * V.m_max;
+    unsigned long long pre[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned q = threadIdx.x + 256u * j;
+        pre[j] = (int64_t)q < 2 * V.m_max ? f64_bits(ck[q]) : 0ull;
+    }
     if (cnt <= 1024u) {
         // usual case, a handful of candidates: every key of the list matches the 21 known bits and the wanted key is
         // the one of rank sel_rank[2] among them -- rank each key by counting (ties broken by position)
-        const long long want = sc.sel_rank[2];
-        for (unsigned q = threadIdx.x; q < cnt; q += 256) skeys[q] = f64_bits(ck[q]);
+        for (int b = threadIdx.x; b < 3 * kSelBins; b += 256) hist[b] = 0u;     // clean for the next step
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned q = threadIdx.x + 256u * j;
+            if (q < cnt) skeys[q] = pre[j];
+        }
         __syncthreads();
         for (unsigned q = threadIdx.x; q < cnt; q += 256) {
             const unsigned long long key = skeys[q];
@@ -172,6 +196,7 @@ __global__ __launch_bounds__(256) void k_select_final(DevView V) {
             }
             if (below == want) sc.c_obs = bits_f64(key);
         }
+        return;
     } else {
         if ((int64_t)cnt > 2 * V.m_max) {       // list overflowed: fall back to the full key array
             ck = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;

@@ -835,123 +835,149 @@ __global__ __launch_bounds__(64) void k_solve_blockdiag(DevView V, int PB) {
 // ================================================================================================== accept test
 // LM accept test (BA_filtering.py:51, 66-79).  ranks == 0: sum this window's block partials; ranks > 0: the
 // observation part is the rank-ordered sum of the gathered per-rank sums (sharded mode).
+//
+// One block per window and nothing but latency: the kernel is a handful of dependent round trips to memory, so every
+// load whose address does not depend on loaded data (scalars, all block partials, the dynamics residuals, the states
+// to be committed) is issued up front, speculatively, and the four block sums share one reduction.  The sums are
+// formed in the same order as by block_sum (per-thread strided partials, wave butterflies, wave totals in order).
 constexpr int kDecideThreads = 1024;
+constexpr int kDecidePre = 5;       // state elements per thread loaded ahead of the decision (covers 512 poses)
 
 __global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const double* trial_all, int ranks) {
-    __shared__ double red[kDecideThreads / 64];
-    __shared__ double bc[2];
+    __shared__ double red[4][kDecideThreads / 64];
+    __shared__ int bstop;
     const int w = blockIdx.x;
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
-    if (sc.done) return;
-    unsigned* hist0 = V.hist + (size_t)w * kSelPasses * kSelBins;     // digit 0, filled by k_trial<true>
-    if (sc.flags & 8u) {            // the un-pivoted solve failed its check: the host repeats it with pivoting
-        if (V.emit) for (int b = threadIdx.x; b < 1024; b += kDecideThreads) hist0[b] = 0u;
-        if (threadIdx.x == 0) {
-            V.host_head[w].flags = sc.flags;
-            V.host_head[w].done = 0;
-            __threadfence_system();
-        }
-        return;
-    }
-    const int n = V.n[w];
     const int t = threadIdx.x;
     const StepParams& prm = V.prm;
     const size_t sb = (size_t)w * V.n_max;
-    const double M = V.m_total ? (double)V.m_total : (double)V.m[w];
-    const double denom = 2.0 * M + (prm.initialize ? 6.0 : 7.0) * (double)(n - 1);
-    const bool first = sc.n_trials == 0;
-    double init_residual = sc.init_residual;
-    const double lam_in = sc.lamda, lam32 = sc.lam32;
-    __syncthreads();        // every thread has read the scalars that thread 0 rewrites at the end
-    if (first) {
-        // init_residual = mean |[r_obs ; sqrt(Sigma) r_pred]| with UNweighted r_obs (BA_filtering.py:51)
-        double so;
-        if (V.m_total == 0 && V.carry) {
-            so = sc.next_sum_abs_robs;      // the same block sums, added up the same way when that trial was accepted
-        } else if (V.m_total == 0) {
-            double s = 0.0;
-            const double* pi = V.part_init + (size_t)w * V.nblk_obs;
-            for (int b = t; b < V.nblk_obs; b += kDecideThreads) s += pi[b];
-            so = block_sum<kDecideThreads>(s, red);
-        } else {
-            so = sc.sum_abs_robs;
+    // ---- loads, all independent of each other
+    const int done = sc.done;
+    const unsigned flags = sc.flags;
+    const int n_trials = sc.n_trials;
+    const double init_prev = sc.init_residual, lam_in = sc.lamda, lam32 = sc.lam32;
+    const double so_carried = sc.next_sum_abs_robs, so_sharded = sc.sum_abs_robs;
+    const int n = V.n[w], m = V.m[w];
+    double s_init = 0.0, s_pred = 0.0, s_trial = 0.0, s_next = 0.0;
+    if (V.m_total == 0 && !V.carry) {
+        const double* pi = V.part_init + (size_t)w * V.nblk_obs;
+        for (int b = t; b < V.nblk_obs; b += kDecideThreads) s_init += pi[b];
+    }
+    if (!prm.initialize) {
+        for (int i = t; i < V.n_max - 1; i += kDecideThreads) {
+            const double* ro = V.rorb + (sb + i) * 6;
+            const double v = fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]) + fabs(V.fatt[sb + i]);
+            if (i < n - 1) s_pred += v;
         }
-        double sp = 0.0;
-        if (!prm.initialize) {
-            for (int i = t; i < n - 1; i += kDecideThreads) {
-                const double* ro = V.rorb + (sb + i) * 6;
-                sp += fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]) + fabs(V.fatt[sb + i]);
-            }
-            sp = block_sum<kDecideThreads>(sp, red) * prm.sqrt_sigma;
-        }
+    }
+    if (ranks == 0) {
+        const double* pt = V.part_trial + (size_t)w * (V.nblk_obs + V.nblk_dyn);
+        for (int b = t; b < V.nblk_obs + V.nblk_dyn; b += kDecideThreads) s_trial += pt[b];
+    }
+    if (V.emit) {
+        const double* pn = V.part_next + (size_t)w * V.nblk_obs;
+        for (int b = t; b < V.nblk_obs; b += kDecideThreads) s_next += pn[b];
+    }
+    const double* s_new = V.states_new + sb * 10;
+    double* s_cur = V.states + sb * 10;
+    double* s_prev = V.states_prev + sb * 10;
+    double pre_new[kDecidePre], pre_cur[kDecidePre];
+#pragma unroll
+    for (int j = 0; j < kDecidePre; ++j) {
+        const int k = t + j * kDecideThreads;
+        const bool in = k < V.n_max * 10;
+        pre_new[j] = in ? s_new[k] : 0.0;
+        pre_cur[j] = in ? s_cur[k] : 0.0;
+    }
+    double sh_trial = 0.0;
+    if (ranks > 0) {
+        sh_trial = trial_all[1];
+        for (int q = 0; q < ranks; ++q) sh_trial += trial_all[2 * q];
+    }
+    // ---- decisions
+    if (done) return;
+    unsigned* hist0 = V.hist + (size_t)w * kSelPasses * kSelBins;     // digit 0, filled by k_trial<true>
+    if (flags & 8u) {               // the un-pivoted solve failed its check: the host repeats it with pivoting
+        if (V.emit) for (int b = t; b < 1024; b += kDecideThreads) hist0[b] = 0u;
         if (t == 0) {
+            V.host_head[w].flags = flags;
+            V.host_head[w].done = 0;
+        }
+        return;
+    }
+    const double D_last = t < 81 ? V.bands[(sb + n - 1) * 243 + 81 + t] : 0.0;
+    {   // four block sums with one pair of barriers
+        const double v4[4] = {wave_sum(s_init), wave_sum(s_pred), wave_sum(s_trial), wave_sum(s_next)};
+        if ((t & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[q][t >> 6] = v4[q];
+        }
+    }
+    __syncthreads();
+    const double lam = lam_in * 10.0;
+    if (t == 0) {
+        double tot[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double a = 0.0;
+#pragma unroll
+            for (int i = 0; i < kDecideThreads / 64; ++i) a += red[q][i];
+            tot[q] = a;
+        }
+        const double M = V.m_total ? (double)V.m_total : (double)m;
+        const double denom = 2.0 * M + (prm.initialize ? 6.0 : 7.0) * (double)(n - 1);
+        double init_residual = init_prev;
+        if (n_trials == 0) {
+            // init_residual = mean |[r_obs ; sqrt(Sigma) r_pred]| with UNweighted r_obs (BA_filtering.py:51)
+            // carried keys: the same block sums were added up the same way when that trial was accepted
+            const double so = V.m_total ? so_sharded : (V.carry ? so_carried : tot[0]);
+            const double sp = prm.initialize ? 0.0 : tot[1] * prm.sqrt_sigma;
             init_residual = (so + sp) / denom;
             sc.sum_abs_robs = so;
             sc.sum_abs_rpred = sp;
             sc.init_residual = init_residual;
-            bc[0] = init_residual;
         }
-        __syncthreads();
-        init_residual = bc[0];
-    }
-    double S;
-    if (ranks > 0) {
-        S = trial_all[1];
-        for (int q = 0; q < ranks; ++q) S += trial_all[2 * q];
-    } else {
-        const double* pt = V.part_trial + (size_t)w * (V.nblk_obs + V.nblk_dyn);
-        double s = 0.0;
-        for (int b = t; b < V.nblk_obs + V.nblk_dyn; b += kDecideThreads) s += pt[b];
-        s = block_sum<kDecideThreads>(s, red);
-        if (t == 0) bc[1] = s;
-        __syncthreads();
-        S = bc[1];
-    }
-    const double residual = S / denom;
-    const double lam = lam_in * 10.0;
-    const bool accept = residual < init_residual;
-    const bool stop = accept || lam > 1e4;
-    if (stop) {
-        const double* s_new = V.states_new + sb * 10;
-        double* s_cur = V.states + sb * 10;
-        double* s_prev = V.states_prev + sb * 10;
-        for (int k = t; k < n * 10; k += kDecideThreads) { s_prev[k] = s_cur[k]; s_cur[k] = s_new[k]; }
-        const double* D = V.bands + (sb + n - 1) * 243 + 81;
-        if (t < 81) sc.last_hessian[t] = D[t] + ((t / 9 == t % 9) ? lam32 : 0.0);
-    }
-    double so_next = 0.0;
-    if (V.emit) {
-        if (stop) {     // the keys k_trial left behind are the next call's
-            const double* pn = V.part_next + (size_t)w * V.nblk_obs;
-            double s = 0.0;
-            for (int b = t; b < V.nblk_obs; b += kDecideThreads) s += pn[b];
-            so_next = block_sum<kDecideThreads>(s, red);
-        } else {        // rejected: the next trial histograms its own keys
-            for (int b = t; b < 1024; b += kDecideThreads) hist0[b] = 0u;
-        }
-    }
-    if (t == 0) {
-        if (V.emit && stop) sc.next_sum_abs_robs = so_next;
+        const double S = ranks > 0 ? sh_trial : tot[2];
+        const double residual = S / denom;
+        const bool accept = residual < init_residual;
+        const bool stop = accept || lam > 1e4;
+        bstop = stop ? 1 : 0;
+        unsigned fl = flags;
+        if (V.emit && stop) sc.next_sum_abs_robs = tot[3];
         sc.trial_residual = residual;
-        sc.n_trials += 1;
+        sc.n_trials = n_trials + 1;
+        double lam_out = lam;
+        int call_idx = sc.call_idx;
         if (stop) {
             sc.done = 1;
-            if (V.call >= 0) sc.call_idx = V.call + 1;
-            if (!accept) sc.flags |= 1u;
-            if (!(residual == residual)) sc.flags |= 2u;
-            sc.lamda = fmax(fmin(1e-1, lam * 0.01), 1e-4);
-        } else {
-            sc.lamda = lam;
+            if (V.call >= 0) sc.call_idx = call_idx = V.call + 1;
+            if (!accept) fl |= 1u;
+            if (!(residual == residual)) fl |= 2u;
+            sc.flags = fl;
+            lam_out = fmax(fmin(1e-1, lam * 0.01), 1e-4);
         }
+        sc.lamda = lam_out;
+        // read by the host after it has waited for the stream: no fence needed
         WinHead& hh = V.host_head[w];
-        hh.lamda = sc.lamda;
+        hh.lamda = lam_out;
         hh.trial_residual = residual;
-        hh.n_trials = sc.n_trials;
-        hh.flags = sc.flags;
+        hh.n_trials = n_trials + 1;
+        hh.flags = fl;
         hh.done = stop ? 1 : 0;
-        hh.call_idx = sc.call_idx;
-        __threadfence_system();
+        hh.call_idx = call_idx;
+    }
+    __syncthreads();
+    if (bstop) {
+#pragma unroll
+        for (int j = 0; j < kDecidePre; ++j) {
+            const int k = t + j * kDecideThreads;
+            if (k < n * 10) { s_prev[k] = pre_cur[j]; s_cur[k] = pre_new[j]; }
+        }
+        for (int k = t + kDecidePre * kDecideThreads; k < n * 10; k += kDecideThreads) { s_prev[k] = s_cur[k]; s_cur[k] = s_new[k]; }
+        if (t < 81) sc.last_hessian[t] = D_last + ((t / 9 == t % 9) ? lam32 : 0.0);
+    } else if (V.emit) {            // rejected: the next trial histograms its own keys
+        for (int b = t; b < 1024; b += kDecideThreads) hist0[b] = 0u;
     }
 }
 
