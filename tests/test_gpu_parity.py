@@ -23,8 +23,10 @@ def eng_c1(c1, request):
     e.close()
 
 
-@pytest.fixture(scope="module", params=[(-1, False), (0, False), (7, False), (-1, True), (0, True), ((5, 4), False), ((3, 2), True)],
-                ids=["partitioned", "sequential", "chunk7", "partitioned-pivot", "sequential-pivot", "two-level-5-4", "two-level-3-2-pivot"])
+@pytest.fixture(scope="module", params=[(-1, False), (0, False), (7, False), (-1, True), (0, True), ((5, 4), False), ((3, 2), True),
+                                        ((7, -1), False), ((3, -1), True), ((5, 0), False)],
+                ids=["default", "sequential", "chunk7", "default-pivot", "sequential-pivot", "two-level-5-4", "two-level-3-2-pivot",
+                     "cyclic-7", "cyclic-3-pivot", "one-level-5"])
 def eng_c2(c2, request):
     from vinsat_amd.engine import BAEngine
     inp = golden_inputs(c2)

@@ -259,8 +259,10 @@ int vba_destroy(vba_handle h) {
 
 int vba_set_solver2(vba_handle h, int chunk, int chunk2) {
     if (!h) return fail(VBA_EINVAL, "null handle");
-    if (chunk < 2 || chunk > 60 || (chunk2 != 0 && (chunk2 < 2 || chunk2 > 60)))
-        return fail(VBA_EINVAL, "chunk sizes must be in [2, 60] (chunk2 = 0: single level)");
+    if (chunk < 2 || chunk > 60 || (chunk2 != 0 && chunk2 != -1 && (chunk2 < 2 || chunk2 > 60)))
+        return fail(VBA_EINVAL, "chunk sizes must be in [2, 60] (chunk2 = 0: single level, -1: cyclic reduction)");
+    if (chunk2 == -1 && (h->n_max + chunk - 1) / chunk - 1 > 64)
+        return fail(VBA_EINVAL, "chunk2 = -1 needs at most 64 separators: chunk >= ceil(n_max / 65)");
     h->V.chunk = chunk;
     h->V.chunk2 = chunk2;
     h->no_pack = 0;
@@ -270,15 +272,18 @@ int vba_set_solver2(vba_handle h, int chunk, int chunk2) {
 int vba_set_solver(vba_handle h, int chunk) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     h->V.chunk2 = 0;
-    if (chunk == -1) {      // default: many windows supply their own parallelism; a long chain is cut on two levels
-        h->no_pack = 0;     // (~n^(1/3) poses per chunk), a short one on one level (~sqrt(n))
+    if (chunk == -1) {      // default: many windows supply their own parallelism (one wave walks each chain);
+        h->no_pack = 0;     // otherwise the chain is cut into chunks and the reduced system over the (at most 64)
+                            // separators is solved by cyclic reduction in one workgroup; very long chains: two levels
         if (h->W >= 128 || h->n_max < 8) { h->V.chunk = 0; return VBA_OK; }
-        if (h->n_max >= 128) {
+        const int c1 = std::max((h->n_max + 64) / 65, 2);
+        if (c1 <= 60) {
+            h->V.chunk = c1;
+            h->V.chunk2 = -1;
+        } else {
             const int c3 = std::min(std::max((int)std::ceil(std::cbrt((double)h->n_max)), 2), 60);
             h->V.chunk = c3;
             h->V.chunk2 = c3;
-        } else {
-            h->V.chunk = std::min(std::max((int)std::ceil(std::sqrt((double)h->n_max)), 2), 60);
         }
         return VBA_OK;
     }

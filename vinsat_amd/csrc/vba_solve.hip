@@ -699,6 +699,148 @@ __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s, int s2) 
     report_pivot<PIVOT>(zero_pivot, sc, lane);
 }
 
+// The reduced system over the separators by block cyclic reduction inside ONE workgroup (16 waves, the whole system
+// in LDS): log2(n1) levels of "every other block eliminated in parallel" instead of n1 sequential block steps.
+//   level with stride h, active blocks k = r h - 1 (r = 1, 2, ...):
+//     A  odd r:   [PL | PU | Pg]_k = D_k^{-1} [L_k | U_k | g_k]                   (one Gauss-Jordan per wave, in place)
+//     B  even r:  D_j -= L_j PU_{j-h} + U_j PL_{j+h},  g_j -= L_j Pg_{j-h} + U_j Pg_{j+h},
+//                 L_j  = -L_j PL_{j-h},  U_j = -U_j PU_{j+h}                        (couples j to j -+ 2h from now on)
+//   back substitution, coarsest level first:  x_k = Pg_k - PL_k x_{k-h} - PU_k x_{k+h}.
+// Schur complements of the (damped, near-SPD) system stay near-SPD, so the unpivoted path applies with the same
+// per-pivot check; PIVOT exchanges rows inside a block as everywhere else.
+// LDS: n1 blocks of 252 doubles [L | D | U | g]; x overwrites g.  n1 <= kCrMax.
+constexpr int kCrMax = 64;
+constexpr int kCrThreads = 1024;
+
+template <bool PIVOT>
+__global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int s) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int w = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n1 = n_separators(V.n[w], s);
+    if (n1 <= 0 || n1 > kCrMax) return;         // the host only selects this kernel when n1 fits
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = kCrThreads / 64;
+    const size_t sb = (size_t)w * V.n_max;
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lamda;
+    const ReducedSource<BandSource> src{BandSource{V.bands + sb * 243, V.rhs + sb * 9}, V.cL + rb * 171, V.cR + rb * 171, s};
+    // the reduced system into LDS, eight entries per thread at a time so that their (three-operand) loads overlap
+    for (int idx0 = tid; idx0 < n1 * 252; idx0 += 8 * kCrThreads) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = idx0 + u * kCrThreads;
+            v[u] = idx < n1 * 252 ? src(idx / 252, idx % 252) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = idx0 + u * kCrThreads;
+            if (idx < n1 * 252) {
+                const int q = idx / 252, e = idx % 252;
+                double x = v[u];
+                if (e >= 81 && e < 162 && (e - 81) / 9 == (e - 81) % 9) x += lam32;
+                if ((q == 0 && e < 81) || (q == n1 - 1 && e >= 162 && e < 243)) x = 0.0;     // no neighbour on that side
+                smem[idx] = x;
+            }
+        }
+    }
+    __syncthreads();
+    bool bad = false;
+    // lane -> column of [D | L | U | g]: one address per lane and role (selecting among loaded VALUES would make every
+    // lane load every alternative)
+    const int grp = lane < 9 ? 0 : (lane < 18 ? 1 : (lane < 27 ? 2 : (lane == 27 ? 3 : 4)));
+    const int c = grp < 3 ? lane - 9 * grp : 0;
+    const int own = grp == 0 ? 81 + c : (grp == 1 ? c : (grp == 2 ? 162 + c : 243));      // first element of the lane's own column
+    const int ownst = grp == 3 ? 1 : 9;                                                    // ... and its stride
+    const int m_off = grp == 0 ? 162 + c : (grp == 1 ? c : 243);           // column of the left neighbour's P this lane multiplies L_j with
+    const int p_off = grp == 0 ? c : (grp == 2 ? 162 + c : 243);           // ... of the right neighbour's, for U_j
+    const bool m_use = grp == 0 || grp == 1 || grp == 3, p_use = grp == 0 || grp == 2 || grp == 3;
+    int h = 1;
+    for (;; h <<= 1) {
+        const int cnt = n1 / h;                 // active blocks of this level
+        const int nel = (cnt + 1) / 2;
+#pragma nounroll
+        for (int t = wave; t < nel; t += NW) {  // A: eliminate the odd-ranked blocks
+            double* B = smem + (size_t)((2 * t + 1) * h - 1) * 252;
+            double base[9], a[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const double v = B[own + r * ownst];
+                base[r] = grp < 4 ? v : 0.0;
+                a[r] = 0.0;
+            }
+            forward_step<0, 10, PIVOT, false>(nullptr, base, a, lane, bad);
+            if (grp >= 1 && grp <= 3) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) B[own + r * ownst] = a[r];
+            }
+        }
+        __syncthreads();
+        if (cnt <= 1) break;
+        const int nk = cnt / 2;
+#pragma nounroll
+        for (int t = wave; t < nk; t += NW) {   // B: fold the eliminated neighbours into the even-ranked blocks
+            const int j = (2 * t + 2) * h - 1;
+            double* Bj = smem + (size_t)j * 252;
+            const double* Pm = smem + (size_t)(j - h) * 252;
+            const bool has_p = j + h < n1;
+            const double* Pp = smem + (size_t)(has_p ? j + h : j) * 252;
+            double b1[9], b2[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const double u = Pm[m_off + q * ownst], v = Pp[p_off + q * ownst];
+                b1[q] = m_use ? u : 0.0;
+                b2[q] = (p_use && has_p) ? v : 0.0;
+            }
+            // one row at a time (a rolled loop: unrolled, the 162 broadcast reads of L_j / U_j are all hoisted and
+            // spill).  Row r of the new L_j / U_j replaces the old one as soon as the wave has read it: the LDS
+            // operations of a wave execute in order and no later row needs it.
+#pragma nounroll
+            for (int r = 0; r < 9; ++r) {
+                const double o0 = Bj[own + r * ownst];
+                double o = (grp == 0 || grp == 3) ? o0 : 0.0;
+                const double* Lr = Bj + r * 9;
+                const double* Ur = Bj + 162 + r * 9;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    o -= Lr[q] * b1[q];             // broadcast reads
+                    o -= Ur[q] * b2[q];
+                }
+                if (grp < 4) Bj[own + r * ownst] = o;
+            }
+        }
+        __syncthreads();
+    }
+    // back substitution: the level that ended the loop has a single block with no active neighbour (x = Pg)
+    for (; h >= 1; h >>= 1) {
+        const int cnt = n1 / h;
+        const int nel = (cnt + 1) / 2;
+        for (int idx = tid; idx < nel * 9; idx += kCrThreads) {
+            const int t = idx / 9, r = idx % 9;
+            const int k = (2 * t + 1) * h - 1;
+            double* B = smem + (size_t)k * 252;
+            double x = B[243 + r];
+            if (k - h >= 0) {
+                const double* xm = smem + (size_t)(k - h) * 252 + 243;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) x -= B[r * 9 + q] * xm[q];
+            }
+            if (k + h < n1) {
+                const double* xp = smem + (size_t)(k + h) * 252 + 243;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) x -= B[162 + r * 9 + q] * xp[q];
+            }
+            B[243 + r] = x;     // read only by this thread at this level (the neighbours belong to coarser levels)
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < n1 * 9; idx += kCrThreads) V.rx[rb * 9 + idx] = smem[(size_t)(idx / 9) * 252 + 243 + idx % 9];
+    report_pivot<PIVOT>(bad, sc, lane);
+}
+
 // Recovery of a partitioned chain: x_i = yhat_i - Vhat_i x_left - What_i x_right for interior blocks, separators
 // copied from the reduced solution.
 __device__ __forceinline__ void recover_block(int i, int n, int s, const double* csol, const double* xsep, double (&d9)[9]) {
@@ -1002,6 +1144,11 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
         const size_t lds2 = (512 + (size_t)cs2 * 252 + 162) * sizeof(double);
         hipLaunchKernelGGL(k_solve_chunks2<PIVOT>, dim3(P2 > 0 ? P2 : 1, V.W), dim3(64), lds2, s, V, cs, cs2);
     }
+    if (cs2 < 0) {      // one level, the reduced system by cyclic reduction in one workgroup
+        const int n1 = P - 1;
+        if (n1 > 0) hipLaunchKernelGGL(k_solve_reduced_cr<PIVOT>, dim3(V.W), dim3(kCrThreads), (size_t)n1 * 252 * sizeof(double), s, V, cs);
+        return;
+    }
     hipLaunchKernelGGL(k_solve_reduced<PIVOT>, dim3(V.W), dim3(64), 0, s, V, cs, cs2);
 }
 
@@ -1013,6 +1160,9 @@ void launch_solve(const DevView& V, int initialize, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        const int cap_cr = kCrMax * 252 * (int)sizeof(double);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
         lds_attr_set = true;
     }
     if (V.pivot != 1) launch_solve_variant<false>(V, initialize, s);

@@ -47,8 +47,8 @@ class BAEngine:
             pass
 
     def set_solver(self, chunk, chunk2=None):
-        """0 = sequential chain, 2..60 = partitioned with that chunk size (chunk2: second-level chunk size),
-        -1 = default, -2 = sequential without packing."""
+        """0 = sequential chain, 2..60 = partitioned with that chunk size (chunk2: second-level chunk size, or -1 =
+        reduced system by cyclic reduction), -1 = default, -2 = sequential without packing."""
         if chunk2 is None:
             _lib.check(self.lib.vba_set_solver(self.h, int(chunk)), self.lib)
         else:
