@@ -477,21 +477,21 @@ __device__ __forceinline__ void chunk_range(int c, int s, int n, int& a, int& b,
 template <class Inner>
 struct ReducedSource {
     Inner inner;
-    const double* cL;       // [ns][19][9]
+    const double* cL;       // [ns][9][19]
     const double* cR;
     int s;
     __device__ double operator()(int q, int e) const {
         const int j = (q + 1) * s - 1;
-        const double* l = cL + (size_t)q * 171;
-        const double* r_ = cR + (size_t)q * 171;
+        const double* l = cL + (size_t)q * 171;         // [row][19 columns]: row-major like the bands, so that a
+        const double* r_ = cR + (size_t)q * 171;        // consumer walking e reads runs of 9 contiguous doubles
         if (e >= 243) {
             const int r = e - 243;
-            return inner(j, e) - l[r] - r_[r];
+            return inner(j, e) - l[r * 19] - r_[r * 19];
         }
         const int which = e / 81, r = (e % 81) / 9, cc = e % 9;
-        if (which == 0) return -l[(1 + cc) * 9 + r];
-        if (which == 2) return -r_[(10 + cc) * 9 + r];
-        return inner(j, e) - l[(10 + cc) * 9 + r] - r_[(1 + cc) * 9 + r];
+        if (which == 0) return -l[r * 19 + 1 + cc];
+        if (which == 2) return -r_[r * 19 + 10 + cc];
+        return inner(j, e) - l[r * 19 + 10 + cc] - r_[r * 19 + 1 + cc];
     }
 };
 
@@ -585,13 +585,13 @@ __device__ __forceinline__ void chunk_eliminate(const Src& src, int n, int s, in
     }
     // contribution of this chunk to its right separator j = b+1:  L_j [yhat_b | Vhat_b | What_b]
     if (has_sep && lane < 19) {
-        double* cl = cL + (size_t)c * 171 + (size_t)col * 9;
+        double* cl = cL + (size_t)c * 171 + col;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             double v = 0.0;
 #pragma unroll
             for (int k = 0; k < 9; ++k) v += Cm[r * 9 + k] * x[k];
-            cl[r] = v;
+            cl[r * 19] = v;
         }
     }
     for (int t = len - 2; t >= 0; --t) {
@@ -612,13 +612,13 @@ __device__ __forceinline__ void chunk_eliminate(const Src& src, int n, int s, in
     }
     // contribution to the left separator j = a-1:  U_j [yhat_a | Vhat_a | What_a]
     if (c > 0 && lane < 19) {
-        double* cr = cR + (size_t)(c - 1) * 171 + (size_t)col * 9;
+        double* cr = cR + (size_t)(c - 1) * 171 + col;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             double v = 0.0;
 #pragma unroll
             for (int k = 0; k < 9; ++k) v += Cm[81 + r * 9 + k] * x[k];
-            cr[r] = v;
+            cr[r * 19] = v;
         }
     }
 }
@@ -709,6 +709,7 @@ __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s, int s2) 
 // Schur complements of the (damped, near-SPD) system stay near-SPD, so the unpivoted path applies with the same
 // per-pivot check; PIVOT exchanges rows inside a block as everywhere else.
 // LDS: n1 blocks of 252 doubles [L | D | U | g]; x overwrites g.  n1 <= kCrMax.
+typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int kCrMax = 64;
 constexpr int kCrThreads = 1024;
 
@@ -726,24 +727,52 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
     const size_t sb = (size_t)w * V.n_max;
     const size_t rb = (size_t)w * V.p_max;
     const double lam32 = (double)(float)sc.lamda;
-    const ReducedSource<BandSource> src{BandSource{V.bands + sb * 243, V.rhs + sb * 9}, V.cL + rb * 171, V.cR + rb * 171, s};
-    // the reduced system into LDS, eight entries per thread at a time so that their (three-operand) loads overlap
-    for (int idx0 = tid; idx0 < n1 * 252; idx0 += 8 * kCrThreads) {
-        double v[8];
+    // The reduced system (see ReducedSource) into LDS.  A wave takes whole blocks and a lane the same (row, column)
+    // of L, D and U, so the index arithmetic is done once per three entries and nothing diverges (walking the 252
+    // entries of a block through the generic source costs more in integer divisions and branches than in loads).
+    {
+        const double* bands = V.bands + sb * 243;
+        const double* rhs = V.rhs + sb * 9;
+        const double* cL = V.cL + rb * 171;
+        const double* cR = V.cR + rb * 171;
+        constexpr int QB = kCrMax / NW;         // blocks per wave: all their loads are issued before the first store
+        const int r0 = lane / 9, c0 = lane % 9, r1 = (lane + 64) / 9, c1 = (lane + 64) % 9;
+        double lv[QB][2], lw[QB][2], rv[QB][2], rw[QB][2], dv[QB][2], gv[QB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = idx0 + u * kCrThreads;
-            v[u] = idx < n1 * 252 ? src(idx / 252, idx % 252) : 0.0;
+        for (int u = 0; u < QB; ++u) {
+            const int q = wave + u * NW;
+            const bool in = q < n1;
+            const size_t j = in ? (size_t)(q + 1) * s - 1 : 0;
+            const double* l = cL + (size_t)(in ? q : 0) * 171;
+            const double* r_ = cR + (size_t)(in ? q : 0) * 171;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int r = it ? r1 : r0, cc = it ? c1 : c0;
+                const bool ok = in && lane + 64 * it < 81;
+                lv[u][it] = ok ? l[r * 19 + 1 + cc] : 0.0;
+                lw[u][it] = ok ? l[r * 19 + 10 + cc] : 0.0;
+                rv[u][it] = ok ? r_[r * 19 + 1 + cc] : 0.0;
+                rw[u][it] = ok ? r_[r * 19 + 10 + cc] : 0.0;
+                dv[u][it] = ok ? bands[j * 243 + 81 + lane + 64 * it] : 0.0;
+            }
+            gv[u] = (in && lane < 9) ? rhs[j * 9 + lane] - l[lane * 19] - r_[lane * 19] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = idx0 + u * kCrThreads;
-            if (idx < n1 * 252) {
-                const int q = idx / 252, e = idx % 252;
-                double x = v[u];
-                if (e >= 81 && e < 162 && (e - 81) / 9 == (e - 81) % 9) x += lam32;
-                if ((q == 0 && e < 81) || (q == n1 - 1 && e >= 162 && e < 243)) x = 0.0;     // no neighbour on that side
-                smem[idx] = x;
+        for (int u = 0; u < QB; ++u) {
+            const int q = wave + u * NW;
+            if (q < n1) {
+                double* B = smem + (size_t)q * 252;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int i = lane + 64 * it;
+                    if (i < 81) {
+                        const int r = it ? r1 : r0, cc = it ? c1 : c0;
+                        B[i] = q == 0 ? 0.0 : -lv[u][it];                       // no neighbour on that side
+                        B[81 + i] = dv[u][it] - lw[u][it] - rv[u][it] + (r == cc ? lam32 : 0.0);
+                        B[162 + i] = q == n1 - 1 ? 0.0 : -rw[u][it];
+                    }
+                }
+                if (lane < 9) B[243 + lane] = gv[u];
             }
         }
     }
@@ -755,9 +784,6 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
     const int c = grp < 3 ? lane - 9 * grp : 0;
     const int own = grp == 0 ? 81 + c : (grp == 1 ? c : (grp == 2 ? 162 + c : 243));      // first element of the lane's own column
     const int ownst = grp == 3 ? 1 : 9;                                                    // ... and its stride
-    const int m_off = grp == 0 ? 162 + c : (grp == 1 ? c : 243);           // column of the left neighbour's P this lane multiplies L_j with
-    const int p_off = grp == 0 ? c : (grp == 2 ? 162 + c : 243);           // ... of the right neighbour's, for U_j
-    const bool m_use = grp == 0 || grp == 1 || grp == 3, p_use = grp == 0 || grp == 2 || grp == 3;
     int h = 1;
     for (;; h <<= 1) {
         const int cnt = n1 / h;                 // active blocks of this level
@@ -788,28 +814,57 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
             const double* Pm = smem + (size_t)(j - h) * 252;
             const bool has_p = j + h < n1;
             const double* Pp = smem + (size_t)(has_p ? j + h : j) * 252;
-            double b1[9], b2[9];
+            // out (9 x 28: new D | L | U | g) = init - [L_j | U_j] (9 x 18) * Bm (18 x 28) on the matrix cores:
+            //   Bm rows 0..8  = [PU | PL | 0  | Pg] of the left neighbour,  rows 9..17 = [PL | 0 | PU | Pg] of the right one.
+            // v_mfma_f64_16x16x4: lane l feeds A[l & 15][4 s + (l >> 4)] and B[4 s + (l >> 4)][l & 15] of k-step s and
+            // owns C[(l >> 4) + 4 i][l & 15], i = 0..3; two column tiles, five k-steps.  One LDS read per operand
+            // element instead of 162 broadcast reads per lane.
+            const int lr = lane & 15, lk = lane >> 4;
+            auto Bm = [&](int k, int col) -> double {
+                const bool lo = k < 9;
+                const int q = lo ? k : k - 9;
+                const double* P = lo ? Pm : Pp;
+                bool ok = k < 18 && (lo || has_p);
+                int off = 0;
+                if (col < 9) off = lo ? 162 + q * 9 + col : q * 9 + col;
+                else if (col < 18) { off = q * 9 + col - 9; ok = ok && lo; }
+                else if (col < 27) { off = 162 + q * 9 + col - 18; ok = ok && !lo; }
+                else if (col == 27) off = 243 + q;
+                else ok = false;
+                const double v = P[ok ? off : 0];
+                return ok ? v : 0.0;
+            };
+            d4 acc0, acc1;
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const double u = Pm[m_off + q * ownst], v = Pp[p_off + q * ownst];
-                b1[q] = m_use ? u : 0.0;
-                b2[q] = (p_use && has_p) ? v : 0.0;
+            for (int i = 0; i < 4; ++i) {
+                const int row = lk + 4 * i;
+                const bool rv = row < 9;
+                const double d0 = Bj[(rv && lr < 9) ? 81 + row * 9 + lr : 0];
+                const double g0 = Bj[(rv && lr == 11) ? 243 + row : 0];
+                acc0[i] = (rv && lr < 9) ? d0 : 0.0;
+                acc1[i] = (rv && lr == 11) ? g0 : 0.0;      // column 27 = 16 + 11
             }
-            // one row at a time (a rolled loop: unrolled, the 162 broadcast reads of L_j / U_j are all hoisted and
-            // spill).  Row r of the new L_j / U_j replaces the old one as soon as the wave has read it: the LDS
-            // operations of a wave execute in order and no later row needs it.
-#pragma nounroll
-            for (int r = 0; r < 9; ++r) {
-                const double o0 = Bj[own + r * ownst];
-                double o = (grp == 0 || grp == 3) ? o0 : 0.0;
-                const double* Lr = Bj + r * 9;
-                const double* Ur = Bj + 162 + r * 9;
 #pragma unroll
-                for (int q = 0; q < 9; ++q) {
-                    o -= Lr[q] * b1[q];             // broadcast reads
-                    o -= Ur[q] * b2[q];
+            for (int st = 0; st < 5; ++st) {
+                const int k = 4 * st + lk;
+                const bool av = lr < 9 && k < 18;
+                const double a0 = Bj[av ? (k < 9 ? lr * 9 + k : 162 + lr * 9 + (k - 9)) : 0];
+                const double am = av ? -a0 : 0.0;
+                const double b0 = Bm(k, lr), b1 = Bm(k, 16 + lr);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b1, acc1, 0, 0, 0);
+            }
+            // every operand has been read (the LDS operations of a wave execute in order): replace the block
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lk + 4 * i;
+                if (row < 9) {
+                    Bj[lr < 9 ? 81 + row * 9 + lr : row * 9 + (lr - 9)] = acc0[i];                   // D | L columns 0..6
+                    const int c1 = 16 + lr;
+                    if (c1 < 18) Bj[row * 9 + (c1 - 9)] = acc1[i];                                      // L columns 7, 8
+                    else if (c1 < 27) Bj[162 + row * 9 + (c1 - 18)] = acc1[i];                          // U
+                    else if (c1 == 27) Bj[243 + row] = acc1[i];                                         // g
                 }
-                if (grp < 4) Bj[own + r * ownst] = o;
             }
         }
         __syncthreads();
