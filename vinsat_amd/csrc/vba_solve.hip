@@ -534,17 +534,20 @@ __device__ __forceinline__ void chunk_eliminate(const Src& src, int n, int s, in
     // lanes: D/U groups in 0..17 (alternating), V = 18..26, W = 27..35, y = 36  -> rhs column order in Zb: y, V, W
     const bool isV = lane >= 18 && lane < 27, isW = lane >= 27 && lane < 36, isY = lane == 36;
     const int zcol = isY ? 0 : (isV ? 1 + (lane - 18) : (isW ? 10 + (lane - 27) : 0));
+    // one LDS address per lane and role (selecting among loaded values would make every lane load all five)
     auto load_base = [&](const double* b, int db, bool first, bool last, double (&base)[9]) {
         const int ub = 9 - db;
         const bool isD = lane >= db && lane < db + 9, isU = lane >= ub && lane < ub + 9;
+        const int cc = isD ? lane - db : (isU ? lane - ub : (isV ? lane - 18 : (isW ? lane - 27 : 0)));
+        const bool ok = isD || isU || isY || (isV && first) || (isW && last);
+        const int off = isD ? 81 + cc : ((isU || isW) ? 162 + cc : (isY ? 243 : cc));
+        const int stride = isY ? 1 : 9;
+        const double* p = b + (ok ? off : 0);
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            double v = 0.0;
-            if (isD) v = b[81 + r * 9 + (lane - db)] + ((r == lane - db) ? lam32 : 0.0);
-            else if (isU) v = b[162 + r * 9 + (lane - ub)];
-            else if (isY) v = b[243 + r];
-            else if (isV && first) v = b[r * 9 + (lane - 18)];           // L_a
-            else if (isW && last) v = b[162 + r * 9 + (lane - 27)];      // U_b
+            double v = p[r * stride];
+            v = ok ? v : 0.0;
+            if (isD && r == cc) v += lam32;
             base[r] = v;
         }
     };
