@@ -67,13 +67,14 @@ __global__ __launch_bounds__(256) void k_dynamics(DevView V) {
 // entries from LDS and the block writes its 252 * kAsmPoses outputs contiguously.
 constexpr int kAsmIn = 21 + 6 + 36 + 6 + 3 + 27;     // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl
 
-// 1/x to ~1 ulp (same sequence as the chain solver's): v_rcp_f64 plus two Newton steps
+// 1/x to ~1 ulp (same sequence as the chain solver's)
 __device__ __forceinline__ double asm_fast_rcp(double x) {
+    // 1/x = r / (1 - e) with e = 1 - x r ~ 4e-8: r (1 + e + e^2) is exact to e^3, three dependent operations after the
+    // seed instead of the four of two Newton steps
     double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
+    const double e = fma(-x, r, 1.0);
+    const double t = fma(e, e, e);
+    r = fma(r, t, r);
     return r;
 }
 

@@ -45,14 +45,15 @@ struct Roles {
     __device__ static bool isR(int lane) { return lane >= 18 && lane < 18 + NRHS; }
 };
 
-// 1/x to ~1 ulp: v_rcp_f64 plus two Newton steps (the full IEEE division sequence is 3x longer and sits on the
+// 1/x to ~1 ulp from v_rcp_f64's 24-bit seed (the full IEEE division sequence is 3x longer and sits on the
 // critical path of every pivot)
 __device__ __forceinline__ double fast_rcp(double x) {
+    // 1/x = r / (1 - e) with e = 1 - x r ~ 4e-8: r (1 + e + e^2) is exact to e^3, three dependent operations after the
+    // seed instead of the four of two Newton steps
     double r = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
+    const double e = fma(-x, r, 1.0);
+    const double t = fma(e, e, e);
+    r = fma(r, t, r);
     return r;
 }
 
