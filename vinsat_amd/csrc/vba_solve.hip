@@ -788,6 +788,33 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
     const int c = grp < 3 ? lane - 9 * grp : 0;
     const int own = grp == 0 ? 81 + c : (grp == 1 ? c : (grp == 2 ? 162 + c : 243));      // first element of the lane's own column
     const int ownst = grp == 3 ? 1 : 9;                                                    // ... and its stride
+    // fold step (B) operand addresses: they depend on the lane only, not on the block.
+    //   out (9 x 28: new D | L | U | g) = init - [L_j | U_j] (9 x 18) * Bm (18 x 28) on the matrix cores:
+    //   Bm rows 0..8  = [PU | PL | 0  | Pg] of the left neighbour,  rows 9..17 = [PL | 0 | PU | Pg] of the right one.
+    // v_mfma_f64_16x16x4: lane l feeds A[l & 15][4 s + (l >> 4)] and B[4 s + (l >> 4)][l & 15] of k-step s and
+    // owns C[(l >> 4) + 4 i][l & 15], i = 0..3; two column tiles, five k-steps.  One LDS read per operand
+    // element instead of 162 broadcast reads per lane.
+    const int lr = lane & 15, lk = lane >> 4;
+    int offA[5], offB0[5], offB1[5];        // -1: the operand element is a structural zero
+    bool hiB[5];                            // the B element comes from the right neighbour
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int k = 4 * st + lk;
+        offA[st] = (lr < 9 && k < 18) ? (k < 9 ? lr * 9 + k : 162 + lr * 9 + (k - 9)) : -1;
+        const bool lo = k < 9;
+        const int q = lo ? k : k - 9;
+        hiB[st] = !lo;
+        auto bm = [&](int col) -> int {
+            if (k >= 18) return -1;
+            if (col < 9) return lo ? 162 + q * 9 + col : q * 9 + col;
+            if (col < 18) return lo ? q * 9 + col - 9 : -1;
+            if (col < 27) return lo ? -1 : 162 + q * 9 + col - 18;
+            if (col == 27) return 243 + q;
+            return -1;
+        };
+        offB0[st] = bm(lr);
+        offB1[st] = bm(16 + lr);
+    }
     int h = 1;
     for (;; h <<= 1) {
         const int cnt = n1 / h;                 // active blocks of this level
@@ -818,26 +845,6 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
             const double* Pm = smem + (size_t)(j - h) * 252;
             const bool has_p = j + h < n1;
             const double* Pp = smem + (size_t)(has_p ? j + h : j) * 252;
-            // out (9 x 28: new D | L | U | g) = init - [L_j | U_j] (9 x 18) * Bm (18 x 28) on the matrix cores:
-            //   Bm rows 0..8  = [PU | PL | 0  | Pg] of the left neighbour,  rows 9..17 = [PL | 0 | PU | Pg] of the right one.
-            // v_mfma_f64_16x16x4: lane l feeds A[l & 15][4 s + (l >> 4)] and B[4 s + (l >> 4)][l & 15] of k-step s and
-            // owns C[(l >> 4) + 4 i][l & 15], i = 0..3; two column tiles, five k-steps.  One LDS read per operand
-            // element instead of 162 broadcast reads per lane.
-            const int lr = lane & 15, lk = lane >> 4;
-            auto Bm = [&](int k, int col) -> double {
-                const bool lo = k < 9;
-                const int q = lo ? k : k - 9;
-                const double* P = lo ? Pm : Pp;
-                bool ok = k < 18 && (lo || has_p);
-                int off = 0;
-                if (col < 9) off = lo ? 162 + q * 9 + col : q * 9 + col;
-                else if (col < 18) { off = q * 9 + col - 9; ok = ok && lo; }
-                else if (col < 27) { off = 162 + q * 9 + col - 18; ok = ok && !lo; }
-                else if (col == 27) off = 243 + q;
-                else ok = false;
-                const double v = P[ok ? off : 0];
-                return ok ? v : 0.0;
-            };
             d4 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -850,11 +857,12 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
             }
 #pragma unroll
             for (int st = 0; st < 5; ++st) {
-                const int k = 4 * st + lk;
-                const bool av = lr < 9 && k < 18;
-                const double a0 = Bj[av ? (k < 9 ? lr * 9 + k : 162 + lr * 9 + (k - 9)) : 0];
-                const double am = av ? -a0 : 0.0;
-                const double b0 = Bm(k, lr), b1 = Bm(k, 16 + lr);
+                const double a0 = Bj[offA[st] >= 0 ? offA[st] : 0];
+                const double am = offA[st] >= 0 ? -a0 : 0.0;
+                const double* P = hiB[st] ? Pp : Pm;
+                const bool okp = !hiB[st] || has_p;
+                const double v0 = P[offB0[st] >= 0 ? offB0[st] : 0], v1 = P[offB1[st] >= 0 ? offB1[st] : 0];
+                const double b0 = (okp && offB0[st] >= 0) ? v0 : 0.0, b1 = (okp && offB1[st] >= 0) ? v1 : 0.0;
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b1, acc1, 0, 0, 0);
             }
