@@ -104,6 +104,18 @@ int vba_set_integrator(vba_handle h, int hop100);
  * reduction tree, i.e. results are bit-reproducible for equal settings. */
 int vba_set_accumulate_lanes(vba_handle h, int lanes);
 
+/* BA_reg (BA_filtering.py:100-210): the BA call with a propagated-covariance prior per pose.
+ * vba_upload_prior: states_prior [n,10] (arguments states_prior / velocity_prior of BA_reg: positions and the velocity
+ * columns are used), hessian_state [n,6,6] (argument hessian_state_t: information matrix over [position, velocity]).
+ * The reference's hessian_rot_t has no effect on its result: the rotation term of prior_gpu (BA_utils.py:626) is
+ * quat_coeff (1 - |q_p^T G(q_p) H_rot G(q)^T q|) with G(q)^T q = 0 identically, i.e. a constant -- it is reproduced
+ * as that constant (1 per pose in the initial residual mean, 100 per pose in every trial mean, as the reference
+ * passes its coefficients) and takes no matrix.
+ * vba_set_prior(h, 1): the following vba_step / vba_iterate / vba_run_schedule calls are BA_reg calls (the prior is
+ * inactive in landmark-only calls, BA_utils.py:609-612, but still counts in the residual means); 0 (default): BA. */
+int vba_upload_prior(vba_handle h, int window, int n, const double* states_prior, const double* hessian_state);
+int vba_set_prior(vba_handle h, int on);
+
 /* Carried keys (default on).  The trial residual of an accepted LM trial (BA_filtering.py:61-66) is evaluated at
  * exactly the states the next BA call starts from (BA_filtering.py:12-21), so the trial kernel also leaves the |r|
  * keys, their exponent histogram and sum |r| of the next call on the device, and a call that follows another one

@@ -398,14 +398,42 @@ def dynamics_residual(states, cumrot, time_idx, initialize, hop=False):
     return np.concatenate([r, f[:, None]], -1)
 
 
+def prior_factor(states, states_prior, hessian_state, vel_coeff=1.0):
+    """State part of the propagated-covariance prior of ``BA_reg``: ``res_reg_state`` and its Jacobian
+    (``prior_gpu`` BA_utils.py:617-627, 651-655; closed form of the autograd Jacobian).
+
+    r_i = H_i [p_prior - p ; (v_prior - v) vel_coeff]  (6 per pose);  Jp_i [6,9] = d r_i / d(dp, dtheta, dv)
+        = [-H_i[:, :3] | 0 | -vel_coeff H_i[:, 3:]].
+    The rotation part ``res_reg_rot`` = quat_coeff (1 - |q_prior^T G(q_prior) H_rot G(q)^T q|) is analytically the
+    CONSTANT quat_coeff: G(q)^T q = 0 for every q (the columns of the attitude Jacobian are orthogonal to q), so the
+    argument of |.| is rounding noise (~1e-31), its gradient and Hessian (qgradp, Hqp) are rounding noise times
+    H_rot (~1e-14) and are taken as exactly 0 here.  hessian_rot_t therefore does not enter.
+    """
+    d = np.concatenate([states_prior[:, :3] - states[:, :3], (states_prior[:, 7:] - states[:, 7:]) * vel_coeff], -1)
+    r = np.einsum("iab,ib->ia", hessian_state, d)
+    n = states.shape[0]
+    Jp = np.zeros((n, 6, 9))
+    Jp[:, :, 0:3] = -hessian_state[:, :, :3]
+    Jp[:, :, 6:9] = -vel_coeff * hessian_state[:, :, 3:]
+    return r, Jp
+
+
 def ba_iteration(it, states, cumrot, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences,
-                 lamda_init, initialize=False, solver="banded", debug=None, hop=False):
+                 lamda_init, initialize=False, solver="banded", debug=None, hop=False, prior=None):
     """One call of the reference's ``BA`` (BA_filtering.py:4-98) for batch size 1.
 
     hop=True swaps the orbit integrator for the coarse one of the reference's ``predict_gpu`` (BA_utils.py:52-71, 544).
     Arrays carry no batch dimension: states [n,10], cumrot [n,4] (= imu_meas[0,:,-1,6:10]),
     landmarks [m,2], landmarks_xyz [m,3], ii [m], time_idx [n], intrinsics [n,4],
     confidences [m].  Returns (states_new [n,10], lamda_out, last_hessian [9,9], n_trials).
+
+    prior = (states_prior [n,10], hessian_state_t [n,6,6]) turns the call into the reference's ``BA_reg``
+    (BA_filtering.py:100-210) AS WRITTEN: the prior enters the normal equations through Jp^T Jp and -Jp^T r_prior
+    (:146, 157-159, 166); the residual means of the accept test carry 7 prior entries per pose whose last one is the
+    constant quat_coeff of ``prior_gpu`` -- 1 in the initial residual (:121, 163), 100 in every trial because the
+    trial call passes (quat_coeff_prior, vel_coeff) = (1, 100) into (vel_coeff, quat_coeff) (:175) -- and the trial's
+    dynamics residual is evaluated with quat_coeff_prior = 1 instead of quat_coeff = 100 (:172, 174).  In the
+    landmark-only phase the prior is switched off but still contributes 6 zeros per pose to both means (:609-612).
     """
     states = np.asarray(states, dtype=np.float64)
     n = states.shape[0]
@@ -424,7 +452,17 @@ def ba_iteration(it, states, cumrot, landmarks, landmarks_xyz, ii, time_idx, int
         r_pred = np.concatenate([r_orb, f[:, None]], -1)
     bands, rhs = assemble(H, b, 1.0, float(sigma), E, F, r_orb, qgrad, Hd, Hu, Hl, initialize)
     sq = np.sqrt(sigma)
-    init_residual = np.abs(np.concatenate([r_obs.reshape(-1), r_pred.reshape(-1) * sq])).mean()
+    r_prior = np.zeros(0)
+    if prior is not None:
+        states_prior, hessian_state = (np.asarray(a, dtype=np.float64) for a in prior)
+        if initialize:
+            r_prior = np.zeros((n, 6))
+        else:
+            rp, Jp = prior_factor(states, states_prior, hessian_state, vel_coeff=1.0)
+            bands[:, 1] += np.einsum("irc,ird->icd", Jp, Jp)
+            rhs -= np.einsum("irc,ir->ic", Jp, rp)
+            r_prior = np.concatenate([rp, np.full((n, 1), 1.0)], -1)      # quat_coeff_prior = 1
+    init_residual = np.abs(np.concatenate([r_obs.reshape(-1), r_pred.reshape(-1) * sq, r_prior.reshape(-1)])).mean()
     if debug is not None:
         debug.update(est=est, Jg=Jg, r_obs=r_obs, w=w, c_obs=c_obs, wmax=wmax, H=H, b=b, r_pred=r_pred,
                      E=E, F=F, qgrad=qgrad, Hd=Hd, Hu=Hu, Hl=Hl, bands=bands, rhs=rhs,
@@ -440,7 +478,15 @@ def ba_iteration(it, states, cumrot, landmarks, landmarks_xyz, ii, time_idx, int
         est1 = landmark_project(states_new, landmarks_xyz, intrinsics, ii, jacobian=False)
         r_obs1 = (landmarks - est1) * w[:, None]
         r_pred1 = dynamics_residual(states_new, cumrot, time_idx, initialize, hop=hop) * sq
-        residual = np.abs(np.concatenate([r_obs1.reshape(-1), r_pred1.reshape(-1)])).mean()
+        r_prior1 = np.zeros(0)
+        if prior is not None:
+            if initialize:
+                r_prior1 = np.zeros((n, 6))
+            else:
+                r_pred1[:, 6] *= 1.0 / QUAT_COEFF          # predict(..., quat_coeff_prior = 1, ...) in the trial
+                rp1, _ = prior_factor(states_new, states_prior, hessian_state, vel_coeff=1.0)
+                r_prior1 = np.concatenate([rp1, np.full((n, 1), 100.0)], -1)
+        residual = np.abs(np.concatenate([r_obs1.reshape(-1), r_pred1.reshape(-1), r_prior1.reshape(-1)])).mean()
         n_trials += 1
         if debug is not None:
             debug["trials"].append(dict(lam=lam, lam32=lam32, A=A, dpose=dpose, est=est1, residual=residual))

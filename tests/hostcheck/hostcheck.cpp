@@ -69,7 +69,7 @@ void hc_assemble(int n, const double* Hraw, const double* braw, double inv_wmax,
                  const double* rorb, const double* qgrad, const double* Hd, const double* Hu, const double* Hl,
                  double* bands, double* rhs) {
     for (int i = 0; i < n; ++i) {
-        AsmRow R;
+        AsmRow R{};
         R.Hraw = Hraw + 21 * i; R.braw = braw + 6 * i; R.inv_wmax = inv_wmax; R.sigma = sigma;
         const bool dyn = sigma != 0.0;
         R.Phi_i = (dyn && i < n - 1) ? Phi + 36 * i : nullptr;

@@ -829,3 +829,76 @@ def test_carried_keys_in_a_batch_with_stalling_windows(c2):
     for w in range(4):
         a, b = res[False][w], res[True][w]
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2]), w
+
+
+# ------------------------------------------------------------------------------------------------ BA_reg
+@pytest.mark.parametrize("base", ["c1", "c2"])
+@pytest.mark.parametrize("solver", [-1, 0], ids=["default", "sequential"])
+def test_BA_reg_every_call_vs_reference(base, solver):
+    """The reference's ``BA_reg`` (BA_filtering.py:100-210) call by call against fixtures captured from the reference
+    function itself: states, damping, last Hessian block, number of LM trials (lamda exhaustion on most full calls:
+    the trial mean carries the constant 100 per pose), and on three calls the matrix and right-hand side handed to
+    ``torch.linalg.solve``."""
+    from vinsat_amd.engine import BAEngine
+    g, b = load_golden("reg_" + base), load_golden(base)
+    inp = golden_inputs(b)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    e = BAEngine(n, m)
+    e.set_solver(solver)
+    e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
+    e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+    e.upload_prior(g["states_prior"][0], g["hessian_state_t"][0])
+    e.set_prior(True)
+    for k in range(len(g["iters"])):
+        out, lam, hess, ntr, flags = e.iterate(int(g["iters"][k]), bool(g["initialize"][k]), float(g["lamda_in"][k]), g[f"states_in_{k}"][0])
+        assert ntr == g["n_trials"][k] and lam == g["lamda_out"][k], k
+        assert (flags & 1) == (1 if ntr == 9 or (ntr > 1 and lam == 0.1) else 0), k
+        ref = g[f"states_out_{k}"][0]
+        assert rel_err(out, ref) < 1e-8, k
+        assert rel_err(hess, g[f"last_hessian_{k}"][0]) < 1e-9, k
+        if f"A_bands_{k}" in g:
+            A = e.debug("bands").reshape(n, 3, 9, 9).copy()
+            ref_A = g[f"A_bands_{k}"][0].copy()
+            lam32 = float(np.float32(g["lamda_in"][k]))
+            for i in range(n):
+                ref_A[i, 1] -= lam32 * np.eye(9)          # the fixture holds the damped matrix of the first trial
+            assert rel_err(A, ref_A) < 1e-10, k
+            assert rel_err(e.debug("rhs").reshape(-1), g[f"JTr_{k}"][0].reshape(-1)) < 1e-9, k
+    # the same handle goes back to plain BA
+    e.set_prior(False)
+    k = 10
+    out, lam, hess, ntr, flags = e.iterate(int(b["iters"][k]), bool(b["initialize"][k]), float(b["lamda_in"][k]), b[f"states_out_{k-1}"][0])
+    assert rel_err(out, b[f"states_out_{k}"][0]) < 1e-8 and ntr == b["n_trials"][k]
+    e.close()
+
+
+def test_BA_reg_call_surface_and_chained_schedule(c1):
+    """``vinsat_amd.ba.BA_reg`` keeps the reference's positional signature; a 20-call chain on the device
+    (``run_schedule`` with the prior switched on) equals the call-by-call results."""
+    import torch
+    from vinsat_amd.ba import BA_reg
+    from vinsat_amd.engine import BAEngine
+    g, b = load_golden("reg_c1"), c1
+    inp = golden_inputs(b)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    imu = np.zeros(tuple(b["in_imu_shape"]))
+    imu[0, :, -1, 6:10] = inp["cumrot"]
+    k = 12
+    res = BA_reg(int(g["iters"][k]), torch.tensor(g[f"states_in_{k}"]), torch.tensor(b["in_velocities"]), torch.tensor(g["states_prior"]),
+                 torch.tensor(g["velocity_prior"]), torch.tensor(g["hessian_state_t"]), torch.tensor(g["hessian_rot_t"]), torch.tensor(imu),
+                 torch.tensor(b["in_landmarks"]), torch.tensor(b["in_landmarks_xyz"]), inp["ii"], inp["time_idx"],
+                 torch.tensor(b["in_intrinsics"]), torch.tensor(inp["conf"]), None, None, float(g["lamda_in"][k]),
+                 torch.tensor(b["in_poses_gt_eci"]), initialize=False)
+    assert res[0].shape == (1, n, 10) and res[3].shape == (1, 9, 9) and res[2] == g["lamda_out"][k]
+    assert rel_err(res[0][0].numpy(), g[f"states_out_{k}"][0]) < 1e-8
+    e = BAEngine(n, m)
+    e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
+    e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+    e.upload_prior(g["states_prior"][0], g["hessian_state_t"][0])
+    e.set_prior(True)
+    e.set_states(g["states0"][0], 1e-4)
+    trials = e.run_schedule(list(range(20)), [k < 10 for k in range(20)])
+    assert trials >= int(g["n_trials"].sum())       # enqueued trials: re-issued speculative ones count too
+    s, lam, hess, ntr, flags = e.get_states()
+    assert rel_err(s, g["states_out_19"][0]) < 1e-7 and lam == g["lamda_out"][19]
+    e.close()

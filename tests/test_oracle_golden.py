@@ -91,3 +91,21 @@ def test_hop_integrator_matches_reference_function():
     assert rel_err(xh, g["x_pred"]) < 1e-14
     assert rel_err(Phi, g["Phi"]) < 1e-13
     assert np.array_equal(O.propagate_orbit(g["x"], steps, stm=False, hop=True), xh)
+
+
+@pytest.mark.parametrize("base", ["c1", "c2"])
+def test_oracle_reproduces_BA_reg(base):
+    """``BA_reg`` (BA_filtering.py:100-210) as written -- prior blocks, the constant rotation residual with the
+    coefficients the reference passes (1 / 100), the trial's attitude coefficient 1 -- against fixtures made by
+    running the reference's function (tools/gen_golden.py REGC1 REGC2): every call, integer outputs exact."""
+    g, b = load_golden("reg_" + base), load_golden(base)
+    inp = golden_inputs(b)
+    prior = (g["states_prior"][0], g["hessian_state_t"][0])
+    for k in range(len(g["iters"])):
+        out, lam, hess, ntr = O.ba_iteration(int(g["iters"][k]), g[f"states_in_{k}"][0], inp["cumrot"], inp["uv"], inp["xyz"],
+                                             inp["ii"], inp["time_idx"], inp["K"], inp["conf"], float(g["lamda_in"][k]),
+                                             initialize=bool(g["initialize"][k]), prior=prior)
+        assert ntr == g["n_trials"][k] and lam == g["lamda_out"][k], k
+        assert rel_err(out, g[f"states_out_{k}"][0]) < 1e-10, k
+        assert rel_err(hess, g[f"last_hessian_{k}"][0]) < 1e-9, k
+    assert g["n_trials"].max() == 9 and (g["n_trials"][10:] > 1).any()      # the fixture exercises lamda exhaustion

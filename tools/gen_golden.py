@@ -14,7 +14,7 @@ replaced by minimal equivalents before the import:
 ``torch_scatter`` (segment sum / mean, semantics fixed by the call sites
 ``BA_utils.py:1376-1382``) and ``ipdb`` (debugger hook, no-op).
 
-Usage: python tools/gen_golden.py [C1 C2 C3 C4]
+Usage: python tools/gen_golden.py [C1 C2 C3 C4 GAP HOP REGC1 REGC2]
 Outputs are data only (inputs + expected outputs), compressed .npz.
 """
 from __future__ import annotations
@@ -290,6 +290,97 @@ def run_hop(od_pipe, baf):
     print(f"[HOP] n={n} gaps={gaps.tolist()} -> {path}")
 
 
+def run_reg(od_pipe, baf, base="c1", calls=range(20), full=(10, 11, 19)):
+    """Golden vectors of ``BA_reg`` (BA_filtering.py:100-210), the BA call with a propagated-covariance prior.
+
+    Its only caller in the reference cannot run, so the inputs are made here: the window of fixture ``base``, a
+    prior state per pose (the reference's own final estimate plus noise) and random symmetric positive definite
+    prior information matrices.  ``prior_gpu`` (BA_utils.py:604-676) moves its arguments with ``.cuda()``
+    unconditionally; on this CPU-only container that call is made the identity for the duration of the run
+    (``torch.cuda.is_available()`` stays False, so ``BA_reg`` takes its ``predict`` branch).  ``ipdb`` is the
+    no-op of the other fixtures."""
+    g = np.load(os.path.join(REPO, "tests", "golden", f"{base}.npz"))
+    n = g["states0"].shape[1]
+    rng = np.random.default_rng(11)
+    ref = g["states_out_19"][0]
+    prior = ref.copy()
+    prior[:, :3] += rng.normal(0, 0.05, (n, 3))
+    prior[:, 7:] += rng.normal(0, 1e-4, (n, 3))
+    dq = np.concatenate([rng.normal(0, 2e-3, (n, 3)), np.ones((n, 1))], 1)
+    q = ref[:, 3:7]
+    x, y, z, w = q.T
+    dx, dy, dz, dw = dq.T
+    prior[:, 3:7] = np.stack([w * dx + x * dw + y * dz - z * dy, w * dy - x * dz + y * dw + z * dx,
+                              w * dz + x * dy - y * dx + z * dw, w * dw - x * dx - y * dy - z * dz], 1)
+    prior[:, 3:7] /= np.linalg.norm(prior[:, 3:7], axis=1, keepdims=True)
+    Hs = np.zeros((n, 6, 6))
+    Hr = np.zeros((n, 3, 3))
+    for i in range(n):
+        R = rng.normal(0, 1, (6, 6))
+        S = np.diag([2.0, 2.0, 2.0, 20.0, 20.0, 20.0])
+        Hs[i] = S @ (np.eye(6) + 0.2 * R @ R.T / 6) @ S * rng.uniform(0.5, 1.5)
+        R3 = rng.normal(0, 1, (3, 3))
+        Hr[i] = 1e3 * (np.eye(3) + 0.3 * R3 @ R3.T)
+    imu = np.zeros(tuple(g["in_imu_shape"]))
+    imu[0, :, -1, 6:10] = g["in_cumrot_last"]
+    t = lambda a: torch.tensor(np.asarray(a))
+    args = dict(velocities=t(g["in_velocities"]), imu=t(imu), lm=t(g["in_landmarks"]), xyz=t(g["in_landmarks_xyz"]),
+                intr=t(g["in_intrinsics"]), conf=t(g["in_confidences"]), gt=t(g["in_poses_gt_eci"]))
+    ii, time_idx = g["in_ii"], g["in_time_idx"]
+    states_prior, hs, hr = t(prior[None]), t(Hs[None]), t(Hr[None])
+    out = dict(base=np.array(base), states_prior=prior[None], velocity_prior=prior[None, :, 7:], hessian_state_t=Hs[None],
+               hessian_rot_t=Hr[None], states0=g["states0"])
+    solve0 = torch.linalg.solve
+    cuda0 = torch.Tensor.cuda
+    rec = {}
+
+    def solve(A, b, *a, **k):
+        xx = solve0(A, b, *a, **k)
+        rec["n_trials"] += 1
+        if rec["full"]:
+            nn = A.shape[-1] // 9
+            bands, off = tridiag_bands(A.detach().numpy()[0], nn)
+            rec["A"].append(bands)
+            rec["off"].append(off)
+            rec["JTr"].append(b.detach().numpy().copy())
+            rec["dpose"].append(xx.detach().numpy().copy())
+        return xx
+
+    torch.linalg.solve = solve
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        states, lam = t(g["states0"]), 1e-4
+        iters, inits, ntr, lam_in, lam_out, secs = [], [], [], [], [], []
+        for k in calls:
+            init = k < 10
+            rec.update(n_trials=0, full=k in full, A=[], off=[], JTr=[], dpose=[])
+            out[f"states_in_{k}"] = states.detach().numpy().copy()
+            t0 = time.perf_counter()
+            res = baf.BA_reg(k, states.clone(), args["velocities"], states_prior, states_prior[:, :, 7:], hs, hr, args["imu"],
+                             args["lm"], args["xyz"], ii, time_idx, args["intr"], args["conf"], None, None, lam, args["gt"],
+                             initialize=init)
+            secs.append(time.perf_counter() - t0)
+            iters.append(k); inits.append(init); ntr.append(rec["n_trials"]); lam_in.append(lam)
+            states, lam = res[0].detach(), float(res[2])
+            lam_out.append(lam)
+            out[f"states_out_{k}"] = states.numpy().copy()
+            out[f"last_hessian_{k}"] = res[3].detach().numpy().copy()
+            if rec["full"]:
+                out[f"A_bands_{k}"] = np.stack(rec["A"])
+                out[f"A_offband_{k}"] = np.array(rec["off"])
+                out[f"JTr_{k}"] = np.stack(rec["JTr"])
+                out[f"dpose_{k}"] = np.stack(rec["dpose"])
+    finally:
+        torch.linalg.solve = solve0
+        torch.Tensor.cuda = cuda0
+    out.update(iters=np.array(iters), initialize=np.array(inits), n_trials=np.array(ntr), lamda_in=np.array(lam_in),
+               lamda_out=np.array(lam_out), seconds=np.array(secs))
+    path = os.path.join(REPO, "tests", "golden", f"reg_{base}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[REG/{base}] calls={len(iters)} n_trials={ntr} lamda_out={lam_out} {sum(secs):.1f}s -> {path} "
+          f"({os.path.getsize(path)/1e6:.2f} MB)")
+
+
 PLAN = {
     "C1": dict(full_iters=range(20), store_inputs=True, store_states="all"),
     "C2": dict(full_iters=(0, 9, 10, 19), store_inputs=True, store_states="all"),
@@ -305,6 +396,8 @@ def main():
     for name in names:
         if name == "HOP":
             run_hop(od_pipe, baf)
+        elif name.startswith("REG"):
+            run_reg(od_pipe, baf, base=(name[3:] or "C1").lower())
         else:
             run_config(name, od_pipe, baf, **PLAN[name])
 

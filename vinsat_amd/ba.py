@@ -88,6 +88,46 @@ def BA(iter, states, velocities, imu_meas, landmarks, landmarks_xyz, ii, time_id
 BA.last = {}
 
 
+def BA_reg(iter, states, velocities, states_prior, velocity_prior, hessian_state_t, hessian_rot_t, imu_meas, landmarks,
+           landmarks_xyz, ii, time_idx, intrinsics, confidences, Sigma, V, lamda_init, poses_gt_eci, initialize=False,
+           use_reg=True, device=0):
+    """Counterpart of the reference's ``BA_reg`` (``BA_filtering.py:100-210``): ``BA`` with a propagated-covariance
+    prior per pose.  Same positional signature and 4-tuple.  As in the reference ``Sigma``, ``V``, ``use_reg`` and
+    ``velocity_prior`` are not read (the prior velocity is ``states_prior[..., 7:]``, ``BA_utils.py:614``), and
+    ``hessian_rot_t`` has no effect on the result (see ``include/vinsat_ba.h``: the rotation term of ``prior_gpu`` is
+    a constant).  The integrator is the reference's CPU branch (``predict``) unless the engine is switched."""
+    import torch
+    st = _np(states)
+    if st.ndim != 3 or st.shape[0] != 1 or st.shape[2] != 10:
+        raise ValueError("states must be [1, n, 10]")
+    n = st.shape[1]
+    cum = np.ascontiguousarray(_np(imu_meas)[0, :, -1, 6:10])
+    uv = _np(landmarks).reshape(-1, 2)
+    xyz = _np(landmarks_xyz).reshape(-1, 3)
+    K = _np(intrinsics).reshape(-1, 4)
+    conf = _np(confidences).reshape(-1)
+    ii = np.ascontiguousarray(np.asarray(ii), dtype=np.int64).reshape(-1)
+    t = np.ascontiguousarray(np.asarray(time_idx), dtype=np.int64).reshape(-1)
+    sp = _np(states_prior).reshape(-1, 10)
+    Hs = _np(hessian_state_t).reshape(-1, 6, 6)
+    if not (K.shape[0] == n and cum.shape[0] == n and t.shape[0] == n and sp.shape[0] == n and Hs.shape[0] == n):
+        raise ValueError("intrinsics / imu_meas / time_idx / prior must have one row per pose")
+    eng = _engine_for(xyz, uv, conf, ii, K, cum, t, device)
+    eng.upload_prior(sp, Hs)
+    eng.set_prior(True)
+    try:
+        out, lam, hess, n_trials, flags = eng.iterate(int(iter), bool(initialize), float(lamda_init), st[0])
+    finally:
+        eng.set_prior(False)
+    if flags & 1:
+        print("lamda too large")          # reference BA_filtering.py:186
+    BA_reg.last = dict(n_trials=n_trials, flags=flags, ms=eng.last_step_ms())
+    return (torch.from_numpy(out)[None], velocities, lam, torch.from_numpy(hess)[None])
+
+
+BA_reg.last = {}
+
+
 def BA_window(iters, initializes, states, velocities, imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences,
               lamda_init, device=0):
     """The driver's loop ``for iter in range(num_iters): states, ... = BA(iter, states, ...)`` (reference

@@ -57,7 +57,9 @@ struct vba_context {
     double *d_intr = nullptr, *d_cumrot = nullptr;
     WinHead* h_head = nullptr;              // mapped pinned host memory, [W]
     std::vector<int> n, m;
-    std::vector<char> have_obs, have_win, have_state;
+    std::vector<char> have_obs, have_win, have_state, have_prior;
+    bool reg = false;               // BA_reg semantics (per-pose prior) for the following calls
+    double *d_prior_H = nullptr, *d_prior_x = nullptr;
     std::vector<std::vector<int64_t>> perm; // sorted position -> input row
     float last_ms = 0.f;
     bool stepped = false;
@@ -112,6 +114,9 @@ int ready(vba_handle h) {
     for (int w = 0; w < h->W; ++w)
         if (!h->have_obs[w] || !h->have_win[w] || !h->have_state[w])
             return fail(VBA_ESTATE, "window " + std::to_string(w) + " is missing observations, pose constants or states");
+    if (h->reg)
+        for (int w = 0; w < h->W; ++w)
+            if (!h->have_prior[w]) return fail(VBA_ESTATE, "window " + std::to_string(w) + " has no prior (vba_upload_prior)");
     return VBA_OK;
 }
 
@@ -159,6 +164,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     need(W * M * 4); need(W * (N + 1) * 4);
     need(W * N * 10 * 8); need(W * N * 10 * 8); need(W * N * 10 * 8);
     need(W * N * 4 * 8); need(W * N * 4 * 8); need(W * N * 4);
+    need(W * N * 36 * 8); need(W * N * 6 * 8);
     need(W * 2 * M * 8); need(W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * (nblk_obs + nblk_dyn) * 8); need(W * nblk_obs * 8);
     need(W * kSelPasses * kSelBins * 4);
     const size_t per_pose = 21 + 6 + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
@@ -187,6 +193,9 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.intr = h->d_intr = A.take<double>(W * N * 4);
     V.cumrot = h->d_cumrot = A.take<double>(W * N * 4);
     V.steps = h->d_steps = A.take<int>(W * N);
+    V.prior_H = h->d_prior_H = A.take<double>(W * N * 36);
+    V.prior_x = h->d_prior_x = A.take<double>(W * N * 6);
+    V.reg = 0;
     V.absr = A.take<double>(W * 2 * M); V.wraw = A.take<double>(W * M); V.ckeys = A.take<double>(W * 2 * M);
     V.acc_lanes = 8;    // set after construction by vba_set_accumulate_lanes(h, 0)
     V.part_init = A.take<double>(W * nblk_obs); V.part_trial = A.take<double>(W * (nblk_obs + nblk_dyn));
@@ -210,7 +219,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.chunk = 0; V.chunk2 = 0;      // set after construction by vba_set_solver(h, -1)
     {   // every device array a kernel may touch must have been carved: a null here would fault on the GPU
         const void* must[] = {V.n, V.m, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
-                              V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.absr, V.wraw, V.ckeys, V.part_init, V.part_next,
+                              V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.prior_H, V.prior_x, V.absr, V.wraw, V.ckeys, V.part_init, V.part_next,
                               V.part_trial, V.hist, V.Hraw, V.braw, V.xhat, V.Phi, V.rorb, V.fatt, V.qgrad, V.Hd, V.Hu, V.Hl,
                               V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx, V.csol2, V.cL2, V.cR2, V.rx2};
         bool ok = A.used <= A.size;
@@ -233,7 +242,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     }
     h->stream = h->own_stream;
     h->n.assign(W, 0); h->m.assign(W, 0);
-    h->have_obs.assign(W, 0); h->have_win.assign(W, 0); h->have_state.assign(W, 0);
+    h->have_obs.assign(W, 0); h->have_win.assign(W, 0); h->have_state.assign(W, 0); h->have_prior.assign(W, 0);
     h->perm.resize(W);
     vba_set_accumulate_lanes(h, 0);
     vba_set_solver(h, -1);
@@ -358,7 +367,7 @@ int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const do
     h->carry_ok = false;
     if (n < 2 || n > h->n_max) return fail(VBA_EINVAL, "n out of range (need 2 <= n <= n_max)");
     if (m < 1 || m > h->m_max) return fail(VBA_EINVAL, "m out of range (need 1 <= m <= m_max)");
-    if (h->have_win[window] && h->n[window] != n) { h->have_win[window] = 0; h->have_state[window] = 0; }   // a new window: re-upload its constants
+    if (h->have_win[window] && h->n[window] != n) { h->have_win[window] = 0; h->have_state[window] = 0; h->have_prior[window] = 0; }   // a new window: re-upload its constants
     HIPCHK(hipSetDevice(h->device));
     // stable counting sort by pose: the reference's segment sums run in input order inside a pose
     std::vector<int> ptr(n + 1, 0);
@@ -408,7 +417,7 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
     if (!intrinsics || !cumrot_last || !time_idx) return fail(VBA_EINVAL, "null pose-constant array");
     h->carry_ok = false;
     if (n < 2 || n > h->n_max) return fail(VBA_EINVAL, "n out of range (need 2 <= n <= n_max)");
-    if (h->have_obs[window] && h->n[window] != n) { h->have_obs[window] = 0; h->have_state[window] = 0; }   // a new window: re-upload its rows
+    if (h->have_obs[window] && h->n[window] != n) { h->have_obs[window] = 0; h->have_state[window] = 0; h->have_prior[window] = 0; }   // a new window: re-upload its rows
     HIPCHK(hipSetDevice(h->device));
     std::vector<int> steps(n);
     for (int i = 0; i + 1 < n; ++i) {
@@ -425,6 +434,32 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
     HIPCHK(hipMemcpy(h->d_n + window, &n, 4, hipMemcpyHostToDevice));
     h->n[window] = n;
     h->have_win[window] = 1;
+    return VBA_OK;
+}
+
+int vba_upload_prior(vba_handle h, int window, int n, const double* states_prior, const double* hessian_state) {
+    if (int rc = check_window(h, window)) return rc;
+    if (!states_prior || !hessian_state) return fail(VBA_EINVAL, "null prior array");
+    if (!h->have_obs[window] && !h->have_win[window]) return fail(VBA_ESTATE, "upload the window before its prior");
+    if (n != h->n[window]) return fail(VBA_EINVAL, "the prior needs one row per pose of the window");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> xp((size_t)n * 6);
+    for (int i = 0; i < n; ++i) {
+        const double* s = states_prior + (size_t)i * 10;
+        double* o = xp.data() + (size_t)i * 6;
+        o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[7]; o[4] = s[8]; o[5] = s[9];
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t pb = (size_t)window * h->n_max;
+    HIPCHK(hipMemcpy(h->d_prior_x + pb * 6, xp.data(), xp.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_prior_H + pb * 36, hessian_state, (size_t)n * 36 * 8, hipMemcpyHostToDevice));
+    h->have_prior[window] = 1;
+    return VBA_OK;
+}
+
+int vba_set_prior(vba_handle h, int on) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    h->reg = on != 0;
     return VBA_OK;
 }
 
@@ -482,6 +517,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     hipStream_t s = h->stream;
     DevView V = h->V;
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
+    V.reg = h->reg ? 1 : 0;
     V.emit = h->carry_enabled && emit ? 1 : 0;
     V.carry = h->carry_enabled && h->carry_ok ? 1 : 0;
     h->carry_ok = false;
@@ -588,6 +624,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
         V.pack = 1;
         for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
     }
+    V.reg = h->reg ? 1 : 0;
     V.emit = h->carry_enabled ? 1 : 0;
     bool carry = h->carry_enabled && h->carry_ok;
     h->carry_ok = false;
@@ -804,6 +841,7 @@ int64_t vba_sh_partial_count(int n) { return 27 * (int64_t)n + 2; }
 int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, double* d_abs_local) {
     if (!h || !d_abs_local || m_total < 1) return fail(VBA_EINVAL, "bad argument");
     if (h->W != 1) return fail(VBA_EINVAL, "sharded mode uses a single window per handle");
+    if (h->reg) return fail(VBA_EINVAL, "sharded mode does not take a prior (vba_set_prior)");
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;

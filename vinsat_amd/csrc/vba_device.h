@@ -83,6 +83,10 @@ struct DevView {
     const double* intr;             // [4]
     const double* cumrot;           // [4]
     const int* steps;               // RK4 steps to the next pose (last = 1)
+    // BA_reg (BA_filtering.py:100-210): per-pose prior, active when reg != 0 and the call is not landmark-only
+    const double* prior_H;          // [36] hessian_state_t
+    const double* prior_x;          // [6]  prior position, velocity
+    int reg;
     // work
     double* absr;                   // [W][2 m_max]  |r| components
     double* wraw;                   // [W][m_max]    raw robust weight

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_dynamics(DevView V) {
 // batched windows fill the chip anyway: the decode of an entry and the halo slot are amortised over more poses): the per-pose inputs (141 doubles each, plus the
 // transition matrix of the pose in front) are staged once in LDS with coalesced loads, then every thread forms
 // entries from LDS and the block writes its 252 * kAsmPoses outputs contiguously.
-constexpr int kAsmIn = 21 + 6 + 36 + 6 + 3 + 27;     // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl
+constexpr int kAsmIn = 21 + 6 + 36 + 6 + 3 + 27 + 36 + 6;     // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl, prior H, prior r
 
 // 1/x to ~1 ulp (same sequence as the chain solver's)
 __device__ __forceinline__ double asm_fast_rcp(double x) {
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     const StepParams& prm = V.prm;
     const size_t sb = (size_t)w * V.n_max;
     const bool dyn = !prm.initialize;
+    const bool reg = dyn && V.reg;      // BA_reg: the prior is switched off in the landmark-only phase (BA_utils.py:609-612)
     // slot 0 = pose i0-1 (only Phi and rorb are used), slots 1..kAsmPoses = poses i0 ..
     for (int e = threadIdx.x; e < (kAsmPoses + 1) * kAsmIn; e += 256) {
         const int slot = e / kAsmIn, q = e % kAsmIn;
@@ -109,7 +110,17 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
                 else if (q < 72) v = V.qgrad[pb * 3 + (q - 69)];
                 else if (q < 81) v = V.Hd[pb * 9 + (q - 72)];
                 else if (q < 90) v = V.Hu[pb * 9 + (q - 81)];
-                else v = V.Hl[pb * 9 + (q - 90)];
+                else if (q < 99) v = V.Hl[pb * 9 + (q - 90)];
+                else if (reg) {
+                    if (q < 135) v = V.prior_H[pb * 36 + (q - 99)];
+                    else {      // one component of r = H [p_prior - p ; v_prior - v]
+                        const double* Hr = V.prior_H + pb * 36 + (q - 135) * 6;
+                        const double* xp = V.prior_x + pb * 6;
+                        const double* st = V.states + pb * 10;
+                        v = Hr[0] * (xp[0] - st[0]) + Hr[1] * (xp[1] - st[1]) + Hr[2] * (xp[2] - st[2]) +
+                            Hr[3] * (xp[3] - st[7]) + Hr[4] * (xp[4] - st[8]) + Hr[5] * (xp[5] - st[9]);
+                    }
+                }
             }
         }
         in[e] = v;
@@ -142,6 +153,8 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
             R.Hd = me + 72;
             R.Hu = me + 81;
             R.Hl = me + 90;
+            R.prior_H = reg ? me + 99 : nullptr;
+            R.prior_r = me + 135;
             // landmark-only phase: the off-diagonal blocks are zero and nobody reads them (k_solve_blockdiag takes
             // the diagonal block only; vba_debug_fetch reports them as zeros)
             if (is_rhs) V.rhs[(sb + i) * 9 + a] = rhs_entry(R, a);

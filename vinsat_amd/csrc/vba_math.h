@@ -326,7 +326,33 @@ struct AsmRow {
     const double* Hd;         // [9]
     const double* Hu;         // [9]
     const double* Hl;         // [9]
+    // BA_reg: propagated-covariance prior on (position, velocity) of this pose (null without prior)
+    const double* prior_H;    // [36] hessian_state_t, row major
+    const double* prior_r;    // [6]  H [p_prior - p ; v_prior - v]
 };
+
+// Prior of BA_reg (BA_filtering.py:146, 157-159, 166; prior_gpu BA_utils.py:617-627): r = H d, Jp = -H on the
+// position / velocity columns (vel_coeff = 1 as called), so J^T J gains H^T H and the right-hand side H^T r there.
+// The rotation part of prior_gpu is analytically constant (G(q)^T q = 0): no gradient, no Hessian.
+VBA_HD double prior_hth(const double* H, int a, int b) {
+    double s = 0.0;
+    for (int k = 0; k < 6; ++k) s += H[k * 6 + a] * H[k * 6 + b];
+    return s;
+}
+VBA_HD double prior_htr(const double* H, const double* r, int a) {
+    double s = 0.0;
+    for (int k = 0; k < 6; ++k) s += H[k * 6 + a] * r[k];
+    return s;
+}
+// r = H d for one pose: st = its state [10], xp = prior position / velocity [6]
+VBA_HD void prior_residual(const double* H, const double* xp, const double* st, double* r /*[6]*/) {
+    const double d[6] = {xp[0] - st[0], xp[1] - st[1], xp[2] - st[2], xp[3] - st[7], xp[4] - st[8], xp[5] - st[9]};
+    for (int a = 0; a < 6; ++a) {
+        double s = 0.0;
+        for (int b = 0; b < 6; ++b) s += H[a * 6 + b] * d[b];
+        r[a] = s;
+    }
+}
 
 // column c (0..8) of E_i = D Phi_i laid out over [dp, dtheta, dv]: rows r = 0..5; rotation columns are 0.
 VBA_HD double E_entry(const double* Phi, int r, int c) {
@@ -354,6 +380,7 @@ VBA_HD double band_entry(const AsmRow& R, int which, int a, int b) {
             if (R.Phi_im1 && a == b && F_row(a) >= 0) v += (F_val(a) * R.sigma) * F_val(a);
             if (rot) v += R.sigma * R.Hd[3 * (a - 3) + (b - 3)];
         }
+        if (R.prior_H && F_row(a) >= 0 && F_row(b) >= 0) v += prior_hth(R.prior_H, F_row(a), F_row(b));
     } else if (R.sigma != 0.0) {
         if (which == 2 && R.Phi_i) {
             const int r = F_row(b);
@@ -384,6 +411,7 @@ VBA_HD double rhs_entry(const AsmRow& R, int a) {
         }
         if (a >= 3 && a < 6) v -= R.sigma * R.qgrad[a - 3];
     }
+    if (R.prior_H && F_row(a) >= 0) v += prior_htr(R.prior_H, R.prior_r, F_row(a));
     return v;
 }
 

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     } else {
         const int db = blockIdx.x - V.nblk_obs;
         const int i = db * kObsBlock + threadIdx.x;
+        const bool reg = V.reg && !prm.initialize;
         if (!prm.initialize && i < n - 1) {
             const double* st = V.states_new + (sb + i) * 10;
             const double* sn = st + 10;
@@ -387,8 +388,17 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             propagate_gap<false>(x, nullptr, steps, V.hop);
             s = fabs(x[0] - sn[0]) + fabs(x[1] - sn[1]) + fabs(x[2] - sn[2]) +
                 fabs((x[3] - sn[7]) * kVelCoeff) + fabs((x[4] - sn[8]) * kVelCoeff) + fabs((x[5] - sn[9]) * kVelCoeff);
-            s += fabs(attitude_residual(st + 3, V.cumrot + (sb + i) * 4, sn + 3));
+            double att = fabs(attitude_residual(st + 3, V.cumrot + (sb + i) * 4, sn + 3));
+            // BA_reg evaluates the trial's dynamics residual with quat_coeff_prior = 1 where BA passes quat_coeff = 100
+            // (BA_filtering.py:172, 174 vs :63, 65): reproduced as written
+            if (reg) att *= 1.0 / kQuatCoeff;
+            s += att;
             s *= prm.sqrt_sigma;
+        }
+        if (reg && i < n) {     // sum |r_prior| at the trial states (BA_filtering.py:175, 178), not scaled by sigma
+            double r6[6];
+            prior_residual(V.prior_H + (sb + i) * 36, V.prior_x + (sb + i) * 6, V.states_new + (sb + i) * 10, r6);
+            s += fabs(r6[0]) + fabs(r6[1]) + fabs(r6[2]) + fabs(r6[3]) + fabs(r6[4]) + fabs(r6[5]);
         }
     }
     const double t = block_sum<kObsBlock>(s, red);

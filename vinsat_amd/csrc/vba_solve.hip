@@ -1053,7 +1053,7 @@ constexpr int kDecideThreads = 1024;
 constexpr int kDecidePre = 5;       // state elements per thread loaded ahead of the decision (covers 512 poses)
 
 __global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const double* trial_all, int ranks) {
-    __shared__ double red[4][kDecideThreads / 64];
+    __shared__ double red[5][kDecideThreads / 64];
     __shared__ int bstop;
     const int w = blockIdx.x;
     VBA_SKIP_CALL(V, w);
@@ -1068,7 +1068,8 @@ __global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const doub
     const double init_prev = sc.init_residual, lam_in = sc.lamda, lam32 = sc.lam32;
     const double so_carried = sc.next_sum_abs_robs, so_sharded = sc.sum_abs_robs;
     const int n = V.n[w], m = V.m[w];
-    double s_init = 0.0, s_pred = 0.0, s_trial = 0.0, s_next = 0.0;
+    double s_init = 0.0, s_pred = 0.0, s_trial = 0.0, s_next = 0.0, s_prior = 0.0;
+    const bool reg = V.reg && !prm.initialize;
     if (V.m_total == 0 && !V.carry) {
         const double* pi = V.part_init + (size_t)w * V.nblk_obs;
         for (int b = t; b < V.nblk_obs; b += kDecideThreads) s_init += pi[b];
@@ -1078,6 +1079,14 @@ __global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const doub
             const double* ro = V.rorb + (sb + i) * 6;
             const double v = fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]) + fabs(V.fatt[sb + i]);
             if (i < n - 1) s_pred += v;
+        }
+    }
+    if (reg) {      // BA_reg: sum |r_prior| at the input states (BA_filtering.py:163)
+        for (int i = t; i < V.n_max; i += kDecideThreads) {
+            double r6[6];
+            prior_residual(V.prior_H + (sb + i) * 36, V.prior_x + (sb + i) * 6, V.states + (sb + i) * 10, r6);
+            const double v = fabs(r6[0]) + fabs(r6[1]) + fabs(r6[2]) + fabs(r6[3]) + fabs(r6[4]) + fabs(r6[5]);
+            if (i < n) s_prior += v;
         }
     }
     if (ranks == 0) {
@@ -1117,37 +1126,41 @@ __global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const doub
     }
     const double D_last = t < 81 ? V.bands[(sb + n - 1) * 243 + 81 + t] : 0.0;
     {   // four block sums with one pair of barriers
-        const double v4[4] = {wave_sum(s_init), wave_sum(s_pred), wave_sum(s_trial), wave_sum(s_next)};
+        const double v5[5] = {wave_sum(s_init), wave_sum(s_pred), wave_sum(s_trial), wave_sum(s_next), wave_sum(s_prior)};
         if ((t & 63) == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) red[q][t >> 6] = v4[q];
+            for (int q = 0; q < 5; ++q) red[q][t >> 6] = v5[q];
         }
     }
     __syncthreads();
     const double lam = lam_in * 10.0;
     if (t == 0) {
-        double tot[4];
+        double tot[5];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 5; ++q) {
             double a = 0.0;
 #pragma unroll
             for (int i = 0; i < kDecideThreads / 64; ++i) a += red[q][i];
             tot[q] = a;
         }
         const double M = V.m_total ? (double)V.m_total : (double)m;
-        const double denom = 2.0 * M + (prm.initialize ? 6.0 : 7.0) * (double)(n - 1);
+        // BA_reg: the prior adds 7 entries per pose to both means (6 zeros per pose in the landmark-only phase); the 7th
+        // is prior_gpu's constant rotation residual quat_coeff: 1 in the initial residual, 100 in every trial, as the
+        // reference passes its coefficients (BA_filtering.py:121, 163 vs :175, 178-180)
+        const double denom = 2.0 * M + (prm.initialize ? 6.0 : 7.0) * (double)(n - 1) +
+                             (V.reg ? (prm.initialize ? 6.0 : 7.0) * (double)n : 0.0);
         double init_residual = init_prev;
         if (n_trials == 0) {
             // init_residual = mean |[r_obs ; sqrt(Sigma) r_pred]| with UNweighted r_obs (BA_filtering.py:51)
             // carried keys: the same block sums were added up the same way when that trial was accepted
             const double so = V.m_total ? so_sharded : (V.carry ? so_carried : tot[0]);
             const double sp = prm.initialize ? 0.0 : tot[1] * prm.sqrt_sigma;
-            init_residual = (so + sp) / denom;
+            init_residual = (so + sp + (reg ? tot[4] + 1.0 * (double)n : 0.0)) / denom;
             sc.sum_abs_robs = so;
             sc.sum_abs_rpred = sp;
             sc.init_residual = init_residual;
         }
-        const double S = ranks > 0 ? sh_trial : tot[2];
+        const double S = (ranks > 0 ? sh_trial : tot[2]) + (reg ? 100.0 * (double)n : 0.0);
         const double residual = S / denom;
         const bool accept = residual < init_residual;
         const bool stop = accept || lam > 1e4;

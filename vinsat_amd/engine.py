@@ -93,6 +93,17 @@ class BAEngine:
         _lib.check(self.lib.vba_upload_window(self.h, window, n, _p(K), _p(c), t.ctypes.data_as(PI64)), self.lib)
         self.n[window] = n
 
+    def upload_prior(self, states_prior, hessian_state, window=0):
+        """Per-pose prior of the reference's ``BA_reg``: states_prior [n,10], hessian_state_t [n,6,6]."""
+        sp, H = _f64(states_prior).reshape(-1, 10), _f64(hessian_state).reshape(-1, 36)
+        if sp.shape[0] != H.shape[0]:
+            raise ValueError("prior arrays disagree on the number of poses")
+        _lib.check(self.lib.vba_upload_prior(self.h, window, sp.shape[0], _p(sp), _p(H)), self.lib)
+
+    def set_prior(self, on):
+        """True: the following calls are ``BA_reg`` calls (need ``upload_prior``); False (default): ``BA``."""
+        _lib.check(self.lib.vba_set_prior(self.h, int(bool(on))), self.lib)
+
     def set_states(self, states, lamda, window=0):
         s = _f64(states).reshape(-1, 10)
         _lib.check(self.lib.vba_set_states(self.h, window, _p(s), float(lamda)), self.lib)
