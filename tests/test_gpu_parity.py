@@ -902,3 +902,35 @@ def test_BA_reg_call_surface_and_chained_schedule(c1):
     s, lam, hess, ntr, flags = e.get_states()
     assert rel_err(s, g["states_out_19"][0]) < 1e-7 and lam == g["lamda_out"][19]
     e.close()
+
+
+def test_BA_reg_with_a_propagated_prior_vs_oracle(c2):
+    """Prior made the way the reference means it (``propagate_dynamics_cov_init`` from a last Hessian block: information
+    matrices of condition ~1e4 that tighten along the window), sampled at the window's frames, through two full
+    ``BA_reg`` calls on the GPU against the oracle."""
+    from vinsat_amd import prior
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    t = inp["time_idx"]
+    dur = int(t[-1] - t[0])
+    rng = np.random.default_rng(3)
+    omega = rng.normal(0, 1e-3, (dur + 1, 3))
+    ref0 = g["states_out_19"][0]
+    st_t, v_t, Hs_t, Hr_t = prior.propagate_dynamics_cov_init(ref0[0], ref0[0, 7:], g["last_hessian_19"][0], omega, 0, dur, 1)
+    rows = (t - t[0]).astype(int)
+    sp, Hs = st_t[rows], Hs_t[rows]
+    e = BAEngine(n, m)
+    e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
+    e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+    e.upload_prior(sp, Hs)
+    e.set_prior(True)
+    st, lam = g["states_out_9"][0], 1e-4
+    for it in (10, 11):
+        out, lam_g, hess, ntr, flags = e.iterate(it, False, lam, st)
+        ref, lam_o, hess_o, ntr_o = O.ba_iteration(it, st, inp["cumrot"], inp["uv"], inp["xyz"], inp["ii"], inp["time_idx"], inp["K"],
+                                                   inp["conf"], lam, initialize=False, prior=(sp, Hs))
+        assert ntr == ntr_o and lam_g == lam_o
+        assert rel_err(out, ref) < 1e-7 and rel_err(hess, hess_o) < 1e-9
+        st, lam = out, lam_g
+    e.close()

@@ -14,7 +14,7 @@ replaced by minimal equivalents before the import:
 ``torch_scatter`` (segment sum / mean, semantics fixed by the call sites
 ``BA_utils.py:1376-1382``) and ``ipdb`` (debugger hook, no-op).
 
-Usage: python tools/gen_golden.py [C1 C2 C3 C4 GAP HOP REGC1 REGC2]
+Usage: python tools/gen_golden.py [C1 C2 C3 C4 GAP HOP REGC1 REGC2 PRIORPROP]
 Outputs are data only (inputs + expected outputs), compressed .npz.
 """
 from __future__ import annotations
@@ -381,6 +381,26 @@ def run_reg(od_pipe, baf, base="c1", calls=range(20), full=(10, 11, 19)):
           f"({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def run_prior_prop(od_pipe, baf):
+    """Golden vectors of ``propagate_dynamics_cov_init`` (BA_utils.py:227-248) for a batch of one: the last pose,
+    carried velocity and last Hessian block of the C2 fixture pushed over a 7 s gap and a 40 s window."""
+    import BA.BA_utils as bu
+    g = np.load(os.path.join(REPO, "tests", "golden", "c2.npz"))
+    state = g["states_out_19"][0, -1]
+    vel = g["in_velocities"].reshape(-1, 3)[-1]
+    hess = g["last_hessian_19"][0]
+    tdiff, duration = 7, 40
+    rng = np.random.default_rng(5)
+    omega = rng.normal(0, 2e-3, (tdiff + duration, 3)) + np.array([0.0, 1.1e-3, 0.0])
+    out = bu.propagate_dynamics_cov_init(torch.tensor(state[None]), torch.tensor(vel[None]), torch.tensor(hess[None]),
+                                         torch.tensor(omega[None]), tdiff, duration, 1)
+    path = os.path.join(REPO, "tests", "golden", "prior_prop.npz")
+    np.savez_compressed(path, state=state, velocity=vel, hessian=hess, omega=omega, tdiff=tdiff, duration=duration,
+                        states_t=out[0].detach().numpy(), velocities_t=out[1].detach().numpy(),
+                        hessian_state_t=out[2].detach().numpy(), hessian_rot_t=out[3].detach().numpy())
+    print(f"[PRIORPROP] shapes {[tuple(o.shape) for o in out]} -> {path}")
+
+
 PLAN = {
     "C1": dict(full_iters=range(20), store_inputs=True, store_states="all"),
     "C2": dict(full_iters=(0, 9, 10, 19), store_inputs=True, store_states="all"),
@@ -396,6 +416,8 @@ def main():
     for name in names:
         if name == "HOP":
             run_hop(od_pipe, baf)
+        elif name == "PRIORPROP":
+            run_prior_prop(od_pipe, baf)
         elif name.startswith("REG"):
             run_reg(od_pipe, baf, base=(name[3:] or "C1").lower())
         else:
