@@ -28,6 +28,8 @@
 
 namespace vba {
 
+typedef double vf4 __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f64_16x16x4
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const unsigned long long b = f64_bits(v);
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, lane);
@@ -577,53 +579,65 @@ __device__ __forceinline__ void chunk_eliminate(const Src& src, int n, int s, in
         if (t + 1 < len) stash(buf ^ 1);
         __syncthreads();
     }
-    // backward sweep for the 19 right-hand sides: lane q < 19 owns column q
-    const int col = lane < 19 ? lane : 0;
-    double x[9];
+    // Backward sweep for the 19 right-hand sides on the matrix cores: x_t (9 x 19) = Z_t - X_t x_{t+1}.
+    // v_mfma_f64_16x16x4 leaves C[(l >> 4) + 4 i][l & 15] in register i of lane l, and wants B[4 s + (l >> 4)][l & 15] in
+    // k-step s: register s of the previous result IS the B operand of k-step s, so x never moves between steps.  Two
+    // column tiles (columns 0..15, 16..18), three k-steps (rows 9..11 of x stay zero), one LDS read per A element.
+    const int lr = lane & 15, lk = lane >> 4;
+    auto load_Z = [&](int t, int tile) {
+        vf4 z;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) x[r] = Zb[((size_t)(len - 1) * 19 + col) * 9 + r];
-    double* out = csol + (size_t)a0 * 171;
-    if (lane < 19) {
-#pragma unroll
-        for (int r = 0; r < 9; ++r) out[((size_t)(len - 1) * 19 + col) * 9 + r] = x[r];
-    }
-    // contribution of this chunk to its right separator j = b+1:  L_j [yhat_b | Vhat_b | What_b]
-    if (has_sep && lane < 19) {
-        double* cl = cL + (size_t)c * 171 + col;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) v += Cm[r * 9 + k] * x[k];
-            cl[r * 19] = v;
+        for (int i = 0; i < 4; ++i) {
+            const int row = lk + 4 * i, col = 16 * tile + lr;
+            const bool ok = row < 9 && col < 19;
+            const double v = Zb[ok ? ((size_t)t * 19 + col) * 9 + row : 0];
+            z[i] = ok ? v : 0.0;
         }
+        return z;
+    };
+    auto mul_sub = [&](const double* M, double sign, vf4& acc0, vf4& acc1, const vf4& b0, const vf4& b1) {
+        // acc += sign * M (9 x 9, row major in LDS) * b
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const int k = 4 * st + lk;
+            const bool ok = lr < 9 && k < 9;
+            const double m = M[ok ? lr * 9 + k : 0];
+            const double am = ok ? sign * m : 0.0;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b0[st], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b1[st], acc1, 0, 0, 0);
+        }
+    };
+    auto store_cols = [&](double* dst, size_t col_stride, size_t row_stride, const vf4& v0, const vf4& v1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lk + 4 * i;
+            if (row < 9) {
+                dst[(size_t)lr * col_stride + (size_t)row * row_stride] = v0[i];
+                if (lr < 3) dst[(size_t)(16 + lr) * col_stride + (size_t)row * row_stride] = v1[i];
+            }
+        }
+    };
+    double* out = csol + (size_t)a0 * 171;
+    vf4 x0 = load_Z(len - 1, 0), x1 = load_Z(len - 1, 1);
+    store_cols(out + (size_t)(len - 1) * 171, 9, 1, x0, x1);
+    // contribution of this chunk to its right separator j = b+1:  L_j [yhat_b | Vhat_b | What_b]   ([row][19 columns])
+    if (has_sep) {
+        vf4 p0 = {0.0, 0.0, 0.0, 0.0}, p1 = {0.0, 0.0, 0.0, 0.0};
+        mul_sub(Cm, 1.0, p0, p1, x0, x1);
+        store_cols(cL + (size_t)c * 171, 1, 19, p0, p1);
     }
     for (int t = len - 2; t >= 0; --t) {
-        double xn[9];
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            double v = Zb[((size_t)t * 19 + col) * 9 + r];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) v -= Xb[(size_t)t * 81 + r * 9 + j] * x[j];
-            xn[r] = v;
-        }
-#pragma unroll
-        for (int r = 0; r < 9; ++r) x[r] = xn[r];
-        if (lane < 19) {
-#pragma unroll
-            for (int r = 0; r < 9; ++r) out[((size_t)t * 19 + col) * 9 + r] = x[r];
-        }
+        vf4 n0 = load_Z(t, 0), n1 = load_Z(t, 1);
+        mul_sub(Xb + (size_t)t * 81, -1.0, n0, n1, x0, x1);
+        x0 = n0;
+        x1 = n1;
+        store_cols(out + (size_t)t * 171, 9, 1, x0, x1);
     }
     // contribution to the left separator j = a-1:  U_j [yhat_a | Vhat_a | What_a]
-    if (c > 0 && lane < 19) {
-        double* cr = cR + (size_t)(c - 1) * 171 + col;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) v += Cm[81 + r * 9 + k] * x[k];
-            cr[r * 19] = v;
-        }
+    if (c > 0) {
+        vf4 p0 = {0.0, 0.0, 0.0, 0.0}, p1 = {0.0, 0.0, 0.0, 0.0};
+        mul_sub(Cm + 81, 1.0, p0, p1, x0, x1);
+        store_cols(cR + (size_t)(c - 1) * 171, 1, 19, p0, p1);
     }
 }
 
