@@ -591,6 +591,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
             prof[k] = 0.f;
             if (rc_out == VBA_OK) (void)hipEventElapsedTime(&prof[k], ev[k], ev[k + 1]);
         }
+        if (fuse) prof[VBA_K_SOLVE] = 0.f;              // first trial of a landmark-only call: solved inside k_assemble<true>
         if (V.carry) prof[VBA_K_RESIDUAL] = 0.f;        // not launched: the previous trial left the keys behind
         for (int k = 0; k <= VBA_NKERNELS; ++k) (void)hipEventDestroy(ev[k]);
     }
