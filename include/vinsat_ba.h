@@ -81,16 +81,18 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external);
 /* Choice of the block-tridiagonal solve: chunk = 0 one wavefront walks the whole pose chain (work optimal, used
  * when many windows are batched); chunk in [2,60] cuts the chain into chunks of that many poses that are
  * eliminated in parallel plus a reduced system over the separators; chunk = -1 restores the default
- * (0 for >= 128 windows; otherwise chunks of ceil(n_max / 65) poses and the reduced system by cyclic reduction,
- * see vba_set_solver2; two levels of ~n^(1/3) beyond 3900 poses).  With chunk = 0, equal
+ * (0 for >= 128 windows; otherwise chunks of 8 poses -- fewer up to 520 poses, more beyond 1032 -- and the reduced
+ * system by cyclic reduction, see vba_set_solver2; two levels of ~n^(1/3) beyond 7700 poses).  With chunk = 0, equal
  * pose counts and >= 2048 windows three windows share one wavefront; chunk = -2 is chunk = 0 with one window per
  * wavefront, chunk = -3 packs from 3 windows on.  All variants agree to rounding. */
 int vba_set_solver(vba_handle h, int chunk);
 /* Explicit partition: chunks of `chunk` poses; the reduced system over their separators is
  *   chunk2 = 0       walked by one wavefront,
  *   chunk2 in [2,60] cut again into chunks of `chunk2` separators (two levels),
- *   chunk2 = -1      solved by block cyclic reduction inside one workgroup (log2 of the separator count levels, the
- *                    whole reduced system in LDS: at most 64 separators, i.e. chunk >= ceil(n_max / 65)). */
+ *   chunk2 = -1      solved by block cyclic reduction (log2 of the separator count levels): inside one workgroup with
+ *                    the whole reduced system in LDS up to 23 separators; from 24 on the first level runs as its own
+ *                    kernel on one CU per separator pair and the workgroup continues with the halved system
+ *                    (at most 128 separators, i.e. chunk >= ceil(n_max / 129)). */
 int vba_set_solver2(vba_handle h, int chunk, int chunk2);
 
 /* Orbit integrator of the dynamics factor.  0 (default): one-second RK4 steps, the reference's CPU branch `predict`

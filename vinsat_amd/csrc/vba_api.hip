@@ -270,8 +270,8 @@ int vba_set_solver2(vba_handle h, int chunk, int chunk2) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (chunk < 2 || chunk > 60 || (chunk2 != 0 && chunk2 != -1 && (chunk2 < 2 || chunk2 > 60)))
         return fail(VBA_EINVAL, "chunk sizes must be in [2, 60] (chunk2 = 0: single level, -1: cyclic reduction)");
-    if (chunk2 == -1 && (h->n_max + chunk - 1) / chunk - 1 > 64)
-        return fail(VBA_EINVAL, "chunk2 = -1 needs at most 64 separators: chunk >= ceil(n_max / 65)");
+    if (chunk2 == -1 && (h->n_max + chunk - 1) / chunk - 1 > 128)
+        return fail(VBA_EINVAL, "chunk2 = -1 needs at most 128 separators: chunk >= ceil(n_max / 129)");
     h->V.chunk = chunk;
     h->V.chunk2 = chunk2;
     h->no_pack = 0;
@@ -285,7 +285,10 @@ int vba_set_solver(vba_handle h, int chunk) {
         h->no_pack = 0;     // otherwise the chain is cut into chunks and the reduced system over the (at most 64)
                             // separators is solved by cyclic reduction in one workgroup; very long chains: two levels
         if (h->W >= 128 || h->n_max < 8) { h->V.chunk = 0; return VBA_OK; }
-        const int c1 = std::max((h->n_max + 64) / 65, 2);
+        // <= 64 separators while that keeps the chunks at <= 8 poses, else up to 128 (their first reduction level runs
+        // on its own CUs either way, see k_cr_level0)
+        const int c64 = (h->n_max + 64) / 65, c128 = (h->n_max + 128) / 129;
+        const int c1 = std::max(std::min(c64, std::max(8, c128)), 2);
         if (c1 <= 60) {
             h->V.chunk = c1;
             h->V.chunk2 = -1;
@@ -408,6 +411,7 @@ int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const do
     h->n[window] = n;
     h->m[window] = mi;
     h->have_obs[window] = 1;
+    h->V.n_min = *std::min_element(h->n.begin(), h->n.end());
     return VBA_OK;
 }
 
@@ -518,6 +522,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     DevView V = h->V;
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
     V.reg = h->reg ? 1 : 0;
+    V.n_min = *std::min_element(h->n.begin(), h->n.end());
     V.emit = h->carry_enabled && emit ? 1 : 0;
     V.carry = h->carry_enabled && h->carry_ok ? 1 : 0;
     h->carry_ok = false;
@@ -626,6 +631,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
         for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
     }
     V.reg = h->reg ? 1 : 0;
+    V.n_min = *std::min_element(h->n.begin(), h->n.end());
     V.emit = h->carry_enabled ? 1 : 0;
     bool carry = h->carry_enabled && h->carry_ok;
     h->carry_ok = false;

@@ -64,6 +64,7 @@ struct WinHead {
 // Everything a kernel needs; passed by value.  Arrays of W windows use the *_max strides.
 struct DevView {
     int W, n_max;
+    int n_min;                      // smallest pose count over the windows of the handle (host maintained)
     int call;                       // >= 0: this launch belongs to call `call` of a schedule, windows elsewhere in it skip
     int64_t m_max;
     int nblk_obs;                   // ceil(m_max / kObsBlock)

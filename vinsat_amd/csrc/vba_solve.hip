@@ -727,97 +727,41 @@ __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s, int s2) 
 // Schur complements of the (damped, near-SPD) system stay near-SPD, so the unpivoted path applies with the same
 // per-pivot check; PIVOT exchanges rows inside a block as everywhere else.
 // LDS: n1 blocks of 252 doubles [L | D | U | g]; x overwrites g.  n1 <= kCrMax.
-typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int kCrMax = 64;
 constexpr int kCrThreads = 1024;
+constexpr int kCrSplitMin = 24;     // from this many separators on, the first level runs as its own multi-CU kernel
 
-template <bool PIVOT>
-__global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int s) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int w = blockIdx.x;
-    VBA_SKIP_CALL(V, w);
-    WinScalars& sc = V.sc[w];
-    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
-    const int n1 = n_separators(V.n[w], s);
-    if (n1 <= 0 || n1 > kCrMax) return;         // the host only selects this kernel when n1 fits
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = kCrThreads / 64;
-    const size_t sb = (size_t)w * V.n_max;
-    const size_t rb = (size_t)w * V.p_max;
-    const double lam32 = (double)(float)sc.lamda;
-    // The reduced system (see ReducedSource) into LDS.  A wave takes whole blocks and a lane the same (row, column)
-    // of L, D and U, so the index arithmetic is done once per three entries and nothing diverges (walking the 252
-    // entries of a block through the generic source costs more in integer divisions and branches than in loads).
-    {
-        const double* bands = V.bands + sb * 243;
-        const double* rhs = V.rhs + sb * 9;
-        const double* cL = V.cL + rb * 171;
-        const double* cR = V.cR + rb * 171;
-        constexpr int QB = kCrMax / NW;         // blocks per wave: all their loads are issued before the first store
-        const int r0 = lane / 9, c0 = lane % 9, r1 = (lane + 64) / 9, c1 = (lane + 64) % 9;
-        double lv[QB][2], lw[QB][2], rv[QB][2], rw[QB][2], dv[QB][2], gv[QB];
-#pragma unroll
-        for (int u = 0; u < QB; ++u) {
-            const int q = wave + u * NW;
-            const bool in = q < n1;
-            const size_t j = in ? (size_t)(q + 1) * s - 1 : 0;
-            const double* l = cL + (size_t)(in ? q : 0) * 171;
-            const double* r_ = cR + (size_t)(in ? q : 0) * 171;
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int r = it ? r1 : r0, cc = it ? c1 : c0;
-                const bool ok = in && lane + 64 * it < 81;
-                lv[u][it] = ok ? l[r * 19 + 1 + cc] : 0.0;
-                lw[u][it] = ok ? l[r * 19 + 10 + cc] : 0.0;
-                rv[u][it] = ok ? r_[r * 19 + 1 + cc] : 0.0;
-                rw[u][it] = ok ? r_[r * 19 + 10 + cc] : 0.0;
-                dv[u][it] = ok ? bands[j * 243 + 81 + lane + 64 * it] : 0.0;
-            }
-            gv[u] = (in && lane < 9) ? rhs[j * 9 + lane] - l[lane * 19] - r_[lane * 19] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < QB; ++u) {
-            const int q = wave + u * NW;
-            if (q < n1) {
-                double* B = smem + (size_t)q * 252;
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int i = lane + 64 * it;
-                    if (i < 81) {
-                        const int r = it ? r1 : r0, cc = it ? c1 : c0;
-                        B[i] = q == 0 ? 0.0 : -lv[u][it];                       // no neighbour on that side
-                        B[81 + i] = dv[u][it] - lw[u][it] - rv[u][it] + (r == cc ? lam32 : 0.0);
-                        B[162 + i] = q == n1 - 1 ? 0.0 : -rw[u][it];
-                    }
-                }
-                if (lane < 9) B[243 + lane] = gv[u];
-            }
-        }
-    }
-    __syncthreads();
-    bool bad = false;
-    // lane -> column of [D | L | U | g]: one address per lane and role (selecting among loaded VALUES would make every
-    // lane load every alternative)
-    const int grp = lane < 9 ? 0 : (lane < 18 ? 1 : (lane < 27 ? 2 : (lane == 27 ? 3 : 4)));
-    const int c = grp < 3 ? lane - 9 * grp : 0;
-    const int own = grp == 0 ? 81 + c : (grp == 1 ? c : (grp == 2 ? 162 + c : 243));      // first element of the lane's own column
-    const int ownst = grp == 3 ? 1 : 9;                                                    // ... and its stride
-    // fold step (B) operand addresses: they depend on the lane only, not on the block.
-    //   out (9 x 28: new D | L | U | g) = init - [L_j | U_j] (9 x 18) * Bm (18 x 28) on the matrix cores:
+// Per-lane geometry of the two block operations (depends on the lane only, built once per kernel).
+struct CrLanes {
+    // elimination (A): lane -> column of [D | L | U | g]; one address per lane and role (selecting among loaded
+    // VALUES would make every lane load every alternative)
+    int grp, own, ownst;
+    // fold (B) on the matrix cores:
+    //   out (9 x 28: new D | L | U | g) = init - [L_j | U_j] (9 x 18) * Bm (18 x 28),
     //   Bm rows 0..8  = [PU | PL | 0  | Pg] of the left neighbour,  rows 9..17 = [PL | 0 | PU | Pg] of the right one.
-    // v_mfma_f64_16x16x4: lane l feeds A[l & 15][4 s + (l >> 4)] and B[4 s + (l >> 4)][l & 15] of k-step s and
-    // owns C[(l >> 4) + 4 i][l & 15], i = 0..3; two column tiles, five k-steps.  One LDS read per operand
-    // element instead of 162 broadcast reads per lane.
-    const int lr = lane & 15, lk = lane >> 4;
-    int offA[5], offB0[5], offB1[5];        // -1: the operand element is a structural zero
-    bool hiB[5];                            // the B element comes from the right neighbour
+    // v_mfma_f64_16x16x4: lane l feeds A[l & 15][4 s + (l >> 4)] and B[4 s + (l >> 4)][l & 15] of k-step s and owns
+    // C[(l >> 4) + 4 i][l & 15], i = 0..3; two column tiles, five k-steps.  One LDS read per operand element instead
+    // of 162 broadcast reads per lane (the VALU form was LDS-bandwidth-bound).
+    int lr, lk;
+    int offA[5], offB0[5], offB1[5];    // -1: structural zero
+    bool hiB[5];                        // the B element comes from the right neighbour
+};
+
+__device__ __forceinline__ CrLanes cr_lanes(int lane) {
+    CrLanes g;
+    g.grp = lane < 9 ? 0 : (lane < 18 ? 1 : (lane < 27 ? 2 : (lane == 27 ? 3 : 4)));
+    const int c = g.grp < 3 ? lane - 9 * g.grp : 0;
+    g.own = g.grp == 0 ? 81 + c : (g.grp == 1 ? c : (g.grp == 2 ? 162 + c : 243));
+    g.ownst = g.grp == 3 ? 1 : 9;
+    g.lr = lane & 15;
+    g.lk = lane >> 4;
 #pragma unroll
     for (int st = 0; st < 5; ++st) {
-        const int k = 4 * st + lk;
-        offA[st] = (lr < 9 && k < 18) ? (k < 9 ? lr * 9 + k : 162 + lr * 9 + (k - 9)) : -1;
+        const int k = 4 * st + g.lk;
+        g.offA[st] = (g.lr < 9 && k < 18) ? (k < 9 ? g.lr * 9 + k : 162 + g.lr * 9 + (k - 9)) : -1;
         const bool lo = k < 9;
         const int q = lo ? k : k - 9;
-        hiB[st] = !lo;
+        g.hiB[st] = !lo;
         auto bm = [&](int col) -> int {
             if (k >= 18) return -1;
             if (col < 9) return lo ? 162 + q * 9 + col : q * 9 + col;
@@ -826,72 +770,194 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
             if (col == 27) return 243 + q;
             return -1;
         };
-        offB0[st] = bm(lr);
-        offB1[st] = bm(16 + lr);
+        g.offB0[st] = bm(g.lr);
+        g.offB1[st] = bm(16 + g.lr);
     }
+    return g;
+}
+
+// A: [PL | PU | Pg] = D^{-1} [L | U | g] of block B (LDS, 252 doubles), in place; one wave.
+template <bool PIVOT>
+__device__ __forceinline__ void cr_eliminate(double* B, const CrLanes& g, int lane, bool& bad) {
+    double base[9], a[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const double v = B[g.own + r * g.ownst];
+        base[r] = g.grp < 4 ? v : 0.0;
+        a[r] = 0.0;
+    }
+    forward_step<0, 10, PIVOT, false>(nullptr, base, a, lane, bad);
+    if (g.grp >= 1 && g.grp <= 3) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) B[g.own + r * g.ownst] = a[r];
+    }
+}
+
+// B: fold the eliminated neighbours Pm (left) and Pp (right, if has_p) into block Bj, in place; one wave.
+__device__ __forceinline__ void cr_fold(double* Bj, const double* Pm, const double* Pp, bool has_p, const CrLanes& g) {
+    vf4 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = g.lk + 4 * i;
+        const bool rv = row < 9;
+        const double d0 = Bj[(rv && g.lr < 9) ? 81 + row * 9 + g.lr : 0];
+        const double g0 = Bj[(rv && g.lr == 11) ? 243 + row : 0];
+        acc0[i] = (rv && g.lr < 9) ? d0 : 0.0;
+        acc1[i] = (rv && g.lr == 11) ? g0 : 0.0;      // column 27 = 16 + 11
+    }
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const double a0 = Bj[g.offA[st] >= 0 ? g.offA[st] : 0];
+        const double am = g.offA[st] >= 0 ? -a0 : 0.0;
+        const double* P = g.hiB[st] ? Pp : Pm;
+        const bool okp = !g.hiB[st] || has_p;
+        const double v0 = P[g.offB0[st] >= 0 ? g.offB0[st] : 0], v1 = P[g.offB1[st] >= 0 ? g.offB1[st] : 0];
+        const double b0 = (okp && g.offB0[st] >= 0) ? v0 : 0.0, b1 = (okp && g.offB1[st] >= 0) ? v1 : 0.0;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b1, acc1, 0, 0, 0);
+    }
+    // every operand has been read (the LDS operations of a wave execute in order): replace the block
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = g.lk + 4 * i;
+        if (row < 9) {
+            Bj[g.lr < 9 ? 81 + row * 9 + g.lr : row * 9 + (g.lr - 9)] = acc0[i];                   // D | L columns 0..6
+            const int c1 = 16 + g.lr;
+            if (c1 < 18) Bj[row * 9 + (c1 - 9)] = acc1[i];                                          // L columns 7, 8
+            else if (c1 < 27) Bj[162 + row * 9 + (c1 - 18)] = acc1[i];                              // U
+            else if (c1 == 27) Bj[243 + row] = acc1[i];                                             // g
+        }
+    }
+}
+
+// Blocks q0 + u * stride (u < NB) of the reduced system (see ReducedSource) into LDS at dst + u * dst_stride * 252.  A wave takes
+// whole blocks and a lane the same (row, column) of L, D and U, so the index arithmetic is done once per three
+// entries and nothing diverges (walking the 252 entries of a block through the generic source costs more in integer
+// divisions and branches than in loads); all loads are issued before the first store.
+template <int NB>
+__device__ __forceinline__ void cr_fill(const DevView& V, int w, int s, int n1, double lam32, int q0, int stride, double* dst, int dst_stride, int lane) {
+    const size_t sb = (size_t)w * V.n_max, rb = (size_t)w * V.p_max;
+    const double* bands = V.bands + sb * 243;
+    const double* rhs = V.rhs + sb * 9;
+    const double* cL = V.cL + rb * 171;
+    const double* cR = V.cR + rb * 171;
+    const int r0 = lane / 9, c0 = lane % 9, r1 = (lane + 64) / 9, c1 = (lane + 64) % 9;
+    double lv[NB][2], lw[NB][2], rv[NB][2], rw[NB][2], dv[NB][2], gv[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int q = q0 + u * stride;
+        const bool in = q >= 0 && q < n1;
+        const size_t j = in ? (size_t)(q + 1) * s - 1 : 0;
+        const double* l = cL + (size_t)(in ? q : 0) * 171;
+        const double* r_ = cR + (size_t)(in ? q : 0) * 171;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int r = it ? r1 : r0, cc = it ? c1 : c0;
+            const bool ok = in && lane + 64 * it < 81;
+            lv[u][it] = ok ? l[r * 19 + 1 + cc] : 0.0;
+            lw[u][it] = ok ? l[r * 19 + 10 + cc] : 0.0;
+            rv[u][it] = ok ? r_[r * 19 + 1 + cc] : 0.0;
+            rw[u][it] = ok ? r_[r * 19 + 10 + cc] : 0.0;
+            dv[u][it] = ok ? bands[j * 243 + 81 + lane + 64 * it] : 0.0;
+        }
+        gv[u] = (in && lane < 9) ? rhs[j * 9 + lane] - l[lane * 19] - r_[lane * 19] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int q = q0 + u * stride;
+        if (q >= 0 && q < n1) {
+            double* B = dst + (size_t)u * dst_stride * 252;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int i = lane + 64 * it;
+                if (i < 81) {
+                    const int r = it ? r1 : r0, cc = it ? c1 : c0;
+                    B[i] = q == 0 ? 0.0 : -lv[u][it];                       // no neighbour on that side
+                    B[81 + i] = dv[u][it] - lw[u][it] - rv[u][it] + (r == cc ? lam32 : 0.0);
+                    B[162 + i] = q == n1 - 1 ? 0.0 : -rw[u][it];
+                }
+            }
+            if (lane < 9) B[243 + lane] = gv[u];
+        }
+    }
+}
+
+// First level of the cyclic reduction as its own kernel, one wave (one CU) per pair of separators: wave t builds the
+// blocks 2t, 2t+1, 2t+2, eliminates the two even ones (each even block is eliminated by both of its odd neighbours'
+// waves: redundant work instead of communication), folds them into block 2t+1 and leaves
+//   red[t] = the folded block 2t+1 (252 doubles) and  P[2t] = [PL | PU | Pg] of block 2t (for the back substitution)
+// in global memory.  The 31 eliminations + folds of a 62-separator system then run on 31 CUs instead of sharing the
+// four SIMDs of one.
+template <bool PIVOT>
+__global__ __launch_bounds__(64) void k_cr_level0(DevView V, int s) {
+    __shared__ __attribute__((aligned(16))) double blk[3 * 252];
+    const int w = blockIdx.y, t = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n1 = n_separators(V.n[w], s);
+    if (n1 < kCrSplitMin || n1 > 2 * kCrMax || 2 * t >= n1) return;
+    const int lane = threadIdx.x;
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lamda;
+    cr_fill<3>(V, w, s, n1, lam32, 2 * t, 1, blk, 1, lane);
+    __syncthreads();
+    const CrLanes g = cr_lanes(lane);
+    bool bad = false;
+    const bool has_j = 2 * t + 1 < n1, has_p = 2 * t + 2 < n1;
+    cr_eliminate<PIVOT>(blk, g, lane, bad);
+    if (has_p) cr_eliminate<PIVOT>(blk + 504, g, lane, bad);
+    double* P = V.csol2 + (rb + 2 * t) * 171;           // scratch of the two-level driver, unused in this mode
+    for (int e = lane; e < 171; e += 64) P[e] = e < 81 ? blk[e] : blk[81 + e];       // PL | PU | Pg
+    if (has_j) {
+        cr_fold(blk + 252, blk, blk + 504, has_p, g);
+        double* R = V.cL2 + rb * 171 + (size_t)t * 252;
+        for (int e = lane; e < 252; e += 64) R[e] = blk[252 + e];
+    }
+    report_pivot<PIVOT>(bad, sc, lane);
+}
+
+// PRE: the first level has been done by k_cr_level0; this kernel continues with the n1 / 2 folded blocks and finishes
+// with the back substitution of the level-0 blocks.
+template <bool PIVOT, bool PRE>
+__global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int s) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int w = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n0 = n_separators(V.n[w], s);             // separators of the window
+    if (n0 <= 0) return;
+    if (PRE ? (n0 < kCrSplitMin || n0 > 2 * kCrMax) : (n0 >= kCrSplitMin || n0 > kCrMax)) return;   // the other variant's window
+    const int n1 = PRE ? n0 / 2 : n0;                   // blocks of the system solved here
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = kCrThreads / 64;
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lamda;
+    if (PRE) {
+        const double* R = V.cL2 + rb * 171;
+        for (int idx = tid; idx < n1 * 252; idx += kCrThreads) smem[idx] = R[idx];
+    } else {
+        cr_fill<kCrMax / NW>(V, w, s, n1, lam32, wave, NW, smem + (size_t)wave * 252, NW, lane);   // blocks wave, wave + NW, ...
+    }
+    __syncthreads();
+    bool bad = false;
+    const CrLanes g = cr_lanes(lane);
     int h = 1;
     for (;; h <<= 1) {
         const int cnt = n1 / h;                 // active blocks of this level
         const int nel = (cnt + 1) / 2;
 #pragma nounroll
-        for (int t = wave; t < nel; t += NW) {  // A: eliminate the odd-ranked blocks
-            double* B = smem + (size_t)((2 * t + 1) * h - 1) * 252;
-            double base[9], a[9];
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                const double v = B[own + r * ownst];
-                base[r] = grp < 4 ? v : 0.0;
-                a[r] = 0.0;
-            }
-            forward_step<0, 10, PIVOT, false>(nullptr, base, a, lane, bad);
-            if (grp >= 1 && grp <= 3) {
-#pragma unroll
-                for (int r = 0; r < 9; ++r) B[own + r * ownst] = a[r];
-            }
-        }
+        for (int t = wave; t < nel; t += NW)    // A: eliminate the odd-ranked blocks
+            cr_eliminate<PIVOT>(smem + (size_t)((2 * t + 1) * h - 1) * 252, g, lane, bad);
         __syncthreads();
         if (cnt <= 1) break;
         const int nk = cnt / 2;
 #pragma nounroll
         for (int t = wave; t < nk; t += NW) {   // B: fold the eliminated neighbours into the even-ranked blocks
             const int j = (2 * t + 2) * h - 1;
-            double* Bj = smem + (size_t)j * 252;
-            const double* Pm = smem + (size_t)(j - h) * 252;
             const bool has_p = j + h < n1;
-            const double* Pp = smem + (size_t)(has_p ? j + h : j) * 252;
-            d4 acc0, acc1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lk + 4 * i;
-                const bool rv = row < 9;
-                const double d0 = Bj[(rv && lr < 9) ? 81 + row * 9 + lr : 0];
-                const double g0 = Bj[(rv && lr == 11) ? 243 + row : 0];
-                acc0[i] = (rv && lr < 9) ? d0 : 0.0;
-                acc1[i] = (rv && lr == 11) ? g0 : 0.0;      // column 27 = 16 + 11
-            }
-#pragma unroll
-            for (int st = 0; st < 5; ++st) {
-                const double a0 = Bj[offA[st] >= 0 ? offA[st] : 0];
-                const double am = offA[st] >= 0 ? -a0 : 0.0;
-                const double* P = hiB[st] ? Pp : Pm;
-                const bool okp = !hiB[st] || has_p;
-                const double v0 = P[offB0[st] >= 0 ? offB0[st] : 0], v1 = P[offB1[st] >= 0 ? offB1[st] : 0];
-                const double b0 = (okp && offB0[st] >= 0) ? v0 : 0.0, b1 = (okp && offB1[st] >= 0) ? v1 : 0.0;
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b1, acc1, 0, 0, 0);
-            }
-            // every operand has been read (the LDS operations of a wave execute in order): replace the block
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lk + 4 * i;
-                if (row < 9) {
-                    Bj[lr < 9 ? 81 + row * 9 + lr : row * 9 + (lr - 9)] = acc0[i];                   // D | L columns 0..6
-                    const int c1 = 16 + lr;
-                    if (c1 < 18) Bj[row * 9 + (c1 - 9)] = acc1[i];                                      // L columns 7, 8
-                    else if (c1 < 27) Bj[162 + row * 9 + (c1 - 18)] = acc1[i];                          // U
-                    else if (c1 == 27) Bj[243 + row] = acc1[i];                                         // g
-                }
-            }
+            cr_fold(smem + (size_t)j * 252, smem + (size_t)(j - h) * 252, smem + (size_t)(has_p ? j + h : j) * 252, has_p, g);
         }
         __syncthreads();
     }
@@ -918,7 +984,33 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < n1 * 9; idx += kCrThreads) V.rx[rb * 9 + idx] = smem[(size_t)(idx / 9) * 252 + 243 + idx % 9];
+    if (!PRE) {
+        for (int idx = tid; idx < n1 * 9; idx += kCrThreads) V.rx[rb * 9 + idx] = smem[(size_t)(idx / 9) * 252 + 243 + idx % 9];
+    } else {
+        // separators 2t+1 are the blocks solved here; 2t come from the level-0 eliminations:
+        //   x_{2t} = Pg - PL x_{2t-1} - PU x_{2t+1}
+        for (int idx = tid; idx < n0 * 9; idx += kCrThreads) {
+            const int q = idx / 9, r = idx % 9;
+            double x;
+            if (q & 1) {
+                x = smem[(size_t)(q >> 1) * 252 + 243 + r];
+            } else {
+                const double* P = V.csol2 + (rb + q) * 171;
+                x = P[162 + r];
+                if (q >= 1) {
+                    const double* xm = smem + (size_t)((q - 1) >> 1) * 252 + 243;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) x -= P[r * 9 + k] * xm[k];
+                }
+                if (q + 1 < n0) {
+                    const double* xp = smem + (size_t)((q + 1) >> 1) * 252 + 243;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) x -= P[81 + r * 9 + k] * xp[k];
+                }
+            }
+            V.rx[rb * 9 + idx] = x;
+        }
+    }
     report_pivot<PIVOT>(bad, sc, lane);
 }
 
@@ -1238,9 +1330,16 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
         const size_t lds2 = (512 + (size_t)cs2 * 252 + 162) * sizeof(double);
         hipLaunchKernelGGL(k_solve_chunks2<PIVOT>, dim3(P2 > 0 ? P2 : 1, V.W), dim3(64), lds2, s, V, cs, cs2);
     }
-    if (cs2 < 0) {      // one level, the reduced system by cyclic reduction in one workgroup
-        const int n1 = P - 1;
-        if (n1 > 0) hipLaunchKernelGGL(k_solve_reduced_cr<PIVOT>, dim3(V.W), dim3(kCrThreads), (size_t)n1 * 252 * sizeof(double), s, V, cs);
+    if (cs2 < 0) {      // one level, the reduced system by cyclic reduction (every window picks its variant by its own size)
+        const int n0_max = P - 1, n0_min = (V.n_min + cs - 1) / cs - 1;
+        if (n0_max >= kCrSplitMin) {    // first level on its own CUs, the rest in one workgroup
+            hipLaunchKernelGGL(k_cr_level0<PIVOT>, dim3((n0_max + 1) / 2, V.W), dim3(64), 0, s, V, cs);
+            hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, true>), dim3(V.W), dim3(kCrThreads), (size_t)(n0_max / 2) * 252 * sizeof(double), s, V, cs);
+        }
+        if (n0_min < kCrSplitMin && n0_max > 0) {
+            const int nb = n0_max < kCrSplitMin ? n0_max : kCrSplitMin - 1;
+            hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, false>), dim3(V.W), dim3(kCrThreads), (size_t)nb * 252 * sizeof(double), s, V, cs);
+        }
         return;
     }
     hipLaunchKernelGGL(k_solve_reduced<PIVOT>, dim3(V.W), dim3(64), 0, s, V, cs, cs2);
@@ -1255,8 +1354,10 @@ void launch_solve(const DevView& V, int initialize, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         const int cap_cr = kCrMax * 252 * (int)sizeof(double);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
         lds_attr_set = true;
     }
     if (V.pivot != 1) launch_solve_variant<false>(V, initialize, s);
