@@ -177,7 +177,7 @@ def main():
     achieved = alg / (kernels_ms[dom] * 1e-3) / 1e9
     # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_pmc.sh + tools/summarize_pmc.py:
     # 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); a kernel class sums its kernels
-    KERNELS_OF = {"solve": ["k_solve_chunks<false>", "k_solve_reduced_cr<false>", "k_solve_chunks2<false>", "k_solve_reduced<false>",
+    KERNELS_OF = {"solve": ["k_solve_chunks<false>", "k_cr_level0<false>", "k_solve_reduced_cr<false, true>", "k_solve_reduced_cr<false, false>", "k_solve_chunks2<false>", "k_solve_reduced<false>",
                             "k_solve_recover2", "k_solve_recover", "k_solve_blockdiag<false>", "k_solve<false>", "k_solve_packed<false>"],
                   "select": ["k_select_pass<1, false, 8>", "k_select_pass<2, true, 8>", "k_select_final"]}
     traffic = None
@@ -192,14 +192,14 @@ def main():
         except Exception:
             traffic = None
     if dom == "solve":
-        dom_name = "solve: k_solve_chunks + k_solve_reduced_cr + k_solve_recover"
+        dom_name = "solve: k_solve_chunks + k_cr_level0 + k_solve_reduced_cr + k_solve_recover"
     else:
         dom_name = "k_" + dom
     roofline = {"kernel": dom_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
                 "avg_launch_ms": kernels_ms[dom], "launches_timed": len(kern[dom]),
                 "note": "single window = a latency-bound chain (chunks of ceil(n/65) poses eliminated in parallel, then block "
-                        "cyclic reduction over the separators in one workgroup: ~7 + 6 dependent 9x9 block steps); see "
+                        "cyclic reduction over the separators: ~7 + 6 dependent 9x9 block steps); see "
                         "'batched' for the bandwidth regime"}
 
     # ---- the same calls through vba_iterate: states cross PCIe both ways on every call (never the headline value)
