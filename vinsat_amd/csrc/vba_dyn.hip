@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void k_dynamics(DevView V) {
 // batched windows fill the chip anyway: the decode of an entry and the halo slot are amortised over more poses): the per-pose inputs (141 doubles each, plus the
 // transition matrix of the pose in front) are staged once in LDS with coalesced loads, then every thread forms
 // entries from LDS and the block writes its 252 * kAsmPoses outputs contiguously.
-constexpr int kAsmIn = 21 + 6 + 36 + 6 + 3 + 27 + 36 + 6;     // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl, prior H, prior r
+constexpr int kAsmBase = 21 + 6 + 36 + 6 + 3 + 27;    // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl
+constexpr int kAsmPrior = 36 + 6;                     // BA_reg: prior H, prior r
 
 // 1/x to ~1 ulp (same sequence as the chain solver's)
 __device__ __forceinline__ double asm_fast_rcp(double x) {
@@ -83,8 +84,10 @@ __device__ __forceinline__ double asm_fast_rcp(double x) {
 // w_max.  One thread per pose does it in registers straight from the staged inputs, retracts and writes the trial
 // state -- the separate solve and recover launches of that trial are not needed.  The pivots are checked exactly as
 // in the chain solver; a failed check hands the window to the pivoted kernels.
-template <bool FUSE, int kAsmPoses>
+// REG (BA_reg, full phase only): the per-pose prior is staged and added as well.
+template <bool FUSE, int kAsmPoses, bool REG>
 __global__ __launch_bounds__(256) void k_assemble(DevView V) {
+    constexpr int kAsmIn = kAsmBase + (REG ? kAsmPrior : 0);
     __shared__ double in[(kAsmPoses + 1) * kAsmIn];
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     const StepParams& prm = V.prm;
     const size_t sb = (size_t)w * V.n_max;
     const bool dyn = !prm.initialize;
-    const bool reg = dyn && V.reg;      // BA_reg: the prior is switched off in the landmark-only phase (BA_utils.py:609-612)
+    const bool reg = REG;               // the host launches REG only for full-phase BA_reg calls (BA_utils.py:609-612)
     // slot 0 = pose i0-1 (only Phi and rorb are used), slots 1..kAsmPoses = poses i0 ..
     for (int e = threadIdx.x; e < (kAsmPoses + 1) * kAsmIn; e += 256) {
         const int slot = e / kAsmIn, q = e % kAsmIn;
@@ -219,15 +222,18 @@ void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s) {
 #ifndef VBA_ASM_BATCHED
 #define VBA_ASM_BATCHED 16
 #endif
+    const bool reg = V.reg && !V.prm.initialize;
     if (V.W >= 16) {
         constexpr int P = VBA_ASM_BATCHED;
         const dim3 g((V.n_max + P - 1) / P, V.W);
-        if (fuse_init_solve) hipLaunchKernelGGL((k_assemble<true, P>), g, dim3(256), 0, s, V);
-        else hipLaunchKernelGGL((k_assemble<false, P>), g, dim3(256), 0, s, V);
+        if (fuse_init_solve) hipLaunchKernelGGL((k_assemble<true, P, false>), g, dim3(256), 0, s, V);
+        else if (reg) hipLaunchKernelGGL((k_assemble<false, P, true>), g, dim3(256), 0, s, V);
+        else hipLaunchKernelGGL((k_assemble<false, P, false>), g, dim3(256), 0, s, V);
     } else {
         const dim3 g((V.n_max + 3) / 4, V.W);
-        if (fuse_init_solve) hipLaunchKernelGGL((k_assemble<true, 4>), g, dim3(256), 0, s, V);
-        else hipLaunchKernelGGL((k_assemble<false, 4>), g, dim3(256), 0, s, V);
+        if (fuse_init_solve) hipLaunchKernelGGL((k_assemble<true, 4, false>), g, dim3(256), 0, s, V);
+        else if (reg) hipLaunchKernelGGL((k_assemble<false, 4, true>), g, dim3(256), 0, s, V);
+        else hipLaunchKernelGGL((k_assemble<false, 4, false>), g, dim3(256), 0, s, V);
     }
 }
 

@@ -1059,33 +1059,55 @@ __global__ __launch_bounds__(64) void k_solve_recover2(DevView V, int s, int s2)
 
 // x_i for every block of the window (s == 0: dpose already holds the solution, block-diagonal phase), then the
 // retraction (BA_filtering.py:56-60).
-__global__ __launch_bounds__(64) void k_solve_recover(DevView V, int s) {
+__global__ __launch_bounds__(256) void k_solve_recover(DevView V, int s) {
+    // 16 lanes per pose, lane r < 9 forms row r of the step (for a fixed column of csol the nine lanes read nine
+    // consecutive doubles); lane 0 of the group gathers the rows and retracts
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     if (sc.done) return;
     const int n = V.n[w];
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int r = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
     const size_t sb = (size_t)w * V.n_max;
     const size_t rb = (size_t)w * V.p_max;
     bool bad = false;
-    if (i < n) {
-        double d9[9];
+    double v = 0.0;
+    if (i < n && r < 9) {
         if (s == 0) {
-#pragma unroll
-            for (int r = 0; r < 9; ++r) d9[r] = V.dpose[(sb + i) * 9 + r];
+            v = V.dpose[(sb + i) * 9 + r];
         } else {
-            recover_block(i, n, s, V.csol + sb * 171, V.rx + rb * 9, d9);
-        }
-        double o[10];
+            const int c = i / s;
+            const int P = (n + s - 1) / s;
+            const double* xsep = V.rx + rb * 9;
+            if ((c < P - 1) && (i == (c + 1) * s - 1)) {
+                v = xsep[(size_t)c * 9 + r];            // a separator: copied from the reduced solution
+            } else {
+                const double* so = V.csol + (sb + i) * 171;
+                v = so[r];
 #pragma unroll
-        for (int r = 0; r < 9; ++r) { V.dpose[(sb + i) * 9 + r] = d9[r]; bad |= !(fabs(d9[r]) <= 1.79e308); }
+                for (int k = 0; k < 9; ++k) {
+                    const double xl = c > 0 ? xsep[(size_t)(c - 1) * 9 + k] : 0.0;
+                    const double xr = c < P - 1 ? xsep[(size_t)c * 9 + k] : 0.0;
+                    v -= so[(1 + k) * 9 + r] * xl + so[(10 + k) * 9 + r] * xr;
+                }
+            }
+            V.dpose[(sb + i) * 9 + r] = v;
+        }
+        bad = !(fabs(v) <= 1.79e308);
+    }
+    double d9[9];
+    const int base = (threadIdx.x & 63) & ~15;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) d9[q] = __shfl(v, base + q, kWave);
+    if (i < n && r == 0) {
+        double o[10];
         retract(V.states + (sb + i) * 10, d9, o);
 #pragma unroll
-        for (int r = 0; r < 10; ++r) V.states_new[(sb + i) * 10 + r] = o[r];
+        for (int q = 0; q < 10; ++q) V.states_new[(sb + i) * 10 + q] = o[q];
     }
     const unsigned long long anybad = __ballot(bad);
-    if (threadIdx.x == 0 && anybad) atomicOr(&sc.flags, 2u);
+    if ((threadIdx.x & 63) == 0 && anybad) atomicOr(&sc.flags, 2u);
 }
 
 // Landmark-only phase (initialize): the dynamics factor is absent (BA_utils.py:463-466), the system is block
@@ -1363,10 +1385,10 @@ void launch_solve(const DevView& V, int initialize, hipStream_t s) {
     if (V.pivot != 1) launch_solve_variant<false>(V, initialize, s);
     if (V.pivot != 0) launch_solve_variant<true>(V, initialize, s);
     // interiors / retraction: shared by both variants (k_solve and k_solve_packed retract themselves)
-    if (initialize) hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, 0);
+    if (initialize) hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 15) / 16, V.W), dim3(256), 0, s, V, 0);
     else if (V.chunk > 0) {
         if (V.chunk2 > 0) hipLaunchKernelGGL(k_solve_recover2, dim3((V.p_max + 63) / 64, V.W), dim3(64), 0, s, V, V.chunk, V.chunk2);
-        hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 63) / 64, V.W), dim3(64), 0, s, V, V.chunk);
+        hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 15) / 16, V.W), dim3(256), 0, s, V, V.chunk);
     }
 }
 
