@@ -934,3 +934,40 @@ def test_BA_reg_with_a_propagated_prior_vs_oracle(c2):
         assert rel_err(out, ref) < 1e-7 and rel_err(hess, hess_o) < 1e-9
         st, lam = out, lam_g
     e.close()
+
+
+def test_BA_reg_batched_windows_equal_single_window_runs(c2):
+    """Three windows with different priors in one handle (prior on), stepped together through rejected trials and
+    lamda exhaustion, against one handle per window: same bits."""
+    from vinsat_amd.engine import BAEngine
+    g = load_golden("reg_c2")
+    inp = golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    rng = np.random.default_rng(0)
+    priors = []
+    for w in range(3):
+        sp = g["states_prior"][0].copy()
+        sp[:, :3] += rng.normal(0, 0.02 * w, (n, 3))
+        priors.append((sp, g["hessian_state_t"][0] * (1.0 + 0.5 * w)))
+    calls = [(9, True), (10, False), (11, False), (12, False)]
+
+    def run(ws, W):
+        e = BAEngine(n, m, windows=W)
+        e.set_accumulate_lanes(8)
+        for k, w in enumerate(ws):
+            e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n, window=k)
+            e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"], window=k)
+            e.upload_prior(*priors[w], window=k)
+            e.set_states(g["states_in_9"][0], 1e-4, window=k)
+        e.set_prior(True)
+        for it, init in calls:
+            e.step(it, init)
+        out = [e.get_states(window=k) for k in range(W)]
+        e.close()
+        return out
+
+    batch = run([0, 1, 2], 3)
+    for w in range(3):
+        single = run([w], 1)[0]
+        assert np.array_equal(batch[w][0], single[0]) and batch[w][1] == single[1] and batch[w][3] == single[3], w
+    assert max(b[3] for b in batch) > 1
