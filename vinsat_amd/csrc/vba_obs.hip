@@ -236,7 +236,9 @@ __global__ __launch_bounds__(256) void k_select_final(DevView V) {
 #endif
 constexpr int kAccDepth = VBA_ACC_DEPTH;
 
-template <int G>
+// PAIR: a lane takes two consecutive observations per step with 16-byte loads, so that the G lanes of a pose read
+// whole 128-byte lines (G = 8) instead of half lines whose other half is fetched again by the next step.
+template <int G, bool PAIR>
 __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     __shared__ double wmx[4];
     constexpr int PPB = 256 / G;            // poses per block
@@ -279,27 +281,15 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             o.u = V.ou[ob + k]; o.v = V.ov[ob + k]; o.c = V.oconf[ob + k];
             return o;
         };
-        int k = beg + sub;
-        Obs ring[kAccDepth];
-#pragma unroll
-        for (int d = 0; d < kAccDepth; ++d) {
-            ring[d] = Obs{0, 0, 0, 0, 0, 0};
-            if (k + d * G < end) ring[d] = load(k + d * G);
-        }
-        while (k < end) {
-            const int kn = k + G;
-            const Obs cur = ring[0];
-#pragma unroll
-            for (int d = 0; d + 1 < kAccDepth; ++d) ring[d] = ring[d + 1];
-            if (k + kAccDepth * G < end) ring[kAccDepth - 1] = load(k + kAccDepth * G);
+        auto process = [&](double ox_, double oy_, double oz_, double ou_, double ov_, double oc_, int k) {
             double u, v, cam[3], d, J[12];
-            project(pc, cur.x, cur.y, cur.z, u, v, cam, d);
+            project(pc, ox_, oy_, oz_, u, v, cam, d);
             project_jacobian(pc, cam, d, J);
-            const double ru = cur.u - u, rv = cur.v - v;
+            const double ru = ou_ - u, rv = ov_ - v;
             const double wr = robust_weight_raw(rp, ru, rv);
             V.wraw[ob + k] = wr;
             wmax_l = fmax(wmax_l, wr);
-            const double wc = wr * cur.c;
+            const double wc = wr * oc_;
             int q = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -308,7 +298,45 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
                 for (int b = a; b < 6; ++b) { acc[q] += ja * J[b] + jb * J[6 + b]; ++q; }
                 acc[21 + a] += ja * ru + jb * rv;
             }
-            k = kn;
+        };
+        if (PAIR) {
+            struct alignas(8) D2 { double a, b; };
+            struct Obs2 { D2 x, y, z, u, v, c; };
+            auto load2 = [&](int k) {       // observations k, k + 1 (the second may belong to the next pose: masked below)
+                Obs2 o;
+                o.x = *reinterpret_cast<const D2*>(V.ox + ob + k); o.y = *reinterpret_cast<const D2*>(V.oy + ob + k);
+                o.z = *reinterpret_cast<const D2*>(V.oz + ob + k); o.u = *reinterpret_cast<const D2*>(V.ou + ob + k);
+                o.v = *reinterpret_cast<const D2*>(V.ov + ob + k); o.c = *reinterpret_cast<const D2*>(V.oconf + ob + k);
+                return o;
+            };
+            int k = beg + 2 * sub;
+            Obs2 nxt{};
+            if (k < end) nxt = load2(k);
+            while (k < end) {
+                const int kn = k + 2 * G;
+                const Obs2 cur = nxt;
+                if (kn < end) nxt = load2(kn);
+                process(cur.x.a, cur.y.a, cur.z.a, cur.u.a, cur.v.a, cur.c.a, k);
+                if (k + 1 < end) process(cur.x.b, cur.y.b, cur.z.b, cur.u.b, cur.v.b, cur.c.b, k + 1);
+                k = kn;
+            }
+        } else {
+            int k = beg + sub;
+            Obs ring[kAccDepth];
+#pragma unroll
+            for (int d = 0; d < kAccDepth; ++d) {
+                ring[d] = Obs{0, 0, 0, 0, 0, 0};
+                if (k + d * G < end) ring[d] = load(k + d * G);
+            }
+            while (k < end) {
+                const int kn = k + G;
+                const Obs cur = ring[0];
+#pragma unroll
+                for (int d = 0; d + 1 < kAccDepth; ++d) ring[d] = ring[d + 1];
+                if (k + kAccDepth * G < end) ring[kAccDepth - 1] = load(k + kAccDepth * G);
+                process(cur.x, cur.y, cur.z, cur.u, cur.v, cur.c, k);
+                k = kn;
+            }
         }
     }
 #pragma unroll
@@ -494,12 +522,16 @@ void launch_obs_accumulate(const DevView& V, hipStream_t s) {
     const int G = V.acc_lanes;
     const int nb = (V.n_max * G + 255) / 256;
     const dim3 g(nb, V.W), b(256);
+#ifndef VBA_ACC_PAIR
+#define VBA_ACC_PAIR 1
+#endif
+    constexpr bool kPair = VBA_ACC_PAIR != 0;
     switch (G) {
-        case 4: hipLaunchKernelGGL(k_obs_accumulate<4>, g, b, 0, s, V); break;
-        case 8: hipLaunchKernelGGL(k_obs_accumulate<8>, g, b, 0, s, V); break;
-        case 16: hipLaunchKernelGGL(k_obs_accumulate<16>, g, b, 0, s, V); break;
-        case 32: hipLaunchKernelGGL(k_obs_accumulate<32>, g, b, 0, s, V); break;
-        default: hipLaunchKernelGGL(k_obs_accumulate<64>, g, b, 0, s, V); break;
+        case 4: hipLaunchKernelGGL((k_obs_accumulate<4, kPair>), g, b, 0, s, V); break;
+        case 8: hipLaunchKernelGGL((k_obs_accumulate<8, kPair>), g, b, 0, s, V); break;
+        case 16: hipLaunchKernelGGL((k_obs_accumulate<16, false>), g, b, 0, s, V); break;
+        case 32: hipLaunchKernelGGL((k_obs_accumulate<32, false>), g, b, 0, s, V); break;
+        default: hipLaunchKernelGGL((k_obs_accumulate<64, false>), g, b, 0, s, V); break;
     }
 }
 
