@@ -971,3 +971,41 @@ def test_BA_reg_batched_windows_equal_single_window_runs(c2):
         single = run([w], 1)[0]
         assert np.array_equal(batch[w][0], single[0]) and batch[w][1] == single[1] and batch[w][3] == single[3], w
     assert max(b[3] for b in batch) > 1
+
+
+@pytest.mark.parametrize("chunk", [-1, 3, 2])
+def test_windows_of_different_length_pick_their_own_reduction_variant(chunk):
+    """Three windows of 100, 60 and 20 poses in one handle: with chunks of 3 their separator counts (33, 19, 6) fall on
+    both sides of the size from which the first cyclic-reduction level runs as its own kernel, so every solve kernel of
+    the family is launched and each window must be taken by exactly one.  Against single-window handles, bit for bit."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    wins = []
+    for k, npose in enumerate((100, 60, 20)):
+        det, orb = synth.make_sequence(synth.WindowConfig(f"w{k}", npose, 30, 5), seed=40 + k)
+        wins.append(od_pipe.prepare_window(det, orb))
+    n_max = max(w.time_idx.size for w in wins)
+    m_max = max(w.ii.size for w in wins)
+    sched = [(9, True), (10, False), (11, False), (14, False)]
+
+    def run(idx):
+        e = BAEngine(n_max, m_max, windows=len(idx))
+        e.set_accumulate_lanes(8)
+        if chunk > 0:
+            e.set_solver(chunk, -1)
+        for k, i in enumerate(idx):
+            w = wins[i]
+            e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, w.time_idx.size, window=k)
+            e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx, window=k)
+            e.set_states(od_pipe.initial_guess(w, seed=i), 1e-4, window=k)
+        for it, init in sched:
+            e.step(it, init)
+        out = [e.get_states(window=k) for k in range(len(idx))]
+        e.close()
+        return out
+
+    batch = run([0, 1, 2])
+    for i in range(3):
+        single = run([i])[0]
+        assert np.array_equal(batch[i][0], single[0]) and batch[i][1] == single[1], i
+        assert np.isfinite(batch[i][0]).all()
