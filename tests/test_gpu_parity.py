@@ -642,6 +642,7 @@ def test_run_schedule_equals_step_by_step(c2):
     for w in range(4):
         s, lam, hess, ntr, flags = e.get_states(window=w)
         assert np.array_equal(s, ref[w][0]) and lam == ref[w][1] and np.array_equal(hess, ref[w][2]), w
+        assert ntr == ref[w][3] and flags == ref[w][4], w     # a window stalled at a later call than another one must not run that call twice
     assert rel_err(e.get_states(window=0)[0], g["states_out_19"][0]) < 1e-7
     # a second run on the same handle (state of the call counters is reset)
     for w in range(4):

@@ -670,32 +670,41 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
         }
         HIPCHK(hipGetLastError());
         if (int rc = read_heads(h)) return rc;
-        int minc = ncalls;
-        for (int w = 0; w < h->W; ++w) minc = std::min(minc, (int)head(h, w)->call_idx);
         trials += (long)(ncalls - next);
-        if (minc >= ncalls) break;
-        // call `minc` is unfinished for at least one window: finish it with the ordinary LM loop
-        V.call = minc;
-        V.pivot = h->pivot_mode;
-        V.carry = call_carry[minc];
-        fill_params(V.prm, iters[minc], inits[minc]);
-        for (int trial = 0; trial < 24; ++trial) {
-            bool repeat = false, all = true;
-            for (int w = 0; w < h->W; ++w) {
-                if (head(h, w)->call_idx != minc) continue;
-                all = false;
-                repeat = repeat || (head(h, w)->flags & 8u);
-            }
-            if (all) break;
-            if (repeat && V.pivot == 0) { V.pivot = 2; h->fallbacks++; }
-            launch_solve(V, inits[minc], s);
-            launch_trial(V, s);
-            launch_decide(V, nullptr, 0, s);
-            HIPCHK(hipGetLastError());
-            if (int rc = read_heads(h)) return rc;
-            ++trials;
+        // After a pass over calls next .. ncalls-1 every window whose counter is below ncalls is stalled AT that call
+        // (its first trial was rejected or its unpivoted solve failed the check).  Every stalled call is finished with
+        // the ordinary LM loop -- each one, not only the earliest: a window left at a later call would otherwise run
+        // that call again from its start when the chain is re-issued.
+        std::vector<int> stalled;
+        for (int w = 0; w < h->W; ++w) {
+            const int c = (int)head(h, w)->call_idx;
+            if (c < ncalls && std::find(stalled.begin(), stalled.end(), c) == stalled.end()) stalled.push_back(c);
         }
-        next = minc + 1;
+        if (stalled.empty()) break;
+        std::sort(stalled.begin(), stalled.end());
+        for (int sc_call : stalled) {
+            V.call = sc_call;
+            V.pivot = h->pivot_mode;
+            V.carry = call_carry[sc_call];
+            fill_params(V.prm, iters[sc_call], inits[sc_call]);
+            for (int trial = 0; trial < 24; ++trial) {
+                bool repeat = false, all = true;
+                for (int w = 0; w < h->W; ++w) {
+                    if (head(h, w)->call_idx != sc_call) continue;
+                    all = false;
+                    repeat = repeat || (head(h, w)->flags & 8u);
+                }
+                if (all) break;
+                if (repeat && V.pivot == 0) { V.pivot = 2; h->fallbacks++; }
+                launch_solve(V, inits[sc_call], s);
+                launch_trial(V, s);
+                launch_decide(V, nullptr, 0, s);
+                HIPCHK(hipGetLastError());
+                if (int rc = read_heads(h)) return rc;
+                ++trials;
+            }
+        }
+        next = stalled.front() + 1;
     }
     if (trials_total) *trials_total = (int)trials;
     h->carry_ok = h->carry_enabled;

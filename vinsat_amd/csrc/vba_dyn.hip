@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     VBA_SKIP_CALL(V, w);
     const int n = V.n[w];
     const int i0 = blockIdx.x * kAsmPoses;
+    if (blockIdx.x == 0) {      // the select is over (its last reader was k_obs_accumulate): clean histograms for the next call
+        unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
+        for (int b = threadIdx.x; b < 3 * kSelBins; b += 256) hist[b] = 0u;
+    }
     if (i0 >= n) return;
     const StepParams& prm = V.prm;
     const size_t sb = (size_t)w * V.n_max;

@@ -4,7 +4,7 @@
 //   k_select_pass<P>   A3a: exact lower median of the 2m keys by most-significant-digit radix select:
 //                      digit 0 (exponent) is histogrammed inside k_obs_residual, digits 1 and 2 read the keys
 //                      once each, the second of them compacting the (few) keys that match the 32 known bits,
-//                      and k_select_final finishes digits 3..5 on that short list in one block
+//                      and select_finish (prologue of k_obs_accumulate) finishes digits 3..5 on that short list
 //   k_obs_accumulate<G> A2 + A3a + A3b: Jacobian, robust weight, per-pose 6x6 / 6 accumulation (G lanes per pose)
 //   k_trial            A8: weighted trial residuals (observations) and dynamics residuals at the trial states
 //   k_debug_project    recompute est / Jacobian at the step's input states for vba_debug_fetch
@@ -17,7 +17,7 @@
 namespace vba {
 
 // Per-step state that must be clean before the first kernel touches it:
-//   * radix histograms: zeroed by k_select_final of the PREVIOUS step (and by the allocation), because the first
+//   * radix histograms: zeroed by k_assemble of the PREVIOUS step (and by the allocation), because the first
 //     kernel of a step already accumulates digit 0 into them;
 //   * scalars (done, n_trials, flags, max weight, list length): reset by thread 0 of block 0 of k_obs_residual,
 //     no later block or kernel of the step reads them before the next kernel boundary;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
                     base = __shfl(base, leader, kWave);
                     if (match) {
                         const unsigned off = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-                        // the list has room for 2 m_max keys; if more match (massive ties) k_select_final sees
+                        // the list has room for 2 m_max keys; if more match (massive ties) select_finish sees
                         // sel_cnt > capacity and rescans the full key array instead
                         if ((int64_t)base + off < 2 * V.m_max) V.ckeys[2 * (size_t)w * V.m_max + base + off] = bits_f64(key);
                     }
@@ -156,18 +156,17 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     }
 }
 
-// Finishes the select on the compacted list (keys whose top 32 bits are known to match): digits 3, 4, 5 with a
-// block-local histogram each, then publishes c_obs.  One block per window.
-__global__ __launch_bounds__(256) void k_select_final(DevView V) {
-    __shared__ unsigned lh[kSelBins];
-    __shared__ unsigned lds_u[260];
-    __shared__ unsigned long long skeys[1024];
-    const int w = blockIdx.x;
-    VBA_SKIP_CALL(V, w);
-    WinScalars& sc = V.sc[w];
-    unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
-    // latency chain of one block: the list length, the wanted rank and the first 1024 list entries are loaded together
-    // (the entries speculatively: the list is almost always that short)
+// Finishes the select on the compacted list (keys whose top 32 bits are known to match): returns the lower median
+// c_obs to every thread of the (256-thread) block.  It is the prologue of k_obs_accumulate -- every block of a window
+// redoes it (a handful of keys: rank by counting) instead of one more single-block kernel on the critical path; long
+// lists (massive ties) take digits 3, 4, 5 with a block-local histogram each, the full key array if the list
+// overflowed.  The histograms it reads are cleared afterwards by k_assemble.
+__device__ __forceinline__ double select_finish(const DevView& V, int w, unsigned* lh /*[kSelBins]*/, unsigned* lds_u /*[260]*/,
+                                                unsigned long long* skeys /*[1024] + 1*/) {
+    const WinScalars& sc = V.sc[w];
+    const unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
+    // the list length, the wanted rank and the first 1024 list entries are loaded together (the entries
+    // speculatively: the list is almost always that short)
     unsigned cnt = sc.sel_cnt;
     const long long want = sc.sel_rank[2];
     const double* ck = V.ckeys + 2 * (size_t)w * V.m_max;
@@ -178,9 +177,8 @@ __global__ __launch_bounds__(256) void k_select_final(DevView V) {
         pre[j] = (int64_t)q < 2 * V.m_max ? f64_bits(ck[q]) : 0ull;
     }
     if (cnt <= 1024u) {
-        // usual case, a handful of candidates: every key of the list matches the 21 known bits and the wanted key is
-        // the one of rank sel_rank[2] among them -- rank each key by counting (ties broken by position)
-        for (int b = threadIdx.x; b < 3 * kSelBins; b += 256) hist[b] = 0u;     // clean for the next step
+        // every key of the list matches the 21 known bits and the wanted key is the one of rank sel_rank[2] among
+        // them -- rank each key by counting (ties broken by position)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned q = threadIdx.x + 256u * j;
@@ -194,36 +192,35 @@ __global__ __launch_bounds__(256) void k_select_final(DevView V) {
                 const unsigned long long o = skeys[j];
                 below += (o < key) || (o == key && j < q);
             }
-            if (below == want) sc.c_obs = bits_f64(key);
+            if (below == want) skeys[1024] = key;
         }
-        return;
-    } else {
-        if ((int64_t)cnt > 2 * V.m_max) {       // list overflowed: fall back to the full key array
-            ck = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
-            cnt = (unsigned)(V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w]);
-        }
-        unsigned long long prefix;
-        long long rank;
-        select_resolve(hist + 2 * kSelBins, 1 << sel_width(2), sel_width(2), sc.sel_prefix[2], sc.sel_rank[2], prefix, rank, lds_u);
-#pragma unroll
-        for (int P = 3; P < 6; ++P) {
-            const int nbins = 1 << sel_width(P);
-            for (int b = threadIdx.x; b < kSelBins; b += 256) lh[b] = 0u;
-            __syncthreads();
-            for (unsigned q = threadIdx.x; q < cnt; q += 256) {
-                const unsigned long long key = f64_bits(ck[q]);
-                if ((key >> sel_shift(P - 1)) == prefix) atomicAdd(&lh[(unsigned)(key >> sel_shift(P)) & (nbins - 1)], 1u);
-            }
-            __syncthreads();
-            unsigned long long np;
-            long long nr;
-            select_resolve(lh, nbins, sel_width(P), prefix, rank, np, nr, lds_u);
-            prefix = np;
-            rank = nr;
-        }
-        if (threadIdx.x == 0) sc.c_obs = bits_f64(prefix);
+        __syncthreads();
+        return bits_f64(skeys[1024]);
     }
-    for (int b = threadIdx.x; b < 3 * kSelBins; b += 256) hist[b] = 0u;     // clean for the next step
+    if ((int64_t)cnt > 2 * V.m_max) {       // list overflowed: fall back to the full key array
+        ck = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
+        cnt = (unsigned)(V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w]);
+    }
+    unsigned long long prefix;
+    long long rank;
+    select_resolve(hist + 2 * kSelBins, 1 << sel_width(2), sel_width(2), sc.sel_prefix[2], sc.sel_rank[2], prefix, rank, lds_u);
+#pragma unroll
+    for (int P = 3; P < 6; ++P) {
+        const int nbins = 1 << sel_width(P);
+        for (int b = threadIdx.x; b < kSelBins; b += 256) lh[b] = 0u;
+        __syncthreads();
+        for (unsigned q = threadIdx.x; q < cnt; q += 256) {
+            const unsigned long long key = f64_bits(ck[q]);
+            if ((key >> sel_shift(P - 1)) == prefix) atomicAdd(&lh[(unsigned)(key >> sel_shift(P)) & (nbins - 1)], 1u);
+        }
+        __syncthreads();
+        unsigned long long np;
+        long long nr;
+        select_resolve(lh, nbins, sel_width(P), prefix, rank, np, nr, lds_u);
+        prefix = np;
+        rank = nr;
+    }
+    return bits_f64(prefix);
 }
 
 // ---------------------------------------------------------------------------------------------- A2 + A3
@@ -248,8 +245,12 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     if (blockIdx.x * PPB >= n) return;
     WinScalars& sc = V.sc[w];
     const StepParams& prm = V.prm;
+    __shared__ unsigned sel_lh[kSelBins];
+    __shared__ unsigned sel_u[260];
+    __shared__ unsigned long long sel_keys[1025];
     RobustParams rp;
-    rp.c = sc.c_obs;
+    rp.c = select_finish(V, w, sel_lh, sel_u, sel_keys);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc.c_obs = rp.c;      // for the record (vba_debug_fetch)
     rp.inv_c = 1.0 / rp.c;
     rp.inv_c2 = 1.0 / (rp.c * rp.c);
     rp.am2 = prm.am2;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 // blocks [0, nblk_obs): sum |w (uv - est')| over the observations (BA_filtering.py:61, 66);
 // blocks [nblk_obs, nblk_obs + nblk_dyn): sqrt(sigma) sum |r_pred'| over the pose edges (BA_filtering.py:65, 67).
 // EMIT: the observation blocks also write the |r| keys, their exponent histogram (select digit 0, zeroed by this
-// call's k_select_final) and the block sums of |r| at the trial states -- the input of the next call if this trial
+// call's k_assemble) and the block sums of |r| at the trial states -- the input of the next call if this trial
 // is accepted (k_decide clears the histogram again if it is not).
 template <bool EMIT>
 __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
@@ -515,7 +516,6 @@ void launch_select(const DevView& V, hipStream_t s) {
         hipLaunchKernelGGL((k_select_pass<1, false, kSelItems>), g, b, 0, s, V);
         hipLaunchKernelGGL((k_select_pass<2, true, kSelItems>), g, b, 0, s, V);
     }
-    hipLaunchKernelGGL(k_select_final, dim3(V.W), dim3(256), 0, s, V);
 }
 
 void launch_obs_accumulate(const DevView& V, hipStream_t s) {
