@@ -179,7 +179,7 @@ def main():
     # 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); a kernel class sums its kernels
     KERNELS_OF = {"solve": ["k_solve_chunks<false>", "k_cr_level0<false>", "k_solve_reduced_cr<false, true>", "k_solve_reduced_cr<false, false>", "k_solve_chunks2<false>", "k_solve_reduced<false>",
                             "k_solve_recover2", "k_solve_recover", "k_solve_blockdiag<false>", "k_solve<false>", "k_solve_packed<false>"],
-                  "select": ["k_select_pass<1, false, 8>", "k_select_pass<2, true, 8>", "k_select_final"]}
+                  "select": ["k_select_pass<1, false, 8>", "k_select_pass<2, true, 8>"]}
     traffic = None
     tpath = os.path.join(ROOT, "profiles", f"{args.profile_tag}_w1_traffic.json")
     if os.path.exists(tpath):
