@@ -238,6 +238,9 @@ constexpr int kAccDepth = VBA_ACC_DEPTH;
 template <int G, bool PAIR>
 __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     __shared__ double wmx[4];
+    __shared__ unsigned sel_lh[kSelBins];
+    __shared__ unsigned sel_u[260];
+    __shared__ unsigned long long sel_keys[1025];
     constexpr int PPB = 256 / G;            // poses per block
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
@@ -245,9 +248,52 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     if (blockIdx.x * PPB >= n) return;
     WinScalars& sc = V.sc[w];
     const StepParams& prm = V.prm;
-    __shared__ unsigned sel_lh[kSelBins];
-    __shared__ unsigned sel_u[260];
-    __shared__ unsigned long long sel_keys[1025];
+    const int sub = threadIdx.x % G;
+    const int i = blockIdx.x * PPB + threadIdx.x / G;
+    const size_t pb = (size_t)w * V.n_max + (i < n ? i : 0);
+    const size_t ob = (size_t)w * V.m_max;
+
+    struct Obs { double x, y, z, u, v, c; };
+    struct alignas(8) D2 { double a, b; };
+    struct Obs2 { D2 x, y, z, u, v, c; };
+    auto load = [&](int k) {
+        Obs o;
+        o.x = V.ox[ob + k]; o.y = V.oy[ob + k]; o.z = V.oz[ob + k];
+        o.u = V.ou[ob + k]; o.v = V.ov[ob + k]; o.c = V.oconf[ob + k];
+        return o;
+    };
+    auto load2 = [&](int k) {       // observations k, k + 1 (the second may belong to the next pose: masked below)
+        Obs2 o;
+        o.x = *reinterpret_cast<const D2*>(V.ox + ob + k); o.y = *reinterpret_cast<const D2*>(V.oy + ob + k);
+        o.z = *reinterpret_cast<const D2*>(V.oz + ob + k); o.u = *reinterpret_cast<const D2*>(V.ou + ob + k);
+        o.v = *reinterpret_cast<const D2*>(V.ov + ob + k); o.c = *reinterpret_cast<const D2*>(V.oconf + ob + k);
+        return o;
+    };
+
+    // Phase 1: everything that does not need the median is started first (the pose's camera, its row range and the
+    // first observations), so that those round trips overlap with the select finish below.
+    // Software pipelined: the loads of the next observations are in flight while the current ones are processed (the
+    // kernel sits at 2 waves per SIMD because of its accumulators either way; the registers between that and the next
+    // occupancy step are spent on memory-level parallelism).
+    PoseCam pc{};
+    int beg = 0, end = 0;
+    Obs ring[kAccDepth]{};
+    Obs2 nxt{};
+    if (i < n) {
+        pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
+        const int* ptr = V.pose_ptr + (size_t)w * (V.n_max + 1);
+        beg = ptr[i];
+        end = ptr[i + 1];
+        if (PAIR) {
+            if (beg + 2 * sub < end) nxt = load2(beg + 2 * sub);
+        } else {
+#pragma unroll
+            for (int d = 0; d < kAccDepth; ++d)
+                if (beg + sub + d * G < end) ring[d] = load(beg + sub + d * G);
+        }
+    }
+
+    // Phase 2: the median (every block of the window finishes the select itself, see select_finish)
     RobustParams rp;
     rp.c = select_finish(V, w, sel_lh, sel_u, sel_keys);
     if (blockIdx.x == 0 && threadIdx.x == 0) sc.c_obs = rp.c;      // for the record (vba_debug_fetch)
@@ -259,29 +305,12 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     rp.alpha_is_2 = prm.alpha_is_2;
     rp.expo_is_mhalf = prm.expo == -0.5;
 
-    const int sub = threadIdx.x % G;
-    const int i = blockIdx.x * PPB + threadIdx.x / G;
+    // Phase 3: weights and accumulation
     double wmax_l = 0.0;
     double acc[27];
 #pragma unroll
     for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-    const size_t pb = (size_t)w * V.n_max + (i < n ? i : 0);
-    const size_t ob = (size_t)w * V.m_max;
     if (i < n) {
-        PoseCam pc;
-        pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
-        const int* ptr = V.pose_ptr + (size_t)w * (V.n_max + 1);
-        const int beg = ptr[i], end = ptr[i + 1];
-        // software pipelined: the loads of observations k + G .. k + kAccDepth G are in flight while k is processed
-        // (the kernel sits at 2 waves per SIMD because of its accumulators either way; the registers between that
-        // and the next occupancy step are spent on memory-level parallelism)
-        struct Obs { double x, y, z, u, v, c; };
-        auto load = [&](int k) {
-            Obs o;
-            o.x = V.ox[ob + k]; o.y = V.oy[ob + k]; o.z = V.oz[ob + k];
-            o.u = V.ou[ob + k]; o.v = V.ov[ob + k]; o.c = V.oconf[ob + k];
-            return o;
-        };
         auto process = [&](double ox_, double oy_, double oz_, double ou_, double ov_, double oc_, int k) {
             double u, v, cam[3], d, J[12];
             project(pc, ox_, oy_, oz_, u, v, cam, d);
@@ -301,18 +330,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             }
         };
         if (PAIR) {
-            struct alignas(8) D2 { double a, b; };
-            struct Obs2 { D2 x, y, z, u, v, c; };
-            auto load2 = [&](int k) {       // observations k, k + 1 (the second may belong to the next pose: masked below)
-                Obs2 o;
-                o.x = *reinterpret_cast<const D2*>(V.ox + ob + k); o.y = *reinterpret_cast<const D2*>(V.oy + ob + k);
-                o.z = *reinterpret_cast<const D2*>(V.oz + ob + k); o.u = *reinterpret_cast<const D2*>(V.ou + ob + k);
-                o.v = *reinterpret_cast<const D2*>(V.ov + ob + k); o.c = *reinterpret_cast<const D2*>(V.oconf + ob + k);
-                return o;
-            };
             int k = beg + 2 * sub;
-            Obs2 nxt{};
-            if (k < end) nxt = load2(k);
             while (k < end) {
                 const int kn = k + 2 * G;
                 const Obs2 cur = nxt;
@@ -323,12 +341,6 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             }
         } else {
             int k = beg + sub;
-            Obs ring[kAccDepth];
-#pragma unroll
-            for (int d = 0; d < kAccDepth; ++d) {
-                ring[d] = Obs{0, 0, 0, 0, 0, 0};
-                if (k + d * G < end) ring[d] = load(k + d * G);
-            }
             while (k < end) {
                 const int kn = k + G;
                 const Obs cur = ring[0];
