@@ -215,7 +215,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.csol2 = A.take<double>(W * PM * 171); V.cL2 = A.take<double>(W * PM * 171); V.cR2 = A.take<double>(W * PM * 171);
     V.rx2 = A.take<double>(W * PM * 9);
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
-    V.hop = 0; V.pivot = 0; V.call = -1; V.emit = 0; V.carry = 0;
+    V.hop = 0; V.pivot = 0; V.call = -1; V.emit = 0; V.carry = 0; V.dyn_in_acc = 0;
     V.chunk = 0; V.chunk2 = 0;      // set after construction by vba_set_solver(h, -1)
     {   // every device array a kernel may touch must have been carved: a null here would fault on the GPU
         const void* must[] = {V.n, V.m, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
@@ -538,7 +538,10 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     mark(0);
     mark(1);
     // the dynamics factor depends only on the states: it runs beside the observation pipeline on a second stream
-    const bool overlap = !initialize && !prof;
+    // ... or, with few windows, inside the accumulation's grid (no cross-stream join in front of the assembly)
+    const bool ride = !initialize && !prof && h->W < 16;
+    V.dyn_in_acc = ride ? 1 : 0;
+    const bool overlap = !initialize && !prof && !ride;
     if (overlap) {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
@@ -551,7 +554,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     mark(3);
     launch_obs_accumulate(V, s);
     mark(4);
-    if (!initialize && !overlap) launch_dynamics(V, s);
+    if (!initialize && !overlap && !ride) launch_dynamics(V, s);
     if (overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     mark(5);
     // landmark-only phase on the unpivoted path: the first trial's per-pose 6x6 solve + retraction ride in k_assemble
@@ -651,7 +654,9 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             call_carry[c] = (char)V.carry;
             carry = h->carry_enabled;       // every later call starts from a trial of this chain
             fill_params(V.prm, iters[c], inits[c]);
-            const bool dyn = !inits[c];
+            const bool ride = !inits[c] && h->W < 16;      // dynamics inside the accumulation's grid
+            V.dyn_in_acc = ride ? 1 : 0;
+            const bool dyn = !inits[c] && !ride;
             if (dyn) {
                 HIPCHK(hipEventRecord(h->ev_fork, s));
                 HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));

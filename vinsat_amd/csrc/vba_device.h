@@ -100,6 +100,7 @@ struct DevView {
     // from, so k_trial<true> (emit) also leaves that call's |r| keys, their exponent histogram and sum |r| behind and
     // the next call (carry) starts at the select without re-reading the observations.
     int emit, carry;
+    int dyn_in_acc;                 // full-phase call with few windows: k_obs_accumulate's grid also runs the dynamics factor
     unsigned* hist;                 // [W][kSelPasses][kSelBins]
     double* Hraw;                   // [21]
     double* braw;                   // [6]

@@ -1,0 +1,64 @@
+// vba_dyn_body.h -- the dynamics factor of one 256-thread block (A4 + A5), shared by k_dynamics (its own launch on a
+// second stream when many windows are batched) and by k_obs_accumulate (few windows: the dynamics blocks ride in the
+// accumulation's grid, which runs about as long and is just as register-hungry -- no second stream, no cross-stream
+// join in front of the assembly: that join cost 5.5 us on average, 21 us at the 90th percentile).
+//
+// The reference differentiates the RK4 chain with reverse-mode autograd into a dense [6(n-1), 9n] Jacobian
+// (BA_utils.py:506); here every pose carries its six tangent vectors forward through the same RK4 steps
+// (8 lanes per pose: lanes 0-5 one tangent each, lane 6 the attitude term), so only the 6x6 block that is
+// actually non-zero is ever produced.
+#pragma once
+
+#include "vba_device.h"
+
+namespace vba {
+
+__device__ __forceinline__ void dynamics_block(const DevView& V, int w, int block) {
+    const int n = V.n[w];
+    const int gid = block * 256 + threadIdx.x;
+    const int i = gid / kDynLanes, c = gid % kDynLanes;
+    if (i >= n) return;
+    const size_t pb = (size_t)w * V.n_max + i;
+    const double* st = V.states + pb * 10;
+    if (c < 6) {
+        if (i >= n - 1) return;     // the last pose's propagation is discarded by the reference (BA_utils.py:476)
+        double x[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
+        double t[6] = {0, 0, 0, 0, 0, 0};
+        t[c] = 1.0;
+        const int steps = V.steps[pb];
+        propagate_gap<true>(x, t, steps, V.hop);
+        double* Phi = V.Phi + pb * 36;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Phi[6 * r + c] = t[r];
+        if (c == 0) {
+            const double* sn = st + 10;
+            double* xh = V.xhat + pb * 6;
+            double* ro = V.rorb + pb * 6;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) xh[r] = x[r];
+            ro[0] = x[0] - sn[0];
+            ro[1] = x[1] - sn[1];
+            ro[2] = x[2] - sn[2];
+            ro[3] = (x[3] - sn[7]) * kVelCoeff;
+            ro[4] = (x[4] - sn[8]) * kVelCoeff;
+            ro[5] = (x[5] - sn[9]) * kVelCoeff;
+        }
+    } else if (c == 6) {
+        const double* qp = i > 0 ? st - 10 + 3 : nullptr;
+        const double* cp = i > 0 ? V.cumrot + (pb - 1) * 4 : nullptr;
+        const double* qn = i < n - 1 ? st + 10 + 3 : nullptr;
+        double f, qg[3], Hd[9], Hu[9], Hl[9];
+        attitude_term(qp, cp, st + 3, V.cumrot + pb * 4, qn, f, qg, Hd, Hu, Hl);
+        V.fatt[pb] = f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) V.qgrad[pb * 3 + k] = qg[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            V.Hd[pb * 9 + k] = Hd[k];
+            V.Hu[pb * 9 + k] = Hu[k];
+            V.Hl[pb * 9 + k] = Hl[k];
+        }
+    }
+}
+
+}  // namespace vba

@@ -12,6 +12,7 @@
 // All of these stream the observation arrays once, coalesced (SoA, 8 B per lane per array); the pose state
 // is gathered through L1/L2 (observations are pose sorted, so a wave touches one or two poses).
 #include "vba_device.h"
+#include "vba_dyn_body.h"
 #include "vba_launch.h"
 
 namespace vba {
@@ -244,6 +245,11 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     constexpr int PPB = 256 / G;            // poses per block
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
+    const int nb_acc = (V.n_max * G + 255) / 256;
+    if ((int)blockIdx.x >= nb_acc) {        // few windows: the dynamics factor rides in this grid (vba_dyn_body.h)
+        dynamics_block(V, w, blockIdx.x - nb_acc);
+        return;
+    }
     const int n = V.n[w];
     if (blockIdx.x * PPB >= n) return;
     WinScalars& sc = V.sc[w];
@@ -533,7 +539,8 @@ void launch_select(const DevView& V, hipStream_t s) {
 void launch_obs_accumulate(const DevView& V, hipStream_t s) {
     const int G = V.acc_lanes;
     const int nb = (V.n_max * G + 255) / 256;
-    const dim3 g(nb, V.W), b(256);
+    // V.dyn_in_acc: the blocks of the dynamics factor are appended to the grid
+    const dim3 g(nb + (V.dyn_in_acc ? (V.n_max * kDynLanes + 255) / 256 : 0), V.W), b(256);
 #ifndef VBA_ACC_PAIR
 #define VBA_ACC_PAIR 1
 #endif
