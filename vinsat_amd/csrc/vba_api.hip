@@ -56,6 +56,8 @@ struct vba_context {
     double *d_ox = nullptr, *d_oy = nullptr, *d_oz = nullptr, *d_ou = nullptr, *d_ov = nullptr, *d_oconf = nullptr;
     double *d_intr = nullptr, *d_cumrot = nullptr;
     WinHead* h_head = nullptr;              // mapped pinned host memory, [W]
+    double* h_stage = nullptr;              // pinned staging for vba_set_states: [n_max * 10 + 1]
+    hipEvent_t ev_stage = nullptr;          // the last staged copy has left the staging buffer
     std::vector<int> n, m;
     std::vector<char> have_obs, have_win, have_state, have_prior;
     bool reg = false;               // BA_reg semantics (per-pose prior) for the following calls
@@ -235,6 +237,8 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_stage, ((size_t)n_max * 10 + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_head, W * sizeof(WinHead), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->V.host_head, h->h_head, 0) != hipSuccess) {
         vba_destroy(h);
@@ -259,6 +263,8 @@ int vba_destroy(vba_handle h) {
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->ev_stage) hipEventDestroy(h->ev_stage);
+    if (h->h_stage) hipHostFree(h->h_stage);
     if (h->h_head) hipHostFree(h->h_head);
     if (h->d_dbg) hipFree(h->d_dbg);
     if (h->arena.base) hipFree(h->arena.base);
@@ -490,9 +496,15 @@ int vba_set_states(vba_handle h, int window, const double* states, double lamda)
     if (!h->have_obs[window] && !h->have_win[window]) return fail(VBA_ESTATE, "upload the window before its states");
     HIPCHK(hipSetDevice(h->device));
     const int n = h->n[window];
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(h->V.states + (size_t)window * h->n_max * 10, states, (size_t)n * 80, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(&h->V.sc[window].lamda, &lamda, 8, hipMemcpyHostToDevice));
+    // through a pinned staging buffer and asynchronously on the handle's stream: the call returns as soon as the
+    // caller's array has been read, and the next call's kernels queue up behind the copy instead of behind two
+    // blocking transfers
+    HIPCHK(hipEventSynchronize(h->ev_stage));
+    std::memcpy(h->h_stage, states, (size_t)n * 80);
+    h->h_stage[(size_t)h->n_max * 10] = lamda;
+    HIPCHK(hipMemcpyAsync(h->V.states + (size_t)window * h->n_max * 10, h->h_stage, (size_t)n * 80, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(&h->V.sc[window].lamda, h->h_stage + (size_t)h->n_max * 10, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_stage, h->stream));
     h->have_state[window] = 1;
     return VBA_OK;
 }
