@@ -57,6 +57,7 @@ struct vba_context {
     double *d_intr = nullptr, *d_cumrot = nullptr;
     WinHead* h_head = nullptr;              // mapped pinned host memory, [W]
     double* h_stage = nullptr;              // pinned staging for vba_set_states: [n_max * 10 + 1]
+    double* h_back = nullptr;               // pinned staging for vba_get_states: [n_max * 10] + one WinScalars
     hipEvent_t ev_stage = nullptr;          // the last staged copy has left the staging buffer
     std::vector<int> n, m;
     std::vector<char> have_obs, have_win, have_state, have_prior;
@@ -239,6 +240,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void**)&h->h_stage, ((size_t)n_max * 10 + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_back, (size_t)n_max * 10 * sizeof(double) + sizeof(WinScalars), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_head, W * sizeof(WinHead), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->V.host_head, h->h_head, 0) != hipSuccess) {
         vba_destroy(h);
@@ -265,6 +267,7 @@ int vba_destroy(vba_handle h) {
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev_stage) hipEventDestroy(h->ev_stage);
     if (h->h_stage) hipHostFree(h->h_stage);
+    if (h->h_back) hipHostFree(h->h_back);
     if (h->h_head) hipHostFree(h->h_head);
     if (h->d_dbg) hipFree(h->d_dbg);
     if (h->arena.base) hipFree(h->arena.base);
@@ -514,15 +517,17 @@ int vba_get_states(vba_handle h, int window, double* states, double* lamda, doub
     if (int rc = check_window(h, window)) return rc;
     if (!h->have_state[window]) return fail(VBA_ESTATE, "no states uploaded");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
     const int n = h->n[window];
-    if (states) HIPCHK(hipMemcpy(states, h->V.states + (size_t)window * h->n_max * 10, (size_t)n * 80, hipMemcpyDeviceToHost));
-    WinScalars sc;
-    HIPCHK(hipMemcpy(&sc, h->V.sc + window, sizeof(sc), hipMemcpyDeviceToHost));
-    if (lamda) *lamda = sc.lamda;
-    if (last_hessian) std::memcpy(last_hessian, sc.last_hessian, 81 * 8);
-    if (n_trials) *n_trials = sc.n_trials;
-    if (flags) *flags = sc.flags;
+    // both pieces through pinned memory behind the queued work, one wait for the lot
+    WinScalars* sc = reinterpret_cast<WinScalars*>(h->h_back + (size_t)h->n_max * 10);
+    if (states) HIPCHK(hipMemcpyAsync(h->h_back, h->V.states + (size_t)window * h->n_max * 10, (size_t)n * 80, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(sc, h->V.sc + window, sizeof(WinScalars), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (states) std::memcpy(states, h->h_back, (size_t)n * 80);
+    if (lamda) *lamda = sc->lamda;
+    if (last_hessian) std::memcpy(last_hessian, sc->last_hessian, 81 * 8);
+    if (n_trials) *n_trials = sc->n_trials;
+    if (flags) *flags = sc->flags;
     return VBA_OK;
 }
 
