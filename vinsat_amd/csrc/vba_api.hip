@@ -58,6 +58,7 @@ struct vba_context {
     WinHead* h_head = nullptr;              // mapped pinned host memory, [W]
     double* h_stage = nullptr;              // pinned staging for vba_set_states: [n_max * 10 + 1]
     double* h_back = nullptr;               // pinned staging for vba_get_states: [n_max * 10] + one WinScalars
+    bool back_valid = false;                // h_back holds window 0's states and scalars after the last step (vba_iterate)
     hipEvent_t ev_stage = nullptr;          // the last staged copy has left the staging buffer
     std::vector<int> n, m;
     std::vector<char> have_obs, have_win, have_state, have_prior;
@@ -531,7 +532,9 @@ int vba_get_states(vba_handle h, int window, double* states, double* lamda, doub
     return VBA_OK;
 }
 
-static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool emit = true) {
+// readback >= 0: the states and scalars of that window are copied to the pinned read-back buffer right behind the first
+// trial (valid if that trial ends the call: h->back_valid), so that vba_iterate needs one wait instead of two.
+static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool emit = true, int readback = -1) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
@@ -596,6 +599,11 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
             mark(9);
             HIPCHK(hipEventRecord(h->ev1, s));
         }
+        h->back_valid = false;
+        if (readback >= 0) {
+            HIPCHK(hipMemcpyAsync(h->h_back, V.states + (size_t)readback * h->n_max * 10, (size_t)h->n[readback] * 80, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(h->h_back + (size_t)h->n_max * 10, V.sc + readback, sizeof(WinScalars), hipMemcpyDeviceToHost, s));
+        }
         HIPCHK(hipGetLastError());
         if (int rc = read_heads(h)) { rc_out = rc; break; }
         bool all = true, repeat = false;
@@ -608,7 +616,10 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
             h->fallbacks++;
             continue;
         }
-        if (all) break;
+        if (all) {
+            h->back_valid = readback >= 0;      // the copies queued behind this (final) trial hold the result
+            break;
+        }
     }
     if (rc_out == VBA_OK) HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
     if (prof) {
@@ -745,7 +756,16 @@ int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const d
                 double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags) {
     if (int rc = vba_set_states(h, 0, states_in, lamda_in)) return rc;
     // the next call of this kind replaces the states again: nothing to carry over
-    if (int rc = step_impl(h, iter, initialize, nullptr, false)) return rc;
+    if (int rc = step_impl(h, iter, initialize, nullptr, false, 0)) return rc;
+    if (h->back_valid) {        // read back together with the step: no second wait
+        const WinScalars* sc = reinterpret_cast<const WinScalars*>(h->h_back + (size_t)h->n_max * 10);
+        if (states_out) std::memcpy(states_out, h->h_back, (size_t)h->n[0] * 80);
+        if (lamda_out) *lamda_out = sc->lamda;
+        if (last_hessian) std::memcpy(last_hessian, sc->last_hessian, 81 * 8);
+        if (n_trials) *n_trials = sc->n_trials;
+        if (flags) *flags = sc->flags;
+        return VBA_OK;
+    }
     return vba_get_states(h, 0, states_out, lamda_out, last_hessian, n_trials, flags);
 }
 
