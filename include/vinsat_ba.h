@@ -82,9 +82,9 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external);
  * when many windows are batched); chunk in [2,60] cuts the chain into chunks of that many poses that are
  * eliminated in parallel plus a reduced system over the separators; chunk = -1 restores the default
  * (0 for >= 128 windows; otherwise chunks of 8 poses -- fewer up to 520 poses, more beyond 1032 -- and the reduced
- * system by cyclic reduction, see vba_set_solver2; two levels of ~n^(1/3) beyond 7700 poses).  With chunk = 0, equal
- * pose counts and >= 2048 windows three windows share one wavefront; chunk = -2 is chunk = 0 with one window per
- * wavefront, chunk = -3 packs from 3 windows on.  All variants agree to rounding. */
+ * system by cyclic reduction, see vba_set_solver2; two levels of ~n^(1/3) beyond 7700 poses).  With chunk = 0 a
+ * wavefront walks one window; chunk = -3 makes three windows of equal pose count share a wavefront (no faster on
+ * MI355X at any batch size measured, kept for comparison), chunk = -2 forbids it.  All variants agree to rounding. */
 int vba_set_solver(vba_handle h, int chunk);
 /* Explicit partition: chunks of `chunk` poses; the reduced system over their separators is
  *   chunk2 = 0       walked by one wavefront,

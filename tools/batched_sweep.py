@@ -16,6 +16,8 @@ def main():
     n, m = win.time_idx.size, win.ii.size
     for W in Ws:
         e = BAEngine(n, m, windows=W)
+        if os.environ.get("VBA_SWEEP_SOLVER"):
+            e.set_solver(int(os.environ["VBA_SWEEP_SOLVER"]))
         if os.environ.get("VBA_SWEEP_LANES"):
             e.set_accumulate_lanes(int(os.environ["VBA_SWEEP_LANES"]))
         for w in range(W):

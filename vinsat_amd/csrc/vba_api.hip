@@ -72,7 +72,9 @@ struct vba_context {
     bool hist_dirty = false;        // a k_trial<true> has left an exponent histogram behind that nobody consumed
     int last_iter = 0, last_init = 0;
     int sh_pivot = 0;                       // sharded mode: solver variant of the current call (0 unpivoted, 2 mixed after a failed check)
-    int pack_min = 2048;                    // windows from which three chains share a wavefront (below, one wave per window fills the SIMDs)
+    int pack_min = 1 << 30;                 // windows from which three chains share a wavefront: never by default (measured at 1024 / 2048 / 4096
+                                            // windows: one wave per window is as fast or faster, 1.52 / 1.96 / 2.70 ms vs 1.52 / 2.06 / 2.78 ms per solve);
+                                            // vba_set_solver(h, -3) packs from 3 windows on
     int no_pack = 0;                        // diagnostic: force one window per wavefront in the sequential driver
     int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
