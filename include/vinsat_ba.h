@@ -137,7 +137,9 @@ int vba_solver_fallbacks(vba_handle h, int* count);
  * confidences [m], ii [m] pose index of each row (BA arguments landmarks_xyz, landmarks, confidences, ii:
  * BA_filtering.py:4; ii is int64 as at BA_filtering.py:35).  n is the number of poses the indices refer to.
  * Uploading with a pose count different from the window's current one starts a new window: the other upload
- * (pose constants / observations) and the states must follow before the next step. */
+ * (pose constants / observations) and the states must follow before the next step.
+ * The rows are packed into pinned memory and sent with one asynchronous copy on the handle's stream (ordered in
+ * front of the kernels that read them); the caller's arrays may be reused as soon as the call returns. */
 int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const double* landmarks_xyz,
                             const double* landmarks_uv, const double* confidences, const int64_t* ii);
 
@@ -168,6 +170,13 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
 /* Convenience: set_states(window 0) + step + get_states(window 0); the exact shape of one BA() call. */
 int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in,
                 double* states_out, double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags);
+
+/* The same call when the states argument IS the result of the previous vba_iterate / vba_iterate_resident /
+ * vba_run_schedule on this handle (the driver loop `states = BA(iter, states, ...)`, od_pipe.py:1036-1040) and lamda_in
+ * the lamda it returned: nothing is uploaded, the device-resident states and damping are used, and the call starts
+ * from the keys the last accepted trial left behind (vba_set_key_carry).  Same bits as vba_iterate. */
+int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out,
+                         double* last_hessian, int* n_trials, unsigned* flags);
 
 /* Copy an intermediate of the last step of `window` to host memory; *count receives the number of
  * doubles written (capacity is checked). */

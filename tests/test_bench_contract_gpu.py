@@ -34,3 +34,22 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["accuracy"]["max_rel_pos_err_vs_ref"] < 1e-6
     assert d["batched"]["windows"] == 8 and d["batched"]["value"] > d["value"]
+    assert d["python_BA_call"]["value"] > 100 and d["roofline"]["whole_call"]["bytes"] == 208.0 * 50000 + 5000.0 * 500
+
+
+def test_gpus_2_runs_two_replica_ranks_on_this_box():
+    """The driver's `python bench.py --gpus N` must measure N ranks.  On a one-GPU box both ranks share the device (the
+    control plane is gloo, replicas need no RCCL); the RCCL leg says that it was skipped."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "20",
+                          "--windows", "0", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "replicas2"
+    assert d["value"] > 100 and abs(d["value"] * d["ms_per_step"] / 1e3 - 2.0) < 1e-6       # both windows' iterations count
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert "skipped" in d["sharded"]
+    else:
+        assert d["sharded"]["rccl_ranks"] == 2

@@ -40,6 +40,7 @@ SIGNATURES = {
     "vba_step": (c_int, [c_void_p, c_int, c_int]),
     "vba_run_schedule": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "vba_iterate": (c_int, [c_void_p, c_int, c_int, c_double, PD, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
+    "vba_iterate_resident": (c_int, [c_void_p, c_int, c_int, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
     "vba_debug_fetch": (c_int, [c_void_p, c_int, c_int, PD, c_int64, PI64]),
     "vba_last_step_ms": (c_int, [c_void_p, POINTER(c_float)]),
     "vba_step_profiled": (c_int, [c_void_p, c_int, c_int, POINTER(c_float)]),

@@ -52,9 +52,15 @@ struct vba_context {
     Arena arena;
     DevView V{};
     // mutable device pointers (DevView holds const views of some)
-    int *d_n = nullptr, *d_m = nullptr, *d_opose = nullptr, *d_pose_ptr = nullptr, *d_steps = nullptr;
-    double *d_ox = nullptr, *d_oy = nullptr, *d_oz = nullptr, *d_ou = nullptr, *d_ov = nullptr, *d_oconf = nullptr;
+    int *d_n = nullptr, *d_m = nullptr, *d_steps = nullptr;
+    double* d_obs = nullptr;                // observation blocks, [W][obs_stride] (layout: DevView::ox)
+    int64_t m_pad = 0;                      // doubles per observation array inside a block
     double *d_intr = nullptr, *d_cumrot = nullptr;
+    // uploads go through pinned staging and are asynchronous on the handle's stream (ordered with the kernels that
+    // read them); two buffers, so that the host packs window w + 1 while window w is on its way
+    double* h_up[2] = {nullptr, nullptr};
+    hipEvent_t ev_up[2] = {nullptr, nullptr};
+    int up_next = 0;
     WinHead* h_head = nullptr;              // mapped pinned host memory, [W]
     double* h_stage = nullptr;              // pinned staging for vba_set_states: [n_max * 10 + 1]
     double* h_back = nullptr;               // pinned staging for vba_get_states: [n_max * 10] + one WinScalars
@@ -154,6 +160,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) return fail(VBA_ENODEV, "no HIP device visible");
     if (device < 0 || device >= cnt) return fail(VBA_EINVAL, "device index out of range");
     HIPCHK(hipSetDevice(device));
+    HIPCHK(configure_solver_device());
     vba_context* h = new (std::nothrow) vba_context();
     if (!h) return fail(VBA_ENOMEM, "host allocation failed");
     h->device = device;
@@ -166,8 +173,9 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     size_t bytes = 0;
     auto need = [&](size_t b) { bytes += ((b + 255) & ~size_t(255)) + 256; };
     need(W * 4); need(W * 4); need(W * sizeof(WinScalars));
-    for (int k = 0; k < 6; ++k) need(W * M * 8);
-    need(W * M * 4); need(W * (N + 1) * 4);
+    const size_t m_pad = (M + 31) & ~size_t(31);
+    const size_t obs_stride = (6 * m_pad + m_pad / 2 + (N + 2) / 2 + 31) & ~size_t(31);     // doubles
+    need(W * obs_stride * 8);
     need(W * N * 10 * 8); need(W * N * 10 * 8); need(W * N * 10 * 8);
     need(W * N * 4 * 8); need(W * N * 4 * 8); need(W * N * 4);
     need(W * N * 36 * 8); need(W * N * 6 * 8);
@@ -184,17 +192,23 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
         return fail(VBA_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
     }
     h->arena.size = bytes;
-    hipMemset(h->arena.base, 0, bytes);
+    if (hipMemset(h->arena.base, 0, bytes) != hipSuccess) {
+        hipFree(h->arena.base);
+        delete h;
+        return fail(VBA_EHIP, "hipMemset of the device arena failed");
+    }
     Arena& A = h->arena;
     DevView& V = h->V;
     V.W = windows; V.n_max = n_max; V.m_max = m_max; V.nblk_obs = nblk_obs; V.nblk_dyn = nblk_dyn;
     V.n = h->d_n = A.take<int>(W);
     V.m = h->d_m = A.take<int>(W);
     V.sc = A.take<WinScalars>(W);
-    V.ox = h->d_ox = A.take<double>(W * M); V.oy = h->d_oy = A.take<double>(W * M); V.oz = h->d_oz = A.take<double>(W * M);
-    V.ou = h->d_ou = A.take<double>(W * M); V.ov = h->d_ov = A.take<double>(W * M); V.oconf = h->d_oconf = A.take<double>(W * M);
-    V.opose = h->d_opose = A.take<int>(W * M);
-    V.pose_ptr = h->d_pose_ptr = A.take<int>(W * (N + 1));
+    h->d_obs = A.take<double>(W * obs_stride);
+    h->m_pad = (int64_t)m_pad;
+    V.obs_stride = (int64_t)obs_stride;
+    V.ox = h->d_obs; V.oy = V.ox + m_pad; V.oz = V.oy + m_pad; V.ou = V.oz + m_pad; V.ov = V.ou + m_pad; V.oconf = V.ov + m_pad;
+    V.opose = reinterpret_cast<const int*>(V.oconf + m_pad);
+    V.pose_ptr = V.opose + m_pad;
     V.states = A.take<double>(W * N * 10); V.states_new = A.take<double>(W * N * 10); V.states_prev = A.take<double>(W * N * 10);
     V.intr = h->d_intr = A.take<double>(W * N * 4);
     V.cumrot = h->d_cumrot = A.take<double>(W * N * 4);
@@ -242,6 +256,10 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_up[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_up[1], hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_up[0], std::max(obs_stride, 9 * N + 32) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_up[1], std::max(obs_stride, 9 * N + 32) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_stage, ((size_t)n_max * 10 + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_back, (size_t)n_max * 10 * sizeof(double) + sizeof(WinScalars), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_head, W * sizeof(WinHead), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -269,6 +287,10 @@ int vba_destroy(vba_handle h) {
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev_stage) hipEventDestroy(h->ev_stage);
+    for (int k = 0; k < 2; ++k) {
+        if (h->ev_up[k]) hipEventDestroy(h->ev_up[k]);
+        if (h->h_up[k]) hipHostFree(h->h_up[k]);
+    }
     if (h->h_stage) hipHostFree(h->h_stage);
     if (h->h_back) hipHostFree(h->h_back);
     if (h->h_head) hipHostFree(h->h_head);
@@ -397,9 +419,16 @@ int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const do
         std::vector<int> cur(ptr.begin(), ptr.end() - 1);
         for (int64_t k = 0; k < m; ++k) perm[cur[ii[k]]++] = k;
     }
-    std::vector<double> buf(6 * (size_t)m);
-    std::vector<int> pose(m);
-    double *x = buf.data(), *y = x + m, *z = y + m, *u = z + m, *v = u + m, *c = v + m;
+    // the whole block of the window -- six coordinate arrays, pose index, CSR -- is packed into pinned memory and goes up
+    // with ONE asynchronous copy on the handle's stream; the pose / row counts follow in a one-thread kernel
+    const int ub = h->up_next;
+    h->up_next ^= 1;
+    HIPCHK(hipEventSynchronize(h->ev_up[ub]));      // the previous copy out of this buffer has left it
+    double* blk = h->h_up[ub];
+    const size_t mp = (size_t)h->m_pad;
+    double *x = blk, *y = x + mp, *z = y + mp, *u = z + mp, *v = u + mp, *c = v + mp;
+    int* pose = reinterpret_cast<int*>(c + mp);
+    int* cptr = pose + mp;
     for (int64_t s = 0; s < m; ++s) {
         const int64_t k = perm[s];
         x[s] = xyz[3 * k]; y[s] = xyz[3 * k + 1]; z[s] = xyz[3 * k + 2];
@@ -407,19 +436,13 @@ int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const do
         c[s] = conf[k];
         pose[s] = (int)ii[k];
     }
-    const size_t ob = (size_t)window * h->m_max;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(h->d_ox + ob, x, m * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_oy + ob, y, m * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_oz + ob, z, m * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_ou + ob, u, m * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_ov + ob, v, m * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_oconf + ob, c, m * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_opose + ob, pose.data(), m * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_pose_ptr + (size_t)window * (h->n_max + 1), ptr.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    std::memcpy(cptr, ptr.data(), (size_t)(n + 1) * sizeof(int));
     const int mi = (int)m;
-    HIPCHK(hipMemcpy(h->d_m + window, &mi, 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_n + window, &n, 4, hipMemcpyHostToDevice));
+    const size_t used = (size_t)(reinterpret_cast<char*>(cptr + n + 1) - reinterpret_cast<char*>(blk));
+    HIPCHK(hipMemcpyAsync(h->d_obs + (size_t)window * h->V.obs_stride, blk, used, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_up[ub], h->stream));
+    launch_set_counts(h->V, window, n, mi, h->stream);
+    HIPCHK(hipGetLastError());
     h->n[window] = n;
     h->m[window] = mi;
     h->have_obs[window] = 1;
@@ -443,11 +466,19 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
     }
     steps[n - 1] = 1;   // BA_utils.py:75
     const size_t pb = (size_t)window * h->n_max;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(h->d_intr + pb * 4, intrinsics, (size_t)n * 32, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_cumrot + pb * 4, cumrot_last, (size_t)n * 32, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_steps + pb, steps.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_n + window, &n, 4, hipMemcpyHostToDevice));
+    const int ub = h->up_next;
+    h->up_next ^= 1;
+    HIPCHK(hipEventSynchronize(h->ev_up[ub]));
+    double* blk = h->h_up[ub];                      // holds max(obs_stride, 9 n_max + 32) doubles
+    std::memcpy(blk, intrinsics, (size_t)n * 32);
+    std::memcpy(blk + (size_t)n * 4, cumrot_last, (size_t)n * 32);
+    std::memcpy(blk + (size_t)n * 8, steps.data(), (size_t)n * 4);
+    HIPCHK(hipMemcpyAsync(h->d_intr + pb * 4, blk, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_cumrot + pb * 4, blk + (size_t)n * 4, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_steps + pb, blk + (size_t)n * 8, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_up[ub], h->stream));
+    launch_set_counts(h->V, window, n, -1, h->stream);
+    HIPCHK(hipGetLastError());
     h->n[window] = n;
     h->have_win[window] = 1;
     return VBA_OK;
@@ -551,7 +582,11 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     if (!V.carry && h->hist_dirty) launch_clear_hist0(V, s);     // the states were replaced after the last trial
     h->hist_dirty = V.emit != 0;
     fill_params(V.prm, iter, initialize);
-    hipEvent_t ev[VBA_NKERNELS + 1] = {};
+    struct ProfEvents {         // destroyed on every exit path, error returns included
+        hipEvent_t e[VBA_NKERNELS + 1] = {};
+        ~ProfEvents() { for (hipEvent_t q : e) if (q) (void)hipEventDestroy(q); }
+    } pe;
+    hipEvent_t* ev = pe.e;
     if (prof) {
         for (int k = 0; k <= VBA_NKERNELS; ++k) HIPCHK(hipEventCreate(&ev[k]));
     }
@@ -591,7 +626,11 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
         V.pack = 1;
         for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
     }
-    for (int trial = 0; trial < 24; ++trial) {
+    // lamda runs 1e-4 .. 1e4 in decades (at most 9 trials) plus one repeat per window for a pivoted fallback; a loop
+    // that is still not done after kMaxTrials means the device never reported an outcome (a fault, a skipped window)
+    constexpr int kMaxTrials = 24;
+    bool finished = false;
+    for (int trial = 0; trial < kMaxTrials; ++trial) {
         if (!(trial == 0 && fuse)) launch_solve(V, initialize, s);
         if (trial == 0) mark(7);
         launch_trial(V, s);
@@ -620,8 +659,13 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
         }
         if (all) {
             h->back_valid = readback >= 0;      // the copies queued behind this (final) trial hold the result
+            finished = true;
             break;
         }
+    }
+    if (rc_out == VBA_OK && !finished) {
+        h->have_state.assign(h->W, 0);          // half-finished trial states must not be read back as a result
+        rc_out = fail(VBA_ESTATE, "LM loop did not terminate within " + std::to_string(kMaxTrials) + " trials (no outcome reported by the device)");
     }
     if (rc_out == VBA_OK) HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
     if (prof) {
@@ -631,7 +675,6 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
         }
         if (fuse) prof[VBA_K_SOLVE] = 0.f;              // first trial of a landmark-only call: solved inside k_assemble<true>
         if (V.carry) prof[VBA_K_RESIDUAL] = 0.f;        // not launched: the previous trial left the keys behind
-        for (int k = 0; k <= VBA_NKERNELS; ++k) (void)hipEventDestroy(ev[k]);
     }
     if (rc_out != VBA_OK) return rc_out;
     {
@@ -722,14 +765,16 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             V.pivot = h->pivot_mode;
             V.carry = call_carry[sc_call];
             fill_params(V.prm, iters[sc_call], inits[sc_call]);
-            for (int trial = 0; trial < 24; ++trial) {
+            bool finished = false;
+            for (int trial = 0; trial <= 24; ++trial) {
                 bool repeat = false, all = true;
                 for (int w = 0; w < h->W; ++w) {
                     if (head(h, w)->call_idx != sc_call) continue;
                     all = false;
                     repeat = repeat || (head(h, w)->flags & 8u);
                 }
-                if (all) break;
+                if (all) { finished = true; break; }
+                if (trial == 24) break;
                 if (repeat && V.pivot == 0) { V.pivot = 2; h->fallbacks++; }
                 launch_solve(V, inits[sc_call], s);
                 launch_trial(V, s);
@@ -737,6 +782,10 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
                 HIPCHK(hipGetLastError());
                 if (int rc = read_heads(h)) return rc;
                 ++trials;
+            }
+            if (!finished) {
+                h->have_state.assign(h->W, 0);
+                return fail(VBA_ESTATE, "LM loop of call " + std::to_string(sc_call) + " did not terminate (no outcome reported by the device)");
             }
         }
         next = stalled.front() + 1;
@@ -760,6 +809,25 @@ int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const d
     // the next call of this kind replaces the states again: nothing to carry over
     if (int rc = step_impl(h, iter, initialize, nullptr, false, 0)) return rc;
     if (h->back_valid) {        // read back together with the step: no second wait
+        const WinScalars* sc = reinterpret_cast<const WinScalars*>(h->h_back + (size_t)h->n_max * 10);
+        if (states_out) std::memcpy(states_out, h->h_back, (size_t)h->n[0] * 80);
+        if (lamda_out) *lamda_out = sc->lamda;
+        if (last_hessian) std::memcpy(last_hessian, sc->last_hessian, 81 * 8);
+        if (n_trials) *n_trials = sc->n_trials;
+        if (flags) *flags = sc->flags;
+        return VBA_OK;
+    }
+    return vba_get_states(h, 0, states_out, lamda_out, last_hessian, n_trials, flags);
+}
+
+// The next call of a driver loop that hands BA() the states it got back from the previous call: nothing to upload, the
+// device already holds them (and the carried keys of the last accepted trial stay usable).
+int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out, double* last_hessian,
+                         int* n_trials, unsigned* flags) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (!h->stepped) return fail(VBA_ESTATE, "vba_iterate_resident follows a call that left its result on the device");
+    if (int rc = step_impl(h, iter, initialize, nullptr, true, 0)) return rc;
+    if (h->back_valid) {
         const WinScalars* sc = reinterpret_cast<const WinScalars*>(h->h_back + (size_t)h->n_max * 10);
         if (states_out) std::memcpy(states_out, h->h_back, (size_t)h->n[0] * 80);
         if (lamda_out) *lamda_out = sc->lamda;

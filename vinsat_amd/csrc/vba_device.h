@@ -67,16 +67,19 @@ struct DevView {
     int n_min;                      // smallest pose count over the windows of the handle (host maintained)
     int call;                       // >= 0: this launch belongs to call `call` of a schedule, windows elsewhere in it skip
     int64_t m_max;
+    int64_t obs_stride;             // doubles between the observation blocks of consecutive windows (see ox)
     int nblk_obs;                   // ceil(m_max / kObsBlock)
     const int* n;                   // [W]
     const int* m;                   // [W]
     StepParams prm;                 // per-call constants, travel with the kernel arguments
     WinHead* host_head;             // [W] mapped pinned host memory: k_decide publishes the outcome here
     WinScalars* sc;                 // [W]
-    // observations, pose sorted, SoA [W][m_max]
+    // observations, pose sorted, SoA.  One contiguous block per window -- [ox | oy | oz | ou | ov | oconf] of m_pad doubles
+    // each, then opose (m_pad ints) and the CSR pose_ptr (n_max + 1 ints) -- so that a window is uploaded with ONE copy;
+    // the pointers are those of window 0, window w adds w * obs_stride doubles (2 * obs_stride ints)
     const double *ox, *oy, *oz, *ou, *ov, *oconf;
     const int* opose;
-    const int* pose_ptr;            // [W][n_max+1] CSR
+    const int* pose_ptr;
     // per pose [W][n_max][...]
     double* states;                 // [10] current estimate (input of the step)
     double* states_new;             // [10] last trial

@@ -13,6 +13,7 @@ void launch_obs_accumulate(const DevView& V, hipStream_t s);
 void launch_trial(const DevView& V, hipStream_t s);
 void launch_clear_hist0(const DevView& V, hipStream_t s);
 void launch_reset_calls(const DevView& V, hipStream_t s);
+void launch_set_counts(const DevView& V, int w, int n, int m, hipStream_t s);
 void launch_broadcast_states(const DevView& V, int n, double lamda, hipStream_t s);
 void launch_debug_project(const DevView& V, int w, int m, double* est, double* J, double* wt, hipStream_t s);
 
@@ -22,6 +23,7 @@ void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s);
 
 // vba_solve.hip
 void launch_solve(const DevView& V, int initialize, hipStream_t s);
+hipError_t configure_solver_device();      // per device, from vba_create
 void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStream_t s);
 
 // vba_shard.hip

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(kObsBlock) void k_obs_residual(DevView V, double* a
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
     const int m = V.m[w];
-    const size_t ob = (size_t)w * V.m_max;
+    const size_t ob = (size_t)w * V.obs_stride;     // observation block of the window
+    const size_t mb = (size_t)w * V.m_max;          // per-observation work arrays
     const int k = blockIdx.x * kObsBlock + threadIdx.x;
     if (HIST0) {
         for (int b = threadIdx.x; b < 1024; b += kObsBlock) lh[b] = 0u;
@@ -49,14 +50,14 @@ __global__ __launch_bounds__(kObsBlock) void k_obs_residual(DevView V, double* a
     }
     double s = 0.0;
     if (k < m) {
-        const int pose = V.opose[ob + k];
+        const int pose = V.opose[2 * ob + k];
         const size_t pb = (size_t)w * V.n_max + pose;
         PoseCam pc;
         pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
         double u, v, cam[3], d;
         project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
         const double ru = fabs(V.ou[ob + k] - u), rv = fabs(V.ov[ob + k] - v);
-        double* ab = abs_out ? abs_out : V.absr + 2 * ob;
+        double* ab = abs_out ? abs_out : V.absr + 2 * mb;
         reinterpret_cast<double2*>(ab)[k] = make_double2(ru, rv);
         s = ru + rv;
         if (HIST0) {
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     const int sub = threadIdx.x % G;
     const int i = blockIdx.x * PPB + threadIdx.x / G;
     const size_t pb = (size_t)w * V.n_max + (i < n ? i : 0);
-    const size_t ob = (size_t)w * V.m_max;
+    const size_t ob = (size_t)w * V.obs_stride;
+    const size_t mb = (size_t)w * V.m_max;
 
     struct Obs { double x, y, z, u, v, c; };
     struct alignas(8) D2 { double a, b; };
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     Obs2 nxt{};
     if (i < n) {
         pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
-        const int* ptr = V.pose_ptr + (size_t)w * (V.n_max + 1);
+        const int* ptr = V.pose_ptr + 2 * ob;
         beg = ptr[i];
         end = ptr[i + 1];
         if (PAIR) {
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             project_jacobian(pc, cam, d, J);
             const double ru = ou_ - u, rv = ov_ - v;
             const double wr = robust_weight_raw(rp, ru, rv);
-            V.wraw[ob + k] = wr;
+            V.wraw[mb + k] = wr;
             wmax_l = fmax(wmax_l, wr);
             const double wc = wr * oc_;
             int q = 0;
@@ -406,18 +408,18 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     if (obs_block) {
         const int k = blockIdx.x * kObsBlock + threadIdx.x;
         if (k < m) {
-            const size_t ob = (size_t)w * V.m_max;
-            const int pose = V.opose[ob + k];
+            const size_t ob = (size_t)w * V.obs_stride, mb = (size_t)w * V.m_max;
+            const int pose = V.opose[2 * ob + k];
             PoseCam pc;
             pose_camera(V.states_new + (sb + pose) * 10, V.intr + (sb + pose) * 4, pc);
             double u, v, cam[3], d;
             project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
-            const double wk = (V.wraw[ob + k] / bits_f64(sc.wmax_bits)) * V.oconf[ob + k];
+            const double wk = (V.wraw[mb + k] / bits_f64(sc.wmax_bits)) * V.oconf[ob + k];
             const double du = V.ou[ob + k] - u, dv = V.ov[ob + k] - v;
             s = fabs(du * wk) + fabs(dv * wk);
             if (EMIT) {
                 const double ru = fabs(du), rv = fabs(dv);
-                reinterpret_cast<double2*>(V.absr + 2 * ob)[k] = make_double2(ru, rv);
+                reinterpret_cast<double2*>(V.absr + 2 * mb)[k] = make_double2(ru, rv);
                 s_raw = ru + rv;
                 atomicAdd(&lh[(unsigned)(f64_bits(ru) >> 53) & 1023u], 1u);
                 atomicAdd(&lh[(unsigned)(f64_bits(rv) >> 53) & 1023u], 1u);
@@ -466,8 +468,8 @@ __global__ __launch_bounds__(kObsBlock) void k_debug_project(DevView V, int w, d
     const int m = V.m[w];
     const int k = blockIdx.x * kObsBlock + threadIdx.x;
     if (k >= m) return;
-    const size_t ob = (size_t)w * V.m_max;
-    const int pose = V.opose[ob + k];
+    const size_t ob = (size_t)w * V.obs_stride, mb = (size_t)w * V.m_max;
+    const int pose = V.opose[2 * ob + k];
     const size_t pb = (size_t)w * V.n_max + pose;
     PoseCam pc;
     pose_camera(V.states_prev + pb * 10, V.intr + pb * 4, pc);
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(kObsBlock) void k_debug_project(DevView V, int w, d
     est[2 * k] = u;
     est[2 * k + 1] = v;
     project_jacobian(pc, cam, d, J + 12 * (size_t)k);
-    wt[k] = (V.wraw[ob + k] / bits_f64(V.sc[w].wmax_bits)) * V.oconf[ob + k];
+    wt[k] = (V.wraw[mb + k] / bits_f64(V.sc[w].wmax_bits)) * V.oconf[ob + k];
 }
 
 // window 0's states and damping copied to every other window (vba_set_states with window == -1)
@@ -487,6 +489,12 @@ __global__ __launch_bounds__(256) void k_broadcast_states(DevView V, int n, doub
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (w > 0 && k < n * 10) dst[k] = src[k];
     if (k == 0) V.sc[w].lamda = lamda;
+}
+
+// pose / row counts of a freshly uploaded window (m < 0: keep)
+__global__ void k_set_counts(int* n_arr, int* m_arr, int w, int n, int m) {
+    n_arr[w] = n;
+    if (m >= 0) m_arr[w] = m;
 }
 
 __global__ void k_reset_calls(DevView V) {
@@ -501,6 +509,10 @@ __global__ __launch_bounds__(1024) void k_clear_hist0(DevView V) {
 
 void launch_clear_hist0(const DevView& V, hipStream_t s) {
     hipLaunchKernelGGL(k_clear_hist0, dim3(V.W), dim3(1024), 0, s, V);
+}
+
+void launch_set_counts(const DevView& V, int w, int n, int m, hipStream_t s) {
+    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, s, const_cast<int*>(V.n), const_cast<int*>(V.m), w, n, m);
 }
 
 void launch_reset_calls(const DevView& V, hipStream_t s) {

@@ -1367,21 +1367,24 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
     hipLaunchKernelGGL(k_solve_reduced<PIVOT>, dim3(V.W), dim3(64), 0, s, V, cs, cs2);
 }
 
-void launch_solve(const DevView& V, int initialize, hipStream_t s) {
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {     // chunks above ~30 poses need more than the default 64 KiB of dynamic LDS
-        const int cap = (int)((512 + 60 * 252 + 162) * sizeof(double));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_chunks2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        const int cap_cr = kCrMax * 252 * (int)sizeof(double);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_reduced_cr<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap_cr);
-        lds_attr_set = true;
+// Dynamic-LDS limits of the solver kernels.  HIP function attributes are per DEVICE, so this runs in every vba_create
+// (after hipSetDevice); a refused size is reported there instead of surfacing later as a failed launch.
+hipError_t configure_solver_device() {
+    const int cap = (int)((512 + 60 * 252 + 162) * sizeof(double));     // chunks above ~30 poses exceed the default 64 KiB
+    const int cap_cr = kCrMax * 252 * (int)sizeof(double);
+    const struct { const void* fn; int bytes; } set[] = {
+        {reinterpret_cast<const void*>(k_solve_chunks<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks<true>), cap},
+        {reinterpret_cast<const void*>(k_solve_chunks2<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks2<true>), cap},
+        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, false>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, false>), cap_cr},
+        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, true>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, true>), cap_cr}};
+    for (const auto& e : set) {
+        const hipError_t rc = hipFuncSetAttribute(e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, e.bytes);
+        if (rc != hipSuccess) return rc;
     }
+    return hipSuccess;
+}
+
+void launch_solve(const DevView& V, int initialize, hipStream_t s) {
     if (V.pivot != 1) launch_solve_variant<false>(V, initialize, s);
     if (V.pivot != 0) launch_solve_variant<true>(V, initialize, s);
     // interiors / retraction: shared by both variants (k_solve and k_solve_packed retract themselves)

@@ -141,6 +141,16 @@ class BAEngine:
                                         _p(hess), byref(nt), byref(fl)), self.lib)
         return out, lam.value, hess, nt.value, fl.value
 
+    def iterate_resident(self, it, initialize):
+        """``BA()`` on window 0 from the states and damping the previous call left on the device."""
+        out = np.empty((self.n[0], 10))
+        lam = c_double()
+        hess = np.empty((9, 9))
+        nt, fl = c_int(), c_uint()
+        _lib.check(self.lib.vba_iterate_resident(self.h, int(it), int(bool(initialize)), _p(out), byref(lam), _p(hess),
+                                                 byref(nt), byref(fl)), self.lib)
+        return out, lam.value, hess, nt.value, fl.value
+
     # "begin" = two back-to-back event records (the overhead every class contains), no kernel
     KERNELS = ("begin", "residual", "select", "accumulate", "dynamics", "assemble", "solve", "trial", "decide")
 
