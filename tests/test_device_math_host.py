@@ -149,3 +149,16 @@ def test_hop_integrator_device_math(hc):
     hc.hc_orbit_hop(n, _p(np.ascontiguousarray(g["x"])), _pi(steps), _p(xhat), _p(Phi))
     assert rel_err(xhat, g["x_pred"]) < 1e-14
     assert rel_err(Phi, g["Phi"]) < 1e-13
+
+
+def test_device_math_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """a sanitizer build of the host-compiled device arithmetic (CPU only; sanitizers are not
+    available for GPU code on this pool).  Any ASan / UBSan finding aborts the driver with a non-zero code."""
+    src = os.path.join(ROOT, "tests", "hostcheck", "sanitize_main.cpp")
+    exe = str(tmp_path / "sanitize_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-o", exe, src])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "sanitize_main ok" in p.stdout and "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr
