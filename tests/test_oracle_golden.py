@@ -109,3 +109,44 @@ def test_oracle_reproduces_BA_reg(base):
         assert rel_err(out, g[f"states_out_{k}"][0]) < 1e-10, k
         assert rel_err(hess, g[f"last_hessian_{k}"][0]) < 1e-9, k
     assert g["n_trials"].max() == 9 and (g["n_trials"][10:] > 1).any()      # the fixture exercises lamda exhaustion
+
+
+def test_plain_BA_with_rejected_trials_vs_reference():
+    """Plain ``BA`` whose LM loop rejects trials (BA_filtering.py:52-77): 100-pose / 5k window with confidences of 3, run
+    through the reference's driver (tools/gen_golden.py REJ).  Every call: trial count and lamda exact, states; for the
+    calls captured in full, the system, right-hand side and solution of EVERY trial."""
+    g = load_golden("rej")
+    assert g["n_trials"].tolist() == [9, 2, 3, 3, 4, 4, 4, 5, 6, 6, 1, 1, 1, 1, 1, 1, 9, 6, 6, 6]
+    n = g["states0"].shape[1]
+    for k in range(20):
+        dbg = {}
+        states, lam, last_h, ntr = _run(g, k, solver="banded", debug=dbg)
+        assert ntr == g["n_trials"][k] and lam == g["lamda_out"][k], k
+        assert rel_err(states, g[f"states_out_{k}"][0]) < 1e-8, k
+        assert rel_err(last_h, g[f"last_hessian_{k}"][0]) < 1e-10, k
+        if f"A_bands_{k}" in g:
+            assert len(dbg["trials"]) == ntr
+            for t in range(ntr):
+                assert rel_err(dbg["trials"][t]["A"], g[f"A_bands_{k}"][t]) < 1e-11, (k, t)
+                assert rel_err(dbg["trials"][t]["dpose"], g[f"dpose_{k}"][t].reshape(n, 9)) < 1e-7, (k, t)
+            assert rel_err(dbg["rhs"], g[f"JTr_{k}"][0].reshape(n, 9)) < 1e-9
+
+
+def test_c5_subwindow_pins_the_oracle_on_the_c5_orbit():
+    """the reference cannot run the 2000-pose config 5, but it can run its first 500 poses (3 s stride,
+    125 000 rows; tests/golden/c5s.npz from the reference's driver).  The oracle that the full C5 window is checked against
+    on the GPU reproduces all 20 calls of that sub-window: trial counts and lamda exact, states <= 1e-8."""
+    from vinsat_amd import od_pipe, synth
+    g = load_golden("c5s")
+    det, orb = synth.make_subwindow("C5", 500)
+    win = od_pipe.prepare_window(det, orb)
+    assert np.array_equal(win.time_idx, g["in_time_idx"])
+    assert np.array_equal(np.array([win.ii.size, win.ii.sum(), win.ii[0], win.ii[-1]]), g["in_ii_digest"])
+    st, lam = g["states0"][0], 1e-4
+    for k in range(20):
+        st, lam, _, ntr = O.ba_iteration(int(g["iters"][k]), st, win.cumrot_last, win.landmarks_uv, win.landmarks_xyz, win.ii,
+                                         win.time_idx, win.intrinsics, win.confidences, lam, initialize=bool(g["initialize"][k]),
+                                         solver="banded")
+        assert ntr == g["n_trials"][k] and lam == g["lamda_out"][k], k
+        if f"states_out_{k}" in g:
+            assert rel_err(st, g[f"states_out_{k}"][0]) < 1e-8, k

@@ -14,7 +14,7 @@ replaced by minimal equivalents before the import:
 ``torch_scatter`` (segment sum / mean, semantics fixed by the call sites
 ``BA_utils.py:1376-1382``) and ``ipdb`` (debugger hook, no-op).
 
-Usage: python tools/gen_golden.py [C1 C2 C3 C4 GAP HOP REGC1 REGC2 PRIORPROP]
+Usage: python tools/gen_golden.py [C1 C2 C3 C4 GAP HOP REGC1 REGC2 PRIORPROP REJ C5S]
 Outputs are data only (inputs + expected outputs), compressed .npz.
 """
 from __future__ import annotations
@@ -192,9 +192,15 @@ class Capture:
         self.od_pipe.BA = self._BA
 
 
-def run_config(name, od_pipe, baf, full_iters, store_inputs, store_states):
+def run_config(name, od_pipe, baf, full_iters, store_inputs, store_states, drop=()):
     if name == "GAP":
         det, orbit = synth.make_two_pass_sequence()
+    elif name == "REJ":
+        # confidences of 3 (> 1): the weighted trial residual (BA_filtering.py:66-69) no longer undercuts the unweighted
+        # initial one for free, so the LM loop of plain BA rejects trials (:72-77) -- 1 to 9 trials per call
+        det, orbit = synth.make_sequence("C2", seed=3, conf=3.0)
+    elif name == "C5S":
+        det, orbit = synth.make_subwindow("C5", 500)
     else:
         det, orbit = synth.make_sequence(name, seed=0)
     cap = Capture(od_pipe, baf, full_iters)
@@ -238,7 +244,7 @@ def run_config(name, od_pipe, baf, full_iters, store_inputs, store_states):
         k = c["call"]
         out[f"states_in_{k}"] = c["states_in"]
         for key in ("landmark_est", "Jg", "r_pred", "Jf_blocks", "Hq_bands", "qgrad"):
-            if key in c:
+            if key in c and key not in drop:
                 out[f"{key}_{k}"] = c[key]
         for key in ("Jf_offband", "Hq_offband"):
             if key in c:
@@ -247,7 +253,8 @@ def run_config(name, od_pipe, baf, full_iters, store_inputs, store_states):
         out[f"A_offband_{k}"] = np.array(c["A_offband"])
         out[f"JTr_{k}"] = np.stack(c["JTr"])
         out[f"dpose_{k}"] = np.stack(c["dpose"])
-        out[f"trial_est_{k}"] = np.stack(c["trial_est"])
+        if "trial_est" not in drop:
+            out[f"trial_est_{k}"] = np.stack(c["trial_est"])
         out[f"trial_r_pred_{k}"] = np.stack(c["trial_r_pred"])
     out["errors"] = errors.detach().numpy()
     out["first_detection"] = np.array(first_det)
@@ -407,6 +414,10 @@ PLAN = {
     "C3": dict(full_iters=(), store_inputs=False, store_states=(0, 9, 10, 14, 19)),
     "C4": dict(full_iters=(), store_inputs=False, store_states=(0, 9, 10, 14, 19)),
     "GAP": dict(full_iters=(), store_inputs=True, store_states="all"),
+    # plain BA with rejected trials: every LM trial's system / right-hand side / solution of calls with 2, 4, 6 and 9 trials
+    "REJ": dict(full_iters=(1, 5, 9, 16), store_inputs=True, store_states="all", drop=("landmark_est", "Jg", "Jf_blocks", "Hq_bands", "trial_est")),
+    # the first 500 poses of the C5 orbit (3 s stride, 250 observations per pose): SURVEY 8(c)(ii)
+    "C5S": dict(full_iters=(), store_inputs=False, store_states=(0, 9, 10, 14, 19)),
 }
 
 

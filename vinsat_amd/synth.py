@@ -153,6 +153,16 @@ def make_sequence(cfg: WindowConfig | str, seed: int = 0, pixel_noise: float = 1
     return det, orbit_np
 
 
+def make_subwindow(cfg: WindowConfig | str, n_poses: int, **kw):
+    """The first ``n_poses`` frames of a named configuration's sequence: the same orbit, the same detections, cut after
+    frame ``n_poses`` (orbit rows kept up to 5 s past the last frame, as :func:`make_sequence` does)."""
+    if isinstance(cfg, str):
+        cfg = CONFIGS[cfg]
+    det, orbit = make_sequence(cfg, **kw)
+    t_end = cfg.t0 + cfg.stride * n_poses
+    return det[det[:, 0] < t_end].copy(), orbit[: t_end + 5].copy()
+
+
 def make_two_pass_sequence(n_poses=12, obs_per_pose=6, stride=5, gap=1500, seed=4, pixel_noise=1.0, conf=0.95, tail=140):
     """Two ground-station-like passes separated by ``gap`` seconds without detections.
 
