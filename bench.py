@@ -194,11 +194,39 @@ def cpu_worker(seed, budget_s, config):
     sys.stdout.flush()
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, cut down to the cgroup CPU quota when there is one (a
+    GPU box shows every core of the host in the mask but grants a share of them)."""
+    cores = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    cores = min(cores, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
+
+
 def cpu_baseline(args):
     """The NumPy oracle (a structure-aware CPU port, NOT the reference's dense autograd path) on every host core of
     this box: one fresh single-threaded worker process per core, each over its own 500/50k window (the reference's
     outer loop over sequences is embarrassingly parallel).  Runs before this process touches the GPU."""
-    cores = args.cpu_cores or len(os.sched_getaffinity(0))
+    cores = args.cpu_cores
+    if not cores:
+        cores = usable_cores()
+        try:        # a GPU box grants about 16 host cores per GPU whatever its affinity mask shows; counting devices does not touch the GPU
+            import torch
+            cores = min(cores, 16 * max(1, torch.cuda.device_count()))
+        except Exception:
+            pass
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", NUMEXPR_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -228,7 +256,7 @@ def cpu_baseline(args):
     calls = sum(r["calls"] for r in res)
     rate = sum(r["calls"] / r["seconds"] for r in res)
     return {"value": rate, "unit": "BA iterations/s", "cores": cores, "kind": "port",
-            "per_core": rate / cores,
+            "per_core": rate / cores, "cores_in_affinity_mask": len(os.sched_getaffinity(0)),
             "sample": f"{calls} BA calls ({calls // 20} x the 20-call schedule) over {cores} independent 500/50k windows, one "
                       f"single-threaded NumPy fp64 oracle process per host core, {wall:.1f} s wall; the reference's own "
                       "dense-autograd path measured in the build container (8 vCPU, torch intra-op threads): 0.25 it/s over "

@@ -120,10 +120,22 @@ int vba_set_prior(vba_handle h, int on);
 
 /* Carried keys (default on).  The trial residual of an accepted LM trial (BA_filtering.py:61-66) is evaluated at
  * exactly the states the next BA call starts from (BA_filtering.py:12-21), so the trial kernel also leaves the |r|
- * keys, their exponent histogram and sum |r| of the next call on the device, and a call that follows another one
+ * keys, their histogram (see vba_set_warm_select) and sum |r| of the next call on the device, and a call that follows another one
  * without vba_set_states / uploads in between starts at the median select instead of re-reading every observation.
  * on == 0: every call recomputes them (same bits; for comparison). */
 int vba_set_key_carry(vba_handle h, int on);
+
+/* Warm select (default on).  The exact lower median of the 2m keys |r| (torch.median, BA_filtering.py:23) is found by
+ * radix select.  On carried keys the trial that produced them has already binned them into 2046 narrow bins around the
+ * median of its own call (consecutive calls move the median by a factor 0.3 .. 2.5), so ONE pass over the keys -- the
+ * compaction of the bin that holds the wanted rank -- replaces the two digit passes; the short list is ranked exactly as
+ * before.  If the wanted rank falls outside the binned range the call repeats its select with the exact digits (a
+ * "miss": counted by vba_warm_select_misses, same result either way).  In a chained schedule (vba_run_schedule) the
+ * warm pass of call c + 1 also evaluates the LM accept test of call c in its prologue, which removes the decide launch
+ * from the chain.  on == 0: every select takes the exact digit passes and every accept test its own launch (same bits).
+ * on == 2 (test knob): every warm select reports a miss, i.e. every carried call takes the repeat path. */
+int vba_set_warm_select(vba_handle h, int on);
+int vba_warm_select_misses(vba_handle h, int* count);
 
 /* Row pivoting inside the 9x9 diagonal blocks.  always == 0 (default): the blocks are eliminated without row
  * exchanges (the damped normal equations are positive definite up to a ~1e-6 non-symmetric term) while every pivot

@@ -1141,3 +1141,102 @@ def test_windows_of_different_length_pick_their_own_reduction_variant(chunk):
         single = run([i])[0]
         assert np.array_equal(batch[i][0], single[0]) and batch[i][1] == single[1], i
         assert np.isfinite(batch[i][0]).all()
+
+
+# ------------------------------------------------------------------------------------------------ warm select / folded accept test
+def _schedule_states(eng, st0, iters, inits, chained):
+    eng.set_states(st0, 1e-4)
+    if chained:
+        eng.run_schedule(iters, inits)
+    else:
+        for it, init in zip(iters, inits):
+            eng.step(it, init)
+    return eng.get_states()
+
+
+@pytest.mark.parametrize("confmode", ["golden", "rejections"])
+def test_warm_select_and_folded_accept_test_give_the_bits_of_the_exact_path(c2, confmode):
+    """Carried keys are selected in ONE warm pass whose prologue, in a chained schedule, is the accept test of the call
+    in front.  The median stays exact and the accept test is the same arithmetic, so: chained / stepped, warm / exact
+    digits, and a warm select forced to miss on every call (the repeat path) all end in identical bits -- also when calls
+    reject trials and exhaust lamda in the middle of the chain."""
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    conf = inp["conf"] if confmode == "golden" else np.full_like(inp["conf"], 3.0)
+    iters, inits = list(range(20)), [k < 10 for k in range(20)]
+    outs = {}
+    for name, warm, chained in (("exact-stepped", 0, False), ("exact-chained", 0, True), ("warm-stepped", 1, False),
+                                ("warm-chained", 1, True), ("miss-stepped", 2, False), ("miss-chained", 2, True)):
+        e = BAEngine(n, m)
+        e.set_warm_select(warm)
+        e.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
+        e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+        outs[name] = _schedule_states(e, g["states0"][0], iters, inits, chained)
+        misses = e.warm_select_misses()
+        assert (misses > 0) == (warm == 2), (name, misses)       # the golden / rejection windows never leave the warm range
+        e.close()
+    ref = outs["exact-stepped"]
+    for name, o in outs.items():
+        assert np.array_equal(o[0], ref[0]) and o[1] == ref[1] and o[3] == ref[3] and o[4] == ref[4], name
+    if confmode == "golden":
+        assert rel_err(ref[0], g["states_out_19"][0]) < 1e-7
+
+
+def test_warm_select_with_long_bins_and_ties():
+    """Keys that pile up in one warm bin (half of all residuals identical): the list is longer than what is ranked by
+    counting and goes through the radix digits of the in-bin offset; the median must still be the exact lower median."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    cfg = synth.WindowConfig("ties", 24, 400, 5)
+    det, orb = synth.make_sequence(cfg, seed=5, pixel_noise=0.0)
+    win = od_pipe.prepare_window(det, orb)
+    uv = win.landmarks_uv.copy()
+    uv[::2] += 0.75                    # every second row is off by exactly the same amount in both components
+    n, m = win.time_idx.size, win.ii.size
+    st = win.states_gt.copy()
+    outs = []
+    for warm in (0, 1):
+        e = BAEngine(n, m)
+        e.set_warm_select(warm)
+        e.upload_observations(win.landmarks_xyz, uv, win.confidences, win.ii, n)
+        e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+        e.set_states(st, 1e-4)
+        meds = []
+        for it in (5, 6, 7, 8):
+            e.step(it, True)
+            sc = e.debug("scalars")
+            a = np.abs(uv - e.debug("est")).reshape(-1)
+            assert sc[0] == np.sort(a)[(a.size - 1) // 2]       # exact lower median of the device's own residuals
+            meds.append(sc[0])
+        outs.append((e.get_states(), meds))
+        e.close()
+    assert np.array_equal(outs[0][0][0], outs[1][0][0]) and outs[0][1] == outs[1][1]
+
+
+def test_many_windows_per_launch_agree_with_single_window_runs():
+    """From 16 windows per handle on, the bandwidth-mode kernels take over (assembly through memory, one wave per chain,
+    dynamics on a second stream): 20 windows of different data, chained 20 calls, against one-window handles (latency-mode
+    kernels) -- trial counts and lamda exact, states to rounding."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    cfg = synth.WindowConfig("w20", 40, 30, 5)
+    wins = [od_pipe.prepare_window(*synth.make_sequence(cfg, seed=s)) for s in range(20)]
+    n, m = wins[0].time_idx.size, wins[0].ii.size
+    iters, inits = list(range(20)), [k < 10 for k in range(20)]
+    big = BAEngine(n, m, windows=len(wins))
+    for k, w in enumerate(wins):
+        big.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, n, window=k)
+        big.upload_window(w.intrinsics, w.cumrot_last, w.time_idx, window=k)
+        big.set_states(od_pipe.initial_guess(w, seed=k), 1e-4, window=k)
+    big.run_schedule(iters, inits)
+    for k, w in enumerate(wins):
+        e = BAEngine(n, m)
+        e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, n)
+        e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx)
+        ref = _schedule_states(e, od_pipe.initial_guess(w, seed=k), iters, inits, True)
+        e.close()
+        got = big.get_states(window=k)
+        assert got[3] == ref[3] and got[1] == ref[1] and got[4] == ref[4], k
+        assert rel_err(got[0], ref[0]) < 1e-9, k
+    big.close()

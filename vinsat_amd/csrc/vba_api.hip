@@ -65,6 +65,9 @@ struct vba_context {
     double* h_stage = nullptr;              // pinned staging for vba_set_states: [n_max * 10 + 1]
     double* h_back = nullptr;               // pinned staging for vba_get_states: [n_max * 10] + one WinScalars
     bool back_valid = false;                // h_back holds window 0's states and scalars after the last step (vba_iterate)
+    double* S[2] = {nullptr, nullptr};      // the two state buffers [W][n_max][10]; S[par] is the input of the next call
+    int par = 0;                            // parity of the next call (WinScalars: what a call hands on lives in the slots of the reader's parity)
+    bool need_hist_reset = false;           // a call was abandoned half way: its histograms may be dirty
     hipEvent_t ev_stage = nullptr;          // the last staged copy has left the staging buffer
     std::vector<int> n, m;
     std::vector<char> have_obs, have_win, have_state, have_prior;
@@ -75,7 +78,8 @@ struct vba_context {
     bool stepped = false;
     bool carry_ok = false;          // every window's keys / histogram / sum |r| for its current states are on the device (k_trial<true>)
     bool carry_enabled = true;
-    bool hist_dirty = false;        // a k_trial<true> has left an exponent histogram behind that nobody consumed
+    bool hist_dirty = false;        // a k_trial<true> has left a warm histogram (digit-0 slot of parity `par`) behind that nobody consumed
+    int warm_enabled = 1;           // carried keys are selected with the one-pass warm select (vba_set_warm_select; 2: forced misses, test knob)
     int last_iter = 0, last_init = 0;
     int sh_pivot = 0;                       // sharded mode: solver variant of the current call (0 unpivoted, 2 mixed after a failed check)
     int pack_min = 1 << 30;                 // windows from which three chains share a wavefront: never by default (measured at 1024 / 2048 / 4096
@@ -84,6 +88,7 @@ struct vba_context {
     int no_pack = 0;                        // diagnostic: force one window per wavefront in the sequential driver
     int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
+    int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
     size_t dbg_cap = 0;
 };
@@ -139,7 +144,7 @@ extern "C" {
 int vba_set_accumulate_lanes(vba_handle h, int lanes);
 int vba_set_solver(vba_handle h, int chunk);
 
-int vba_version(void) { return 100; }
+int vba_version(void) { return 200; }
 
 const char* vba_last_error(void) { return g_err.c_str(); }
 
@@ -176,11 +181,13 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     const size_t m_pad = (M + 31) & ~size_t(31);
     const size_t obs_stride = (6 * m_pad + m_pad / 2 + (N + 2) / 2 + 31) & ~size_t(31);     // doubles
     need(W * obs_stride * 8);
-    need(W * N * 10 * 8); need(W * N * 10 * 8); need(W * N * 10 * 8);
+    need(W * N * 10 * 8); need(W * N * 10 * 8);
     need(W * N * 4 * 8); need(W * N * 4 * 8); need(W * N * 4);
+    const int nblk_pred = (int)((N * kDynLanes + 255) / 256);
+    need(W * nblk_pred * 8); need(W * nblk_pred * 8); need(W * 81 * 8);
     need(W * N * 36 * 8); need(W * N * 6 * 8);
     need(W * 2 * M * 8); need(W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * (nblk_obs + nblk_dyn) * 8); need(W * nblk_obs * 8);
-    need(W * kSelPasses * kSelBins * 4);
+    need(W * kHistStride * 4);
     const size_t per_pose = 21 + 6 + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
     need(W * N * per_pose * 8 + 16 * 256);
     need(W * N * 171 * 8);
@@ -209,7 +216,10 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.ox = h->d_obs; V.oy = V.ox + m_pad; V.oz = V.oy + m_pad; V.ou = V.oz + m_pad; V.ov = V.ou + m_pad; V.oconf = V.ov + m_pad;
     V.opose = reinterpret_cast<const int*>(V.oconf + m_pad);
     V.pose_ptr = V.opose + m_pad;
-    V.states = A.take<double>(W * N * 10); V.states_new = A.take<double>(W * N * 10); V.states_prev = A.take<double>(W * N * 10);
+    h->S[0] = A.take<double>(W * N * 10); h->S[1] = A.take<double>(W * N * 10);
+    V.states = V.states_prev = h->S[0]; V.states_new = h->S[1];
+    V.part_pred = A.take<double>(W * nblk_pred); V.part_prior = A.take<double>(W * nblk_pred); V.nblk_pred = nblk_pred;
+    V.lastD = A.take<double>(W * 81);
     V.intr = h->d_intr = A.take<double>(W * N * 4);
     V.cumrot = h->d_cumrot = A.take<double>(W * N * 4);
     V.steps = h->d_steps = A.take<int>(W * N);
@@ -220,7 +230,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.acc_lanes = 8;    // set after construction by vba_set_accumulate_lanes(h, 0)
     V.part_init = A.take<double>(W * nblk_obs); V.part_trial = A.take<double>(W * (nblk_obs + nblk_dyn));
     V.part_next = A.take<double>(W * nblk_obs);
-    V.hist = A.take<unsigned>(W * kSelPasses * kSelBins);
+    V.hist = A.take<unsigned>(W * kHistStride);
     V.Hraw = A.take<double>(W * N * 21); V.braw = A.take<double>(W * N * 6);
     V.xhat = A.take<double>(W * N * 6); V.Phi = A.take<double>(W * N * 36); V.rorb = A.take<double>(W * N * 6);
     V.fatt = A.take<double>(W * N); V.qgrad = A.take<double>(W * N * 3);
@@ -236,10 +246,16 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.rx2 = A.take<double>(W * PM * 9);
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
     V.hop = 0; V.pivot = 0; V.call = -1; V.emit = 0; V.carry = 0; V.dyn_in_acc = 0;
+    V.par = 0; V.fold = 0; V.redo = 0; V.fused_trial = 0; V.pending_only = 0; V.warm_force_miss = 0;
+    V.lat = windows < 16 ? 1 : 0;       // latency mode: few windows cannot fill the chip, the kernel COUNT of a call is what costs
+    // warm bins: 2^44 bit patterns (1/256 of a binade, range [c/16, c*8)) while a bin of the median's density stays short,
+    // 2^43 (1/512, [c/4, c*2)) for the big windows
+    V.warm_shift = 2 * m_max <= 300000 ? 44 : 43;
     V.chunk = 0; V.chunk2 = 0;      // set after construction by vba_set_solver(h, -1)
     {   // every device array a kernel may touch must have been carved: a null here would fault on the GPU
         const void* must[] = {V.n, V.m, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
                               V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.prior_H, V.prior_x, V.absr, V.wraw, V.ckeys, V.part_init, V.part_next,
+                              V.part_pred, V.part_prior, V.lastD,
                               V.part_trial, V.hist, V.Hraw, V.braw, V.xhat, V.Phi, V.rorb, V.fatt, V.qgrad, V.Hd, V.Hu, V.Hl,
                               V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx, V.csol2, V.cL2, V.cR2, V.rx2};
         bool ok = A.used <= A.size;
@@ -375,6 +391,18 @@ int vba_set_key_carry(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     h->carry_enabled = on != 0;
     h->carry_ok = false;
+    return VBA_OK;
+}
+
+int vba_set_warm_select(vba_handle h, int on) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    h->warm_enabled = on == 2 ? 2 : (on != 0);
+    return VBA_OK;
+}
+
+int vba_warm_select_misses(vba_handle h, int* count) {
+    if (!h || !count) return fail(VBA_EINVAL, "null argument");
+    *count = h->warm_misses;
     return VBA_OK;
 }
 
@@ -514,6 +542,7 @@ int vba_set_states(vba_handle h, int window, const double* states, double lamda)
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (!states) return fail(VBA_EINVAL, "null states");
     h->carry_ok = false;
+    double* S = h->S[h->par];           // the input buffer of the next call
     if (window == -1) {     // the same states for every window (all windows must have the same number of poses)
         const int n = h->n[0];
         for (int w = 0; w < h->W; ++w) {
@@ -521,11 +550,15 @@ int vba_set_states(vba_handle h, int window, const double* states, double lamda)
             if (h->n[w] != n) return fail(VBA_EINVAL, "window = -1 needs equal pose counts");
         }
         HIPCHK(hipSetDevice(h->device));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemcpy(h->V.states, states, (size_t)n * 80, hipMemcpyHostToDevice));
-        launch_broadcast_states(h->V, n, lamda, h->stream);
+        HIPCHK(hipEventSynchronize(h->ev_stage));
+        std::memcpy(h->h_stage, states, (size_t)n * 80);
+        HIPCHK(hipMemcpyAsync(S, h->h_stage, (size_t)n * 80, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipEventRecord(h->ev_stage, h->stream));
+        DevView V = h->V;
+        V.states = S;
+        V.par = h->par;
+        launch_broadcast_states(V, n, lamda, h->stream);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(h->stream));
         for (int w = 0; w < h->W; ++w) h->have_state[w] = 1;
         return VBA_OK;
     }
@@ -539,11 +572,19 @@ int vba_set_states(vba_handle h, int window, const double* states, double lamda)
     HIPCHK(hipEventSynchronize(h->ev_stage));
     std::memcpy(h->h_stage, states, (size_t)n * 80);
     h->h_stage[(size_t)h->n_max * 10] = lamda;
-    HIPCHK(hipMemcpyAsync(h->V.states + (size_t)window * h->n_max * 10, h->h_stage, (size_t)n * 80, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(&h->V.sc[window].lamda, h->h_stage + (size_t)h->n_max * 10, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(S + (size_t)window * h->n_max * 10, h->h_stage, (size_t)n * 80, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(&h->V.sc[window].lam[h->par], h->h_stage + (size_t)h->n_max * 10, 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipEventRecord(h->ev_stage, h->stream));
     h->have_state[window] = 1;
     return VBA_OK;
+}
+
+// what a finished call left in the window's scalars, seen from the parity `par` of the NEXT call
+static void unpack_scalars(const WinScalars* sc, int par, double* lamda, double* last_hessian, int* n_trials, unsigned* flags) {
+    if (lamda) *lamda = sc->lam[par];
+    if (last_hessian) std::memcpy(last_hessian, sc->last_hessian, 81 * 8);
+    if (n_trials) *n_trials = sc->n_trials;
+    if (flags) *flags = sc->fl[par ^ 1] & 7u;       // the public bits (vinsat_ba.h)
 }
 
 int vba_get_states(vba_handle h, int window, double* states, double* lamda, double* last_hessian, int* n_trials,
@@ -554,16 +595,151 @@ int vba_get_states(vba_handle h, int window, double* states, double* lamda, doub
     const int n = h->n[window];
     // both pieces through pinned memory behind the queued work, one wait for the lot
     WinScalars* sc = reinterpret_cast<WinScalars*>(h->h_back + (size_t)h->n_max * 10);
-    if (states) HIPCHK(hipMemcpyAsync(h->h_back, h->V.states + (size_t)window * h->n_max * 10, (size_t)n * 80, hipMemcpyDeviceToHost, h->stream));
+    if (states) HIPCHK(hipMemcpyAsync(h->h_back, h->S[h->par] + (size_t)window * h->n_max * 10, (size_t)n * 80, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(sc, h->V.sc + window, sizeof(WinScalars), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (states) std::memcpy(states, h->h_back, (size_t)n * 80);
-    if (lamda) *lamda = sc->lamda;
-    if (last_hessian) std::memcpy(last_hessian, sc->last_hessian, 81 * 8);
-    if (n_trials) *n_trials = sc->n_trials;
-    if (flags) *flags = sc->flags;
+    unpack_scalars(sc, h->par, lamda, last_hessian, n_trials, flags);
     return VBA_OK;
 }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- one BA() call
+// The kernels of a call, as the host enqueues them (all asynchronous on the handle's stream):
+//
+//   front   [k_obs_residual]                     only when the host replaced the states (no carried keys)
+//           select                               exact digits (2 passes; 3 when digit 0 is not there yet), or on carried
+//                                                keys ONE warm pass (k_select_warm) -- whose prologue, in a chained
+//                                                schedule, is the accept test of the call in front (fold)
+//           k_obs_accumulate (+ dynamics blocks) median finish, weights, per-pose normal equations [+ orbit / attitude factor]
+//           [k_assemble]                         only when something reads the bands from memory: batched windows, sharded
+//                                                mode, the sequential / always-pivoting solvers
+//   trial   [solve]                              full phase: chunk elimination (forming its own blocks in latency mode),
+//                                                cyclic reduction of the separators; landmark-only phase: nothing in
+//                                                latency mode (the trial kernel solves its 6x6 systems itself)
+//           k_trial                              step + retraction (latency mode) + trial residuals + next call's keys
+//   decide  [k_decide]                           own launch unless the next call's first kernel folds it
+//
+// Latency mode, landmark-only call: 3 kernels (warm select, accumulate, trial); full call: 6 (+ chunks, two
+// cyclic-reduction kernels).  Call parity p: input states S[p], trial states S[p ^ 1] (see WinScalars).
+struct CallSpec {
+    int iter = 0, initialize = 0;
+    int call = -1;          // index inside a chained schedule, -1: stand-alone
+    int par = 0;
+    bool carry = false;     // the keys of the input states are on the device
+    bool emit = false;      // leave the next call's keys behind
+    bool fold = false;      // first kernel evaluates the accept test of call - 1
+    bool prof = false;      // serialised schedule with an event between kernel classes
+};
+
+struct CallCtx {
+    DevView V;
+    bool fuse_assemble = false;     // first trial's landmark-only solve rides in k_assemble<true> (batched windows)
+    bool assembled = false;         // bands / rhs are in memory
+};
+
+void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
+    V = h->V;
+    V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
+    V.reg = h->reg ? 1 : 0;
+    V.n_min = *std::min_element(h->n.begin(), h->n.end());
+    V.call = c.call;
+    V.par = c.par;
+    V.states = h->S[c.par];
+    V.states_new = h->S[c.par ^ 1];
+    V.states_prev = h->S[c.par];
+    V.emit = c.emit ? 1 : 0;
+    V.carry = c.carry ? 1 : 0;
+    V.fold = c.fold ? 1 : 0;
+    V.redo = 0;
+    V.pending_only = 0;
+    V.warm_force_miss = h->warm_enabled == 2;
+    V.pivot = h->pivot_mode;
+    V.pack = 0;
+    if (V.chunk <= 0 && h->W >= h->pack_min && !h->no_pack) {
+        V.pack = 1;
+        for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
+    }
+    fill_params(V.prm, c.iter, c.initialize);
+    // who forms the step: latency mode lets the trial kernel do it (landmark-only: 6x6 solve per pose on the unpivoted
+    // path; full phase: recovery of the partitioned solve)
+    V.fused_trial = 0;
+    if (V.lat) {
+        if (c.initialize) V.fused_trial = h->pivot_mode == 0 ? 1 : 0;
+        else if (V.chunk > 0) V.fused_trial = 2;
+    }
+}
+
+// the kernels in front of the first LM trial; ev (profiled variant): events that bracket the kernel classes
+int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat, hipEvent_t* ev) {
+    DevView& V = C.V;
+    hipStream_t s = h->stream;
+    auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], s); };
+    const bool init = c.initialize != 0;
+    // the dynamics factor depends only on the states: with few windows its blocks ride in the accumulation's grid (no
+    // second stream, no cross-stream join), with many it runs beside the observation kernels on a second stream
+    const bool ride = !init && !c.prof && h->W < 16;
+    V.dyn_in_acc = ride ? 1 : 0;
+    const bool overlap = !init && !c.prof && !ride;
+    if (overlap) {
+        HIPCHK(hipEventRecord(h->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+        launch_dynamics(V, h->aux_stream);
+        HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
+    }
+    mark(1);
+    if (!c.carry) {
+        launch_obs_residual(V, nullptr, s);
+        mark(2);
+        launch_select(V, false, s);
+    } else if (h->warm_enabled && !exact_repeat) {
+        mark(2);
+        launch_select_warm(V, s);
+    } else {            // carried keys, exact digits: the digit-0 slot holds a warm histogram (or nothing): rebuild it by exponent
+        mark(2);
+        launch_clear_hist(V, exact_repeat ? 2 : 0, s);
+        launch_select(V, true, s);
+    }
+    mark(3);
+    launch_obs_accumulate(V, s);
+    mark(4);
+    if (!init && !overlap && !ride) launch_dynamics(V, s);
+    if (overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+    mark(5);
+    C.fuse_assemble = init && h->pivot_mode == 0 && !V.lat;
+    C.assembled = false;
+    const bool need_bands = init ? V.fused_trial != 1 : !solve_forms_blocks(V);
+    if (need_bands) {
+        launch_assemble(V, C.fuse_assemble, s);
+        C.assembled = true;
+    }
+    mark(6);
+    return VBA_OK;
+}
+
+// one LM trial: solve (unless the trial kernel or the assembly formed the step) + trial residuals
+void enqueue_trial(vba_handle h, CallCtx& C, const CallSpec& c, bool first) {
+    DevView& V = C.V;
+    hipStream_t s = h->stream;
+    const bool init = c.initialize != 0;
+    if (init) {
+        const bool pivoted_round = V.pivot != 0;
+        if (V.fused_trial == 1) {
+            if (pivoted_round) {        // some window fell back to the pivoted kernels, which read the diagonal blocks from memory
+                if (!C.assembled) { launch_assemble(V, 0, s); C.assembled = true; }
+                launch_solve(V, 1, s);
+            }
+        } else if (!(first && C.fuse_assemble)) {
+            launch_solve(V, 1, s);
+        }
+    } else {
+        launch_solve(V, 0, s);
+    }
+    launch_trial(V, s);
+}
+
+}  // namespace
 
 // readback >= 0: the states and scalars of that window are copied to the pinned read-back buffer right behind the first
 // trial (valid if that trial ends the call: h->back_valid), so that vba_iterate needs one wait instead of two.
@@ -572,16 +748,23 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    DevView V = h->V;
-    V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
-    V.reg = h->reg ? 1 : 0;
-    V.n_min = *std::min_element(h->n.begin(), h->n.end());
-    V.emit = h->carry_enabled && emit ? 1 : 0;
-    V.carry = h->carry_enabled && h->carry_ok ? 1 : 0;
+    CallSpec c;
+    c.iter = iter; c.initialize = initialize; c.call = -1; c.par = h->par;
+    c.emit = h->carry_enabled && emit;
+    c.carry = h->carry_enabled && h->carry_ok;
+    c.prof = prof != nullptr;
     h->carry_ok = false;
-    if (!V.carry && h->hist_dirty) launch_clear_hist0(V, s);     // the states were replaced after the last trial
-    h->hist_dirty = V.emit != 0;
-    fill_params(V.prm, iter, initialize);
+    CallCtx C;
+    view_for_call(h, C.V, c);
+    DevView& V = C.V;
+    if (h->need_hist_reset) {       // an abandoned call may have left counts in any histogram
+        DevView Q = V;
+        for (int p = 0; p < 2; ++p) { Q.par = p; launch_clear_hist(Q, 1, s); }
+        h->need_hist_reset = false;
+        h->hist_dirty = false;
+    }
+    if (!c.carry && h->hist_dirty) launch_clear_hist(V, 0, s);     // the states were replaced after the last trial
+    h->hist_dirty = c.emit;
     struct ProfEvents {         // destroyed on every exit path, error returns included
         hipEvent_t e[VBA_NKERNELS + 1] = {};
         ~ProfEvents() { for (hipEvent_t q : e) if (q) (void)hipEventDestroy(q); }
@@ -591,67 +774,52 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
         for (int k = 0; k <= VBA_NKERNELS; ++k) HIPCHK(hipEventCreate(&ev[k]));
     }
     auto mark = [&](int k) { if (prof) (void)hipEventRecord(ev[k], s); };
+    struct Abandon {            // any error return below leaves a half-run call behind
+        vba_handle h; bool armed = true;
+        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = false; } }
+    } abandon{h};
     HIPCHK(hipEventRecord(h->ev0, s));
     mark(0);
-    mark(1);
-    // the dynamics factor depends only on the states: it runs beside the observation pipeline on a second stream
-    // ... or, with few windows, inside the accumulation's grid (no cross-stream join in front of the assembly)
-    const bool ride = !initialize && !prof && h->W < 16;
-    V.dyn_in_acc = ride ? 1 : 0;
-    const bool overlap = !initialize && !prof && !ride;
-    if (overlap) {
-        HIPCHK(hipEventRecord(h->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-        launch_dynamics(V, h->aux_stream);
-        HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
-    }
-    if (!V.carry) launch_obs_residual(V, nullptr, s);
-    mark(2);
-    launch_select(V, s);
-    mark(3);
-    launch_obs_accumulate(V, s);
-    mark(4);
-    if (!initialize && !overlap && !ride) launch_dynamics(V, s);
-    if (overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
-    mark(5);
-    // landmark-only phase on the unpivoted path: the first trial's per-pose 6x6 solve + retraction ride in k_assemble
-    const bool fuse = initialize && h->pivot_mode == 0;
-    launch_assemble(V, fuse, s);
-    mark(6);
-    // LM loop (BA_filtering.py:52-77): lamda 1e-4 .. 1e4 in decades, at most 9 trials
-    int rc_out = VBA_OK;
-    V.pivot = h->pivot_mode;
-    V.pack = 0;
-    if (V.chunk <= 0 && h->W >= h->pack_min && !h->no_pack) {
-        V.pack = 1;
-        for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
-    }
-    // lamda runs 1e-4 .. 1e4 in decades (at most 9 trials) plus one repeat per window for a pivoted fallback; a loop
-    // that is still not done after kMaxTrials means the device never reported an outcome (a fault, a skipped window)
+    if (int rc = enqueue_front(h, C, c, false, prof ? ev : nullptr)) return rc;
+    // LM loop (BA_filtering.py:52-77): lamda runs 1e-4 .. 1e4 in decades (at most 9 trials), plus one repeat per window for a
+    // pivoted fallback and one for a missed warm select; a loop that is still not done after kMaxTrials means the device
+    // never reported an outcome (a fault, a skipped window)
     constexpr int kMaxTrials = 24;
-    bool finished = false;
+    bool finished = false, first = true;
     for (int trial = 0; trial < kMaxTrials; ++trial) {
-        if (!(trial == 0 && fuse)) launch_solve(V, initialize, s);
-        if (trial == 0) mark(7);
-        launch_trial(V, s);
-        if (trial == 0) mark(8);
+        enqueue_trial(h, C, c, first);
+        if (first) { mark(7); }
+        if (first) mark(8);
         launch_decide(V, nullptr, 0, s);
-        if (trial == 0) {
+        if (first) {
             mark(9);
             HIPCHK(hipEventRecord(h->ev1, s));
         }
         h->back_valid = false;
-        if (readback >= 0) {
-            HIPCHK(hipMemcpyAsync(h->h_back, V.states + (size_t)readback * h->n_max * 10, (size_t)h->n[readback] * 80, hipMemcpyDeviceToHost, s));
+        if (readback >= 0) {    // the trial states ARE the result if this trial ends the call
+            HIPCHK(hipMemcpyAsync(h->h_back, V.states_new + (size_t)readback * h->n_max * 10, (size_t)h->n[readback] * 80, hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(h->h_back + (size_t)h->n_max * 10, V.sc + readback, sizeof(WinScalars), hipMemcpyDeviceToHost, s));
         }
         HIPCHK(hipGetLastError());
-        if (int rc = read_heads(h)) { rc_out = rc; break; }
-        bool all = true, repeat = false;
+        if (int rc = read_heads(h)) return rc;
+        first = false;
+        bool all = true, repeat = false, miss = false;
         for (int w = 0; w < h->W; ++w) {
             all = all && head(h, w)->done;
             repeat = repeat || (head(h, w)->flags & 8u);
+            miss = miss || (head(h, w)->flags & 32u);
         }
+        if (miss) {     // the warm select missed for some window: those repeat the call's front with the exact digits
+            for (int w = 0; w < h->W; ++w) if (head(h, w)->flags & 32u) h->h_head[w].flags = 0;
+            h->warm_misses++;
+            V.redo = 1;
+            CallSpec cr = c;
+            cr.prof = false;
+            if (int rc = enqueue_front(h, C, cr, true, nullptr)) return rc;
+            V.redo = 2;             // this round: their first trial, the others' next one (the solve is launched for both)
+            continue;
+        }
+        V.redo = 0;
         if (repeat && V.pivot == 0) {   // a pivot check failed on the fast path: those windows repeat the trial with row pivoting
             V.pivot = 2;
             h->fallbacks++;
@@ -663,25 +831,19 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
             break;
         }
     }
-    if (rc_out == VBA_OK && !finished) {
-        h->have_state.assign(h->W, 0);          // half-finished trial states must not be read back as a result
-        rc_out = fail(VBA_ESTATE, "LM loop did not terminate within " + std::to_string(kMaxTrials) + " trials (no outcome reported by the device)");
-    }
-    if (rc_out == VBA_OK) HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    if (!finished)
+        return fail(VBA_ESTATE, "LM loop did not terminate within " + std::to_string(kMaxTrials) + " trials (no outcome reported by the device)");
+    abandon.armed = false;
+    HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
     if (prof) {
         for (int k = 0; k < VBA_NKERNELS; ++k) {
             prof[k] = 0.f;
-            if (rc_out == VBA_OK) (void)hipEventElapsedTime(&prof[k], ev[k], ev[k + 1]);
+            (void)hipEventElapsedTime(&prof[k], ev[k], ev[k + 1]);
         }
-        if (fuse) prof[VBA_K_SOLVE] = 0.f;              // first trial of a landmark-only call: solved inside k_assemble<true>
-        if (V.carry) prof[VBA_K_RESIDUAL] = 0.f;        // not launched: the previous trial left the keys behind
+        if (c.carry) prof[VBA_K_RESIDUAL] = 0.f;        // not launched: the previous trial left the keys behind
     }
-    if (rc_out != VBA_OK) return rc_out;
-    {
-        bool all = V.emit != 0;
-        for (int w = 0; w < h->W; ++w) all = all && head(h, w)->done;
-        h->carry_ok = all;
-    }
+    h->par ^= 1;                    // the trial buffer is the next call's input
+    h->carry_ok = c.emit;
     h->stepped = true;
     h->last_iter = iter;
     h->last_init = initialize;
@@ -691,106 +853,133 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
 int vba_step(vba_handle h, int iter, int initialize) { return step_impl(h, iter, initialize, nullptr); }
 
 // The 20-call loop of the driver (od_pipe.py:1036-1040) as ONE host call.  The kernels of every call are enqueued
-// back to back with a single LM trial each; a window whose first trial is rejected (or whose unpivoted solve
-// fails its check) does not advance its device-side call counter, all later kernels skip it, and the host
-// finishes that call the ordinary way before re-enqueuing the rest.  Results are identical to ncalls vba_step calls.
+// back to back with a single LM trial each and, on carried keys, without a decide launch between them: the first kernel
+// of call c + 1 evaluates the accept test of call c itself.  A window whose first trial is not cleanly accepted (rejected,
+// pivot check failed) or whose warm select misses does not advance its device-side call counter, all later kernels skip
+// it, and the host finishes that call the ordinary way before re-enqueuing the rest.  Results are identical to ncalls
+// vba_step calls.
 int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* inits, int* trials_total) {
     if (!h || !iters || !inits || ncalls < 1) return fail(VBA_EINVAL, "bad argument");
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    DevView V = h->V;
-    V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
-    V.pack = 0;
-    if (V.chunk <= 0 && h->W >= h->pack_min && !h->no_pack) {
-        V.pack = 1;
-        for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
-    }
-    V.reg = h->reg ? 1 : 0;
-    V.n_min = *std::min_element(h->n.begin(), h->n.end());
-    V.emit = h->carry_enabled ? 1 : 0;
-    bool carry = h->carry_enabled && h->carry_ok;
+    const int par0 = h->par;
+    bool carry0 = h->carry_enabled && h->carry_ok;
     h->carry_ok = false;
-    if (!carry && h->hist_dirty) launch_clear_hist0(V, s);
-    h->hist_dirty = V.emit != 0;
-    launch_reset_calls(V, s);
+    struct Abandon {
+        vba_handle h; bool armed = true;
+        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = false; } }
+    } abandon{h};
+    auto spec = [&](int c, bool fold) {
+        CallSpec q;
+        q.iter = iters[c]; q.initialize = inits[c]; q.call = c; q.par = (par0 + c) & 1;
+        q.carry = c == 0 ? carry0 : h->carry_enabled;       // every later call starts from a trial of this chain
+        q.emit = h->carry_enabled;
+        q.fold = fold;
+        return q;
+    };
+    {
+        DevView V0;
+        view_for_call(h, V0, spec(0, false));
+        if (h->need_hist_reset) {
+            DevView Q = V0;
+            for (int p = 0; p < 2; ++p) { Q.par = p; launch_clear_hist(Q, 1, s); }
+            h->need_hist_reset = false;
+            h->hist_dirty = false;
+        }
+        if (!carry0 && h->hist_dirty) launch_clear_hist(V0, 0, s);
+        launch_reset_calls(V0, s);
+    }
+    h->hist_dirty = h->carry_enabled;
     for (int w = 0; w < h->W; ++w) { h->h_head[w].call_idx = 0; h->h_head[w].done = 0; h->h_head[w].flags = 0; }
     long trials = 0;
     int next = 0;
-    std::vector<char> call_carry((size_t)ncalls, 0);    // whether call c starts from carried keys
+    bool complete = false;
     for (int guard = 0; guard <= ncalls; ++guard) {
         // speculative part: calls next .. ncalls-1, one trial each
         for (int c = next; c < ncalls; ++c) {
-            V.call = c;
-            V.pivot = h->pivot_mode;
-            V.carry = carry ? 1 : 0;
-            call_carry[c] = (char)V.carry;
-            carry = h->carry_enabled;       // every later call starts from a trial of this chain
-            fill_params(V.prm, iters[c], inits[c]);
-            const bool ride = !inits[c] && h->W < 16;      // dynamics inside the accumulation's grid
-            V.dyn_in_acc = ride ? 1 : 0;
-            const bool dyn = !inits[c] && !ride;
-            if (dyn) {
-                HIPCHK(hipEventRecord(h->ev_fork, s));
-                HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-                launch_dynamics(V, h->aux_stream);
-                HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
-            }
-            if (!V.carry) launch_obs_residual(V, nullptr, s);
-            launch_select(V, s);
-            launch_obs_accumulate(V, s);
-            if (dyn) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
-            const bool fuse = inits[c] && h->pivot_mode == 0;
-            launch_assemble(V, fuse, s);
-            if (!fuse) launch_solve(V, inits[c], s);
-            launch_trial(V, s);
-            launch_decide(V, nullptr, 0, s);
+            const bool fold = c > next && h->carry_enabled && h->warm_enabled;      // call c-1 of this pass left its decision to us
+            const CallSpec q = spec(c, fold);
+            CallCtx C;
+            view_for_call(h, C.V, q);
+            if (fold) fill_params(C.V.prev, iters[c - 1], inits[c - 1]);
+            if (int rc = enqueue_front(h, C, q, false, nullptr)) return rc;
+            enqueue_trial(h, C, q, true);
+            const bool next_folds = c + 1 < ncalls && h->carry_enabled && h->warm_enabled;
+            if (!next_folds) launch_decide(C.V, nullptr, 0, s);
         }
         HIPCHK(hipGetLastError());
         if (int rc = read_heads(h)) return rc;
         trials += (long)(ncalls - next);
-        // After a pass over calls next .. ncalls-1 every window whose counter is below ncalls is stalled AT that call
-        // (its first trial was rejected or its unpivoted solve failed the check).  Every stalled call is finished with
-        // the ordinary LM loop -- each one, not only the earliest: a window left at a later call would otherwise run
-        // that call again from its start when the chain is re-issued.
+        // After a pass over calls next .. ncalls-1 every window whose counter is below ncalls is stalled AT that call.
+        // Every stalled call is finished with the ordinary LM loop -- each one, not only the earliest: a window left at a
+        // later call would otherwise run that call again from its start when the chain is re-issued.
         std::vector<int> stalled;
         for (int w = 0; w < h->W; ++w) {
             const int c = (int)head(h, w)->call_idx;
             if (c < ncalls && std::find(stalled.begin(), stalled.end(), c) == stalled.end()) stalled.push_back(c);
         }
-        if (stalled.empty()) break;
+        if (stalled.empty()) { complete = true; break; }
         std::sort(stalled.begin(), stalled.end());
         for (int sc_call : stalled) {
-            V.call = sc_call;
-            V.pivot = h->pivot_mode;
-            V.carry = call_carry[sc_call];
-            fill_params(V.prm, iters[sc_call], inits[sc_call]);
+            const CallSpec q = spec(sc_call, false);
+            CallCtx C;
+            view_for_call(h, C.V, q);
+            DevView& V = C.V;
+            // the front of this call has run (for the windows that reached it); what is on the device of it:
+            C.fuse_assemble = q.initialize && h->pivot_mode == 0 && !V.lat;
+            C.assembled = q.initialize ? V.fused_trial != 1 : !solve_forms_blocks(V);
+            auto at_call = [&](int w) { return head(h, w)->call_idx == sc_call; };
+            bool any_miss = false;
+            for (int w = 0; w < h->W; ++w) any_miss = any_miss || (at_call(w) && (head(h, w)->flags & 32u));
+            // (1) the first trial of the windows that got that far has been evaluated but not decided (the decision was left
+            //     to the next call's first kernel, which found it not clean): decide it now
+            V.pending_only = 1;
+            launch_decide(V, nullptr, 0, s);
+            V.pending_only = 0;
+            // (2) windows whose warm select missed repeat the front with the exact digits and run their first trial
+            if (any_miss) {
+                for (int w = 0; w < h->W; ++w) if (at_call(w) && (head(h, w)->flags & 32u)) h->h_head[w].flags = 0;
+                h->warm_misses++;
+                V.redo = 1;
+                if (int rc = enqueue_front(h, C, q, true, nullptr)) return rc;
+                enqueue_trial(h, C, q, true);
+                launch_decide(V, nullptr, 0, s);
+                V.redo = 0;
+                ++trials;
+            }
+            HIPCHK(hipGetLastError());
+            if (int rc = read_heads(h)) return rc;
             bool finished = false;
             for (int trial = 0; trial <= 24; ++trial) {
                 bool repeat = false, all = true;
                 for (int w = 0; w < h->W; ++w) {
-                    if (head(h, w)->call_idx != sc_call) continue;
+                    if (!at_call(w)) continue;
                     all = false;
                     repeat = repeat || (head(h, w)->flags & 8u);
                 }
                 if (all) { finished = true; break; }
                 if (trial == 24) break;
                 if (repeat && V.pivot == 0) { V.pivot = 2; h->fallbacks++; }
-                launch_solve(V, inits[sc_call], s);
-                launch_trial(V, s);
+                enqueue_trial(h, C, q, false);
                 launch_decide(V, nullptr, 0, s);
                 HIPCHK(hipGetLastError());
                 if (int rc = read_heads(h)) return rc;
                 ++trials;
             }
-            if (!finished) {
-                h->have_state.assign(h->W, 0);
+            if (!finished)
                 return fail(VBA_ESTATE, "LM loop of call " + std::to_string(sc_call) + " did not terminate (no outcome reported by the device)");
-            }
         }
         next = stalled.front() + 1;
+        if (next >= ncalls) { complete = true; break; }
     }
+    if (!complete) {
+        for (int w = 0; w < h->W; ++w) complete = complete && head(h, w)->call_idx >= ncalls;
+        if (!complete) return fail(VBA_ESTATE, "chained schedule did not complete (a window never reached its last call)");
+    }
+    abandon.armed = false;
     if (trials_total) *trials_total = (int)trials;
+    h->par = (par0 + ncalls) & 1;
     h->carry_ok = h->carry_enabled;
     h->stepped = true;
     h->last_iter = iters[ncalls - 1];
@@ -803,21 +992,22 @@ int vba_step_profiled(vba_handle h, int iter, int initialize, float* ms) {
     return step_impl(h, iter, initialize, ms);
 }
 
+static int take_back(vba_handle h, double* states_out, double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags) {
+    if (h->back_valid) {        // read back together with the step: no second wait
+        const WinScalars* sc = reinterpret_cast<const WinScalars*>(h->h_back + (size_t)h->n_max * 10);
+        if (states_out) std::memcpy(states_out, h->h_back, (size_t)h->n[0] * 80);
+        unpack_scalars(sc, h->par, lamda_out, last_hessian, n_trials, flags);
+        return VBA_OK;
+    }
+    return vba_get_states(h, 0, states_out, lamda_out, last_hessian, n_trials, flags);
+}
+
 int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in, double* states_out,
                 double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags) {
     if (int rc = vba_set_states(h, 0, states_in, lamda_in)) return rc;
     // the next call of this kind replaces the states again: nothing to carry over
     if (int rc = step_impl(h, iter, initialize, nullptr, false, 0)) return rc;
-    if (h->back_valid) {        // read back together with the step: no second wait
-        const WinScalars* sc = reinterpret_cast<const WinScalars*>(h->h_back + (size_t)h->n_max * 10);
-        if (states_out) std::memcpy(states_out, h->h_back, (size_t)h->n[0] * 80);
-        if (lamda_out) *lamda_out = sc->lamda;
-        if (last_hessian) std::memcpy(last_hessian, sc->last_hessian, 81 * 8);
-        if (n_trials) *n_trials = sc->n_trials;
-        if (flags) *flags = sc->flags;
-        return VBA_OK;
-    }
-    return vba_get_states(h, 0, states_out, lamda_out, last_hessian, n_trials, flags);
+    return take_back(h, states_out, lamda_out, last_hessian, n_trials, flags);
 }
 
 // The next call of a driver loop that hands BA() the states it got back from the previous call: nothing to upload, the
@@ -827,16 +1017,7 @@ int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (!h->stepped) return fail(VBA_ESTATE, "vba_iterate_resident follows a call that left its result on the device");
     if (int rc = step_impl(h, iter, initialize, nullptr, true, 0)) return rc;
-    if (h->back_valid) {
-        const WinScalars* sc = reinterpret_cast<const WinScalars*>(h->h_back + (size_t)h->n_max * 10);
-        if (states_out) std::memcpy(states_out, h->h_back, (size_t)h->n[0] * 80);
-        if (lamda_out) *lamda_out = sc->lamda;
-        if (last_hessian) std::memcpy(last_hessian, sc->last_hessian, 81 * 8);
-        if (n_trials) *n_trials = sc->n_trials;
-        if (flags) *flags = sc->flags;
-        return VBA_OK;
-    }
-    return vba_get_states(h, 0, states_out, lamda_out, last_hessian, n_trials, flags);
+    return take_back(h, states_out, lamda_out, last_hessian, n_trials, flags);
 }
 
 int vba_last_step_ms(vba_handle h, float* ms) {
@@ -855,7 +1036,13 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
     const int n = h->n[window];
     const int64_t m = h->m[window];
     const size_t pb = (size_t)window * h->n_max;
-    const DevView& V = h->V;
+    // the view of the call that ran last: its input states are in the buffer of the other parity by now
+    DevView V;
+    {
+        CallSpec c;
+        c.iter = h->last_iter; c.initialize = h->last_init; c.call = -1; c.par = h->par ^ 1;
+        view_for_call(h, V, c);
+    }
     auto copy = [&](const double* src, int64_t cnt) -> int {
         if (cnt > capacity) return fail(VBA_EINVAL, "debug buffer too small");
         HIPCHK(hipMemcpy(out, src, cnt * 8, hipMemcpyDeviceToHost));
@@ -939,6 +1126,10 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
             return VBA_OK;
         }
         case VBA_DBG_BANDS: {
+            // latency mode never writes the bands to memory (the chunk kernel forms its blocks in LDS): form them now
+            launch_assemble(V, 0, h->stream);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->stream));
             if (int rc = copy(V.bands + pb * 243, (int64_t)n * 243)) return rc;
             if (h->last_init) {     // landmark-only phase: the off-diagonal blocks are zero and are not written
                 for (int i = 0; i < n; ++i) {
@@ -948,7 +1139,12 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
             }
             return VBA_OK;
         }
-        case VBA_DBG_RHS: return copy(V.rhs + pb * 9, (int64_t)n * 9);
+        case VBA_DBG_RHS: {
+            launch_assemble(V, 0, h->stream);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->stream));
+            return copy(V.rhs + pb * 9, (int64_t)n * 9);
+        }
         case VBA_DBG_DPOSE: return copy(V.dpose + pb * 9, (int64_t)n * 9);
         case VBA_DBG_SCALARS: {
             if (capacity < 8) return fail(VBA_EINVAL, "debug buffer too small");
@@ -966,6 +1162,17 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
 // ------------------------------------------------------------------------------------------------ sharded mode
 int64_t vba_sh_partial_count(int n) { return 27 * (int64_t)n + 2; }
 
+// the device view of the sharded call in flight: classic kernels throughout (the bands go through memory, the trial reads
+// the trial states the recovery wrote, every accept test is its own launch)
+static void sharded_view(vba_handle h, DevView& V) {
+    CallSpec c;
+    c.iter = h->last_iter; c.initialize = h->last_init; c.call = -1; c.par = h->par;
+    view_for_call(h, V, c);
+    V.lat = 0;
+    V.fused_trial = 0;
+    V.m_total = h->V.m_total;
+}
+
 int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, double* d_abs_local) {
     if (!h || !d_abs_local || m_total < 1) return fail(VBA_EINVAL, "bad argument");
     if (h->W != 1) return fail(VBA_EINVAL, "sharded mode uses a single window per handle");
@@ -973,14 +1180,19 @@ int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, doubl
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    fill_params(h->V.prm, iter, initialize);
     h->V.m_total = m_total;
-    h->carry_ok = false;
-    if (h->hist_dirty) { launch_clear_hist0(h->V, s); h->hist_dirty = false; }
-    launch_obs_residual(h->V, d_abs_local, s);
-    HIPCHK(hipGetLastError());
     h->last_iter = iter;
     h->last_init = initialize;
+    h->carry_ok = false;
+    DevView V;
+    sharded_view(h, V);
+    if (h->hist_dirty || h->need_hist_reset) {
+        DevView Q = V;
+        for (int p = 0; p < 2; ++p) { Q.par = p; launch_clear_hist(Q, 1, s); }
+        h->hist_dirty = h->need_hist_reset = false;
+    }
+    launch_obs_residual(V, d_abs_local, s);
+    HIPCHK(hipGetLastError());
     return VBA_OK;
 }
 
@@ -989,10 +1201,11 @@ int vba_sh_stage2(vba_handle h, const double* d_abs_all, int64_t count_all, doub
     if (h->V.m_total < 1 || count_all < 2 * h->V.m_total) return fail(VBA_ESTATE, "stage1 has not run or count_all < 2*m_total");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    DevView V = h->V;
+    DevView V;
+    sharded_view(h, V);
     V.abs_all = d_abs_all;
     V.abs_all_count = count_all;
-    launch_select(V, s);
+    launch_select(V, true, s);          // digit 0 over the gathered keys as well
     launch_obs_accumulate(V, s);
     launch_shard_pack(V, d_partial_local, s);
     HIPCHK(hipGetLastError());
@@ -1004,7 +1217,8 @@ int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* 
     if (h->V.m_total < 1) return fail(VBA_ESTATE, "stage1 has not run");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    DevView V = h->V;
+    DevView V;
+    sharded_view(h, V);
     if (d_partial_all) {    // first trial of this call; NULL = another LM trial on the same system
         if (ranks < 1) return fail(VBA_EINVAL, "ranks must be >= 1");
         launch_shard_reduce(V, d_partial_all, ranks, s);
@@ -1025,7 +1239,8 @@ int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* 
 int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done) {
     if (!h || !d_trial_all || !done || ranks < 1) return fail(VBA_EINVAL, "bad argument");
     HIPCHK(hipSetDevice(h->device));
-    DevView V = h->V;
+    DevView V;
+    sharded_view(h, V);
     launch_decide(V, d_trial_all, ranks, h->stream);
     HIPCHK(hipGetLastError());
     if (int rc = read_heads(h)) return rc;
@@ -1034,7 +1249,11 @@ int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done)
         h->sh_pivot = 2;
         h->fallbacks++;
     }
-    if (*done) { h->stepped = true; h->V.m_total = 0; }
+    if (*done) {
+        h->stepped = true;
+        h->V.m_total = 0;
+        h->par ^= 1;            // the trial buffer is the next call's input
+    }
     return VBA_OK;
 }
 

@@ -1,0 +1,72 @@
+// vba_asm.h -- staging of the per-pose inputs of the block-tridiagonal assembly (BA_filtering.py:40-48) in LDS and
+// the row descriptor built on them.  Shared by k_assemble (its own launch: batched windows, sharded mode, debug) and
+// by the chunk elimination of the latency mode, which forms the blocks of its chunk itself.
+#pragma once
+
+#include "vba_device.h"
+
+namespace vba {
+
+constexpr int kAsmBase = 21 + 6 + 36 + 6 + 3 + 27;    // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl
+constexpr int kAsmPrior = 36 + 6;                     // BA_reg: prior H, prior r
+
+// slots [0, slots) of `in` receive the inputs of poses first .. first + slots - 1 (zeros outside [0, n)); every thread
+// of the block takes part (stride = block size); the caller synchronises
+template <bool REG>
+__device__ __forceinline__ void asm_stage(const DevView& V, int w, int n, bool dyn, int first, int slots, double* in, int tid,
+                                          int nthreads) {
+    constexpr int kAsmIn = kAsmBase + (REG ? kAsmPrior : 0);
+    const size_t sb = (size_t)w * V.n_max;
+    for (int e = tid; e < slots * kAsmIn; e += nthreads) {
+        const int slot = e / kAsmIn, q = e % kAsmIn;
+        const int i = first + slot;
+        double v = 0.0;
+        if (i >= 0 && i < n) {
+            const size_t pb = sb + i;
+            if (q < 21) v = V.Hraw[pb * 21 + q];
+            else if (q < 27) v = V.braw[pb * 6 + (q - 21)];
+            else if (dyn) {
+                if (q < 63) v = V.Phi[pb * 36 + (q - 27)];
+                else if (q < 69) v = V.rorb[pb * 6 + (q - 63)];
+                else if (q < 72) v = V.qgrad[pb * 3 + (q - 69)];
+                else if (q < 81) v = V.Hd[pb * 9 + (q - 72)];
+                else if (q < 90) v = V.Hu[pb * 9 + (q - 81)];
+                else if (q < 99) v = V.Hl[pb * 9 + (q - 90)];
+                else if (REG) {
+                    if (q < 135) v = V.prior_H[pb * 36 + (q - 99)];
+                    else {      // one component of r = H [p_prior - p ; v_prior - v]
+                        const double* Hr = V.prior_H + pb * 36 + (q - 135) * 6;
+                        const double* xp = V.prior_x + pb * 6;
+                        const double* st = V.states + pb * 10;
+                        v = Hr[0] * (xp[0] - st[0]) + Hr[1] * (xp[1] - st[1]) + Hr[2] * (xp[2] - st[2]) +
+                            Hr[3] * (xp[3] - st[7]) + Hr[4] * (xp[4] - st[8]) + Hr[5] * (xp[5] - st[9]);
+                    }
+                }
+            }
+        }
+        in[e] = v;
+    }
+}
+
+// row i of the system from the staged inputs of pose i (`me`) and pose i - 1 (`pv`)
+template <bool REG>
+__device__ __forceinline__ AsmRow asm_row(const double* me, const double* pv, int i, int n, bool dyn, double sigma, double inv_wmax) {
+    AsmRow R;
+    R.Hraw = me;
+    R.braw = me + 21;
+    R.inv_wmax = inv_wmax;
+    R.sigma = dyn ? sigma : 0.0;
+    R.Phi_i = (dyn && i < n - 1) ? me + 27 : nullptr;
+    R.Phi_im1 = (dyn && i > 0) ? pv + 27 : nullptr;
+    R.rorb_i = (dyn && i < n - 1) ? me + 63 : nullptr;
+    R.rorb_im1 = (dyn && i > 0) ? pv + 63 : nullptr;
+    R.qgrad = me + 69;
+    R.Hd = me + 72;
+    R.Hu = me + 81;
+    R.Hl = me + 90;
+    R.prior_H = REG ? me + 99 : nullptr;
+    R.prior_r = me + 135;
+    return R;
+}
+
+}  // namespace vba

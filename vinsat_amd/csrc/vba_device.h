@@ -14,6 +14,29 @@ constexpr int kSelItems = 8;            // keys per thread per radix-select pass
 constexpr int kSelPasses = 6;           // 63 key bits = 10 + 11 + 11 + 11 + 11 + 9
 constexpr int kSelBins = 2048;
 constexpr int kDynLanes = 8;            // lanes per pose in the dynamics kernel (6 tangents + attitude + spare)
+constexpr int kHistStride = (kSelPasses + 1) * kSelBins;    // per window: digit 0 twice (call parity), digits 1..5
+constexpr int kWarmCount = 192;         // warm select: up to this many keys are ranked by counting, longer lists by radix digits
+
+// Warm select.  An accepted trial leaves the next call's keys behind (carried keys); their median is close to the
+// median c of the call that produced them, so that trial histograms the keys into 2046 bins of 2^shift bit patterns
+// starting at c / 2^k (bit patterns of non-negative doubles order like the values) instead of by exponent: the bin of
+// the wanted rank then holds a short list and ONE pass over the keys (compaction of that bin) replaces two.  Bin 0 =
+// below the range, bin 2047 = above: a rank that falls there (or no usable c) is a miss and the call repeats its
+// select with the exact exponent / mantissa digits.
+__host__ __device__ __forceinline__ unsigned warm_bin(unsigned long long key, unsigned long long lo, int shift) {
+    if (key < lo) return 0u;
+    const unsigned long long d = (key - lo) >> shift;
+    return d < 2046ull ? 1u + (unsigned)d : 2047u;
+}
+// lower end of the binned range for median bits c: 2046 bins of 2^shift cover 2046 / 2^(52 - shift) binades --
+// [c / 16, c * 16) for shift 44, [c / 4, c * 4) for shift 43
+__host__ __device__ __forceinline__ unsigned long long warm_range_start(unsigned long long c_bits, int shift) {
+    const unsigned long long binades = 2046ull >> (52 - shift);         // 7 (shift 44), 3 (shift 43)
+    const unsigned long long down = (binades + 1) / 2;                   // 4, 2
+    const unsigned long long e = c_bits >> 52;
+    if (e <= down || e >= 0x7feull) return ~0ull;                        // zero / denormal / inf / nan median: no warm range (every key "below")
+    return c_bits - (down << 52);
+}
 
 __host__ __device__ constexpr int sel_shift(int p) { return p == 0 ? 53 : p == 1 ? 42 : p == 2 ? 31 : p == 3 ? 20 : p == 4 ? 9 : 0; }
 __host__ __device__ constexpr int sel_width(int p) { return p == 0 ? 10 : p == 5 ? 9 : 11; }
@@ -29,22 +52,32 @@ struct StepParams {
 };
 
 // Per-window scalars living in device memory.
+// Call parity.  What one call hands to the next lives twice, indexed by the parity p of the call that READS it: the
+// states (DevView::states = buffer p, ::states_new = buffer p ^ 1: a call's last trial IS the next call's input, no
+// copy), the damping lam[p], sum |r_obs| at the input states sum_in[p], the flags fl[p], the digit-0 histogram of the
+// carried keys hist0[p].  A kernel of call c reads slot p and the end of the call (k_decide, or the first kernel of
+// call c + 1 when the accept test is folded into it) writes slot p ^ 1 -- so the blocks of that first kernel, which all
+// re-evaluate the accept test redundantly, never read a word that one of them writes.
 struct WinScalars {
-    double lamda;                   // LM damping carried between calls
+    double lam[2];                  // LM damping of the call of that parity (BA_filtering.py:52-79)
+    double sum_in[2];               // sum |r_obs| at that call's input states (carried keys; sharded mode: local part)
+    unsigned fl[2];                 // flags of that call
     double lam32;                   // float32-rounded damping of the last trial (BA_filtering.py:54)
     double c_obs;                   // lower median of |r_obs|
     unsigned long long wmax_bits;   // max raw weight, as ordered bits
     double init_residual;
     double trial_residual;
-    double sum_abs_robs;            // sum |r_obs| at the input states (sharded mode: local part)
     double sum_abs_rpred;           // sqrt(sigma) * sum |r_pred|
-    double next_sum_abs_robs;       // sum |r_obs| at the states the last accepted trial committed (carried keys)
     int done;
     int n_trials;
-    unsigned flags;
     unsigned sel_cnt;               // keys appended to the compacted select list
+    int sel_mode;                   // how the list was made: 0 = exact digits (prefix of 32 bits known), 1 = one warm bin
     int call_idx;                   // calls of the current vba_run_schedule completed by this window
+    int pending;                    // call whose first trial has been evaluated (k_trial) and not yet decided; -1: none
+    int miss;                       // the warm select of the current call missed: the call is repeated with the exact select
     int pad2;
+    unsigned long long warm_lo[2];  // lower end of the warm bins of hist0[p]
+    unsigned long long warm_base;   // bit pattern at which the selected warm bin starts (sel_mode 1)
     unsigned long long sel_prefix[kSelPasses + 1];
     long long sel_rank[kSelPasses + 1];
     double last_hessian[81];
@@ -66,12 +99,21 @@ struct DevView {
     int W, n_max;
     int n_min;                      // smallest pose count over the windows of the handle (host maintained)
     int call;                       // >= 0: this launch belongs to call `call` of a schedule, windows elsewhere in it skip
+    int par;                        // parity of this call (see WinScalars)
+    int fold;                       // this call's first kernel first evaluates the accept test of call - 1 (chained schedule)
+    int pending_only;               // k_decide: only windows whose trial of this call is evaluated and not yet decided (sc.pending)
+    int redo;                       // 1: this launch repeats the call for the windows whose warm select missed (sc.miss), others skip
+    int lat;                        // latency mode (few windows): fused kernels, see vba_api.hip
+    int warm_shift;                 // log2 of the bit-pattern width of a warm bin
+    int warm_force_miss;            // test knob: every warm select reports a miss (exercises the repeat with the exact digits)
+    int fused_trial;                // k_trial forms the step itself (0 no, 1 landmark-only 6x6 solve, 2 recovery of the partitioned solve)
     int64_t m_max;
     int64_t obs_stride;             // doubles between the observation blocks of consecutive windows (see ox)
     int nblk_obs;                   // ceil(m_max / kObsBlock)
     const int* n;                   // [W]
     const int* m;                   // [W]
     StepParams prm;                 // per-call constants, travel with the kernel arguments
+    StepParams prev;                // those of the call in front (fold: its accept test is evaluated with them)
     WinHead* host_head;             // [W] mapped pinned host memory: k_decide publishes the outcome here
     WinScalars* sc;                 // [W]
     // observations, pose sorted, SoA.  One contiguous block per window -- [ox | oy | oz | ou | ov | oconf] of m_pad doubles
@@ -99,12 +141,16 @@ struct DevView {
     double* part_init;              // [W][nblk_obs] block sums of |r_obs|
     double* part_trial;             // [W][nblk_obs + nblk_dyn]
     double* part_next;              // [W][nblk_obs] block sums of |r_obs| at the trial states (carried keys)
+    double* part_pred;              // [W][nblk_pred] block sums of |r_pred| at the input states (dynamics factor, 32 poses per block)
+    double* part_prior;             // [W][nblk_pred] block sums of |r_prior| at the input states (BA_reg)
+    int nblk_pred;
+    double* lastD;                  // [W][81] undamped diagonal block of the last pose (BA_filtering.py:97: last_hessian)
     // Carried keys: the trial residual of an accepted trial is evaluated at exactly the states the next call starts
     // from, so k_trial<true> (emit) also leaves that call's |r| keys, their exponent histogram and sum |r| behind and
     // the next call (carry) starts at the select without re-reading the observations.
     int emit, carry;
     int dyn_in_acc;                 // full-phase call with few windows: k_obs_accumulate's grid also runs the dynamics factor
-    unsigned* hist;                 // [W][kSelPasses][kSelBins]
+    unsigned* hist;                 // [W][kHistStride]: digit 0 for parity 0, digit 0 for parity 1, digits 1..5
     double* Hraw;                   // [21]
     double* braw;                   // [6]
     double* xhat;                   // [6]
@@ -140,7 +186,13 @@ struct DevView {
 // Speculatively chained calls (vba_run_schedule): the kernels of call c are enqueued before call c-1 is known to
 // have finished with its first LM trial; a window that needs more trials (or a pivoted repeat) simply does not
 // advance its call counter, and every later kernel leaves it alone until the host has finished that call.
-#define VBA_SKIP_CALL(V, w) do { if ((V).call >= 0 && (V).sc[(w)].call_idx != (V).call) return; } while (0)
+// V.redo: 0 = ordinary launch (windows whose warm select missed wait), 1 = the repeat of such a call (only they run),
+// 2 = a trial round both kinds take part in.
+#define VBA_WINDOW_RUNS(V, w) (((V).call < 0 || (V).sc[(w)].call_idx == (V).call) && ((V).redo == 2 || ((V).sc[(w)].miss != 0) == ((V).redo != 0)))
+#define VBA_SKIP_CALL(V, w) do { if (!VBA_WINDOW_RUNS(V, w)) return; } while (0)
+
+__device__ __forceinline__ unsigned* hist0_of(const DevView& V, int w, int par) { return V.hist + (size_t)w * kHistStride + (size_t)par * kSelBins; }
+__device__ __forceinline__ unsigned* histd_of(const DevView& V, int w, int digit /*1..5*/) { return V.hist + (size_t)w * kHistStride + (size_t)(digit + 1) * kSelBins; }
 
 // ------------------------------------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, kWave); }

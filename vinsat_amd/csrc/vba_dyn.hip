@@ -5,9 +5,11 @@
 // (BA_utils.py:506); here every pose carries its six tangent vectors forward through the same RK4 steps
 // (8 lanes per pose: lanes 0-5 one tangent each, lane 6 the attitude term), so only the 6x6 block that is
 // actually non-zero is ever produced.
+#include "vba_asm.h"
 #include "vba_device.h"
 #include "vba_dyn_body.h"
 #include "vba_launch.h"
+#include "vba_step.h"
 
 namespace vba {
 
@@ -22,20 +24,6 @@ __global__ __launch_bounds__(256) void k_dynamics(DevView V) {
 // batched windows fill the chip anyway: the decode of an entry and the halo slot are amortised over more poses): the per-pose inputs (141 doubles each, plus the
 // transition matrix of the pose in front) are staged once in LDS with coalesced loads, then every thread forms
 // entries from LDS and the block writes its 252 * kAsmPoses outputs contiguously.
-constexpr int kAsmBase = 21 + 6 + 36 + 6 + 3 + 27;    // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl
-constexpr int kAsmPrior = 36 + 6;                     // BA_reg: prior H, prior r
-
-// 1/x to ~1 ulp (same sequence as the chain solver's)
-__device__ __forceinline__ double asm_fast_rcp(double x) {
-    // 1/x = r / (1 - e) with e = 1 - x r ~ 4e-8: r (1 + e + e^2) is exact to e^3, three dependent operations after the
-    // seed instead of the four of two Newton steps
-    double r = __builtin_amdgcn_rcp(x);
-    const double e = fma(-x, r, 1.0);
-    const double t = fma(e, e, e);
-    r = fma(r, t, r);
-    return r;
-}
-
 // FUSE (landmark-only phase, first LM trial, unpivoted path): the system is block diagonal and, inside a pose,
 // the velocity rows carry only the damping, so the step of a pose is a 6x6 solve of (H_i / w_max + lamda I) x = b_i /
 // w_max.  One thread per pose does it in registers straight from the staged inputs, retracts and writes the trial
@@ -50,45 +38,13 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     VBA_SKIP_CALL(V, w);
     const int n = V.n[w];
     const int i0 = blockIdx.x * kAsmPoses;
-    if (blockIdx.x == 0) {      // the select is over (its last reader was k_obs_accumulate): clean histograms for the next call
-        unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
-        for (int b = threadIdx.x; b < 3 * kSelBins; b += 256) hist[b] = 0u;
-    }
     if (i0 >= n) return;
     const StepParams& prm = V.prm;
     const size_t sb = (size_t)w * V.n_max;
     const bool dyn = !prm.initialize;
-    const bool reg = REG;               // the host launches REG only for full-phase BA_reg calls (BA_utils.py:609-612)
+    // REG: the host launches it only for full-phase BA_reg calls (BA_utils.py:609-612)
     // slot 0 = pose i0-1 (only Phi and rorb are used), slots 1..kAsmPoses = poses i0 ..
-    for (int e = threadIdx.x; e < (kAsmPoses + 1) * kAsmIn; e += 256) {
-        const int slot = e / kAsmIn, q = e % kAsmIn;
-        const int i = i0 - 1 + slot;
-        double v = 0.0;
-        if (i >= 0 && i < n) {
-            const size_t pb = sb + i;
-            if (q < 21) v = V.Hraw[pb * 21 + q];
-            else if (q < 27) v = V.braw[pb * 6 + (q - 21)];
-            else if (dyn) {
-                if (q < 63) v = V.Phi[pb * 36 + (q - 27)];
-                else if (q < 69) v = V.rorb[pb * 6 + (q - 63)];
-                else if (q < 72) v = V.qgrad[pb * 3 + (q - 69)];
-                else if (q < 81) v = V.Hd[pb * 9 + (q - 72)];
-                else if (q < 90) v = V.Hu[pb * 9 + (q - 81)];
-                else if (q < 99) v = V.Hl[pb * 9 + (q - 90)];
-                else if (reg) {
-                    if (q < 135) v = V.prior_H[pb * 36 + (q - 99)];
-                    else {      // one component of r = H [p_prior - p ; v_prior - v]
-                        const double* Hr = V.prior_H + pb * 36 + (q - 135) * 6;
-                        const double* xp = V.prior_x + pb * 6;
-                        const double* st = V.states + pb * 10;
-                        v = Hr[0] * (xp[0] - st[0]) + Hr[1] * (xp[1] - st[1]) + Hr[2] * (xp[2] - st[2]) +
-                            Hr[3] * (xp[3] - st[7]) + Hr[4] * (xp[4] - st[8]) + Hr[5] * (xp[5] - st[9]);
-                    }
-                }
-            }
-        }
-        in[e] = v;
-    }
+    asm_stage<REG>(V, w, n, dyn, i0 - 1, kAsmPoses + 1, in, threadIdx.x, 256);
     __syncthreads();
     const double inv_wmax = 1.0 / bits_f64(V.sc[w].wmax_bits);
     const int cnt = min(kAsmPoses, n - i0);
@@ -104,62 +60,29 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
             const int i = i0 + p;
             const double* me = in + (p + 1) * kAsmIn;
             const double* pv = in + p * kAsmIn;
-            AsmRow R;
-            R.Hraw = me;
-            R.braw = me + 21;
-            R.inv_wmax = inv_wmax;
-            R.sigma = dyn ? prm.sigma : 0.0;
-            R.Phi_i = (dyn && i < n - 1) ? me + 27 : nullptr;
-            R.Phi_im1 = (dyn && i > 0) ? pv + 27 : nullptr;
-            R.rorb_i = (dyn && i < n - 1) ? me + 63 : nullptr;
-            R.rorb_im1 = (dyn && i > 0) ? pv + 63 : nullptr;
-            R.qgrad = me + 69;
-            R.Hd = me + 72;
-            R.Hu = me + 81;
-            R.Hl = me + 90;
-            R.prior_H = reg ? me + 99 : nullptr;
-            R.prior_r = me + 135;
+            const AsmRow R = asm_row<REG>(me, pv, i, n, dyn, prm.sigma, inv_wmax);
             // landmark-only phase: the off-diagonal blocks are zero and nobody reads them (k_solve_blockdiag takes
             // the diagonal block only; vba_debug_fetch reports them as zeros)
             if (is_rhs) V.rhs[(sb + i) * 9 + a] = rhs_entry(R, a);
-            else if (dyn || which == 1) V.bands[(sb + i) * 243 + t] = band_entry(R, which, a, b);
+            else if (dyn || which == 1) {
+                const double e = band_entry(R, which, a, b);
+                V.bands[(sb + i) * 243 + t] = e;
+                if (which == 1 && i == n - 1) V.lastD[(size_t)w * 81 + (t - 81)] = e;      // BA_filtering.py:97
+            }
         }
     }
     if (FUSE) {
         WinScalars& sc = V.sc[w];
-        const double lam32 = (double)(float)sc.lamda;      // torch.eye() is float32 (BA_filtering.py:54)
+        const double lam32 = (double)(float)sc.lam[V.par];      // torch.eye() is float32 (BA_filtering.py:54)
         if (blockIdx.x == 0 && threadIdx.x == 0) sc.lam32 = lam32;
         bool badpiv = false, badnum = false;
         if ((int)threadIdx.x < cnt) {
             const int i = i0 + threadIdx.x;
             const double* me = in + (threadIdx.x + 1) * kAsmIn;
-            double A[6][7], d0[6];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                for (int b = 0; b < 6; ++b) A[a][b] = me[sym6(a, b)] * inv_wmax + (a == b ? lam32 : 0.0);
-                A[a][6] = me[21 + a] * inv_wmax;
-                d0[a] = A[a][a];
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (!(A[k][k] > 1e-10 * d0[k])) badpiv = true;
-                const double inv = asm_fast_rcp(A[k][k]);
-#pragma unroll
-                for (int c = 0; c < 7; ++c) A[k][c] *= inv;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    if (r != k) {
-                        const double f = A[r][k];
-#pragma unroll
-                        for (int c = 0; c < 7; ++c) A[r][c] -= f * A[k][c];
-                    }
-                }
-            }
             double d9[9], o[10];
+            badpiv = !step_blockdiag6(me, me + 21, inv_wmax, lam32, d9);
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
-                d9[r] = r < 6 ? A[r][6] : 0.0;
                 badnum |= !(fabs(d9[r]) <= 1.79e308);
                 V.dpose[(sb + i) * 9 + r] = d9[r];
             }
@@ -169,7 +92,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
         }
         if (threadIdx.x < 64) {
             const unsigned long long bp = __ballot(badpiv), bn = __ballot(badnum);
-            if (threadIdx.x == 0 && (bp || bn)) atomicOr(&sc.flags, (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
+            if (threadIdx.x == 0 && (bp || bn)) atomicOr(&sc.fl[V.par], (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
         }
     }
 }

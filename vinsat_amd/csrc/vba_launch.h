@@ -8,10 +8,11 @@ namespace vba {
 
 // vba_obs.hip
 void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s);
-void launch_select(const DevView& V, hipStream_t s);
+void launch_select(const DevView& V, bool with_digit0, hipStream_t s);
+void launch_select_warm(const DevView& V, hipStream_t s);
 void launch_obs_accumulate(const DevView& V, hipStream_t s);
 void launch_trial(const DevView& V, hipStream_t s);
-void launch_clear_hist0(const DevView& V, hipStream_t s);
+void launch_clear_hist(const DevView& V, int which, hipStream_t s);
 void launch_reset_calls(const DevView& V, hipStream_t s);
 void launch_set_counts(const DevView& V, int w, int n, int m, hipStream_t s);
 void launch_broadcast_states(const DevView& V, int n, double lamda, hipStream_t s);
@@ -24,6 +25,7 @@ void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s);
 // vba_solve.hip
 void launch_solve(const DevView& V, int initialize, hipStream_t s);
 hipError_t configure_solver_device();      // per device, from vba_create
+bool solve_forms_blocks(const DevView& V);  // the chunk kernel forms its blocks itself: no k_assemble for this call
 void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStream_t s);
 
 // vba_shard.hip

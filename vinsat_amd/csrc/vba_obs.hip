@@ -5,31 +5,36 @@
 //                      digit 0 (exponent) is histogrammed inside k_obs_residual, digits 1 and 2 read the keys
 //                      once each, the second of them compacting the (few) keys that match the 32 known bits,
 //                      and select_finish (prologue of k_obs_accumulate) finishes digits 3..5 on that short list
+//   k_select_warm      A3a on carried keys: the trial that produced the keys binned them around the median of its own
+//                      call (warm_bin, vba_device.h), so ONE pass compacts the bin of the wanted rank; in a chained
+//                      schedule its prologue is the accept test of the call in front (vba_decide.h)
 //   k_obs_accumulate<G> A2 + A3a + A3b: Jacobian, robust weight, per-pose 6x6 / 6 accumulation (G lanes per pose)
 //   k_trial            A8: weighted trial residuals (observations) and dynamics residuals at the trial states
 //   k_debug_project    recompute est / Jacobian at the step's input states for vba_debug_fetch
 //
 // All of these stream the observation arrays once, coalesced (SoA, 8 B per lane per array); the pose state
 // is gathered through L1/L2 (observations are pose sorted, so a wave touches one or two poses).
+#include "vba_decide.h"
 #include "vba_device.h"
 #include "vba_dyn_body.h"
 #include "vba_launch.h"
+#include "vba_step.h"
 
 namespace vba {
 
-// Per-step state that must be clean before the first kernel touches it:
-//   * radix histograms: zeroed by k_assemble of the PREVIOUS step (and by the allocation), because the first
-//     kernel of a step already accumulates digit 0 into them;
-//   * scalars (done, n_trials, flags, max weight, list length): reset by thread 0 of block 0 of k_obs_residual,
-//     no later block or kernel of the step reads them before the next kernel boundary;
-//   * states_prev (debug copy of the step's input): written by k_decide just before it commits the new states.
-__device__ __forceinline__ void reset_step_scalars(WinScalars& sc) {
+// Per-call state that must be clean before the first kernel touches it:
+//   * digit-0 histogram of the call's parity: zeroed by k_obs_accumulate of the call that consumed it last (and by
+//     the allocation); digits 1, 2: zeroed by k_trial;
+//   * scalars (done, n_trials, flags, max weight): reset by thread 0 of block 0 of the call's first kernel
+//     (k_obs_residual, k_select_warm, or k_select_pass<1> of a repeated select), no other block of that kernel reads them;
+//   * the length of the compacted list: reset by the kernel in FRONT of the one that appends (k_obs_residual /
+//     k_select_pass<1>, or the previous call's k_trial for k_select_warm).
+__device__ __forceinline__ void begin_call_scalars(WinScalars& sc, int par) {
     sc.done = 0;
     sc.n_trials = 0;
-    sc.flags = 0u;
+    sc.fl[par] = 0u;
     sc.wmax_bits = 0ull;
     sc.sum_abs_rpred = 0.0;
-    sc.sel_cnt = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------- A1
@@ -67,9 +72,12 @@ __global__ __launch_bounds__(kObsBlock) void k_obs_residual(DevView V, double* a
     }
     const double t = block_sum<kObsBlock>(s, red);
     if (threadIdx.x == 0) V.part_init[(size_t)w * V.nblk_obs + blockIdx.x] = t;
-    if (blockIdx.x == 0 && threadIdx.x == 0) reset_step_scalars(V.sc[w]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        begin_call_scalars(V.sc[w], V.par);
+        V.sc[w].sel_cnt = 0u;
+    }
     if (HIST0) {
-        unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
+        unsigned* hist = hist0_of(V, w, V.par);
         for (int b = threadIdx.x; b < 1024; b += kObsBlock) {
             const unsigned c = lh[b];
             if (c) atomicAdd(&hist[b], c);
@@ -89,14 +97,27 @@ template <int P, bool COMPACT, int ITEMS>
 __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     __shared__ unsigned lh[kSelBins];
     __shared__ unsigned lds_u[260];
+    __shared__ double red[kObsBlock / 64];
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
     const double* keys = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
     const int64_t count = V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w];
-    // carried keys: k_obs_residual did not run, this is the first kernel of the call and owns the scalar reset
-    if (P == 1 && V.carry && blockIdx.x == 0 && threadIdx.x == 0) reset_step_scalars(V.sc[w]);
+    // carried keys (a select repeated with the exact digits): k_obs_residual did not run, this kernel owns the resets
+    if (P == 1 && V.carry && blockIdx.x == 0 && threadIdx.x == 0) {
+        begin_call_scalars(V.sc[w], V.par);
+        V.sc[w].sel_cnt = 0u;
+    }
+    // sum |r_obs| at the input states for the accept test: fixed-order sum of k_obs_residual's block partials
+    // (carried keys bring it along; sharded mode gets the sum over all ranks from k_shard_reduce)
+    if (P == 1 && !V.carry && V.m_total == 0 && blockIdx.x == 0) {
+        const double* pi = V.part_init + (size_t)w * V.nblk_obs;
+        double s_init = 0.0;
+        for (int b = threadIdx.x; b < V.nblk_obs; b += 256) s_init += pi[b];
+        const double tot = block_sum<256>(s_init, red);
+        if (threadIdx.x == 0) V.sc[w].sum_in[V.par] = tot;
+    }
     if ((int64_t)blockIdx.x * 256 * ITEMS >= count) return;
-    unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
+    auto digit_hist = [&](int d) { return d == 0 ? hist0_of(V, w, V.par) : histd_of(V, w, d); };
     constexpr int nbins = 1 << sel_width(P);
     for (int b = threadIdx.x; b < nbins; b += 256) lh[b] = 0u;
     // few keys per thread (single window, latency matters): their loads are issued before the histogram of the
@@ -115,7 +136,7 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     long long rank = ((V.m_total ? 2 * V.m_total : count) - 1) / 2;
     if (P > 0) {
         constexpr int Q = P > 0 ? P - 1 : 0;
-        select_resolve(hist + Q * kSelBins, 1 << sel_width(Q), sel_width(Q), V.sc[w].sel_prefix[Q], V.sc[w].sel_rank[Q],
+        select_resolve(digit_hist(Q), 1 << sel_width(Q), sel_width(Q), V.sc[w].sel_prefix[Q], V.sc[w].sel_rank[Q],
                        prefix, rank, lds_u);
     } else {
         __syncthreads();
@@ -123,6 +144,7 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         V.sc[w].sel_prefix[P] = prefix;
         V.sc[w].sel_rank[P] = rank;
+        if (COMPACT) V.sc[w].sel_mode = 0;
     }
 #pragma unroll 8
     for (int it = 0; it < ITEMS; ++it) {
@@ -152,9 +174,102 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
         }
     }
     __syncthreads();
+    unsigned* hist_out = digit_hist(P);
     for (int b = threadIdx.x; b < nbins; b += 256) {
         const unsigned c = lh[b];
-        if (c) atomicAdd(&hist[P * kSelBins + b], c);
+        if (c) atomicAdd(&hist_out[b], c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- A3a: warm select
+// One pass over carried keys.  Prologue (chained schedule, V.fold): the accept test of the call in front, evaluated by
+// every block (vba_decide.h); a first trial that was cleanly accepted lets the window move on to this call at once.
+// Then every block resolves the warm histogram the trial left behind (bin of the wanted rank), and the keys of that
+// bin are compacted for select_finish.  A rank outside the binned range, or a bin longer than the list may be, is a
+// miss: the window waits (sc.miss) until the host has repeated this call's select with the exact digits.
+template <int ITEMS>
+__global__ __launch_bounds__(256) void k_select_warm(DevView V) {
+    __shared__ unsigned lds_u[260];
+    __shared__ double red[5][4];
+    const int w = blockIdx.y;
+    WinScalars& sc = V.sc[w];
+    const int t = threadIdx.x;
+    const int par = V.par;
+    const bool fold_here = V.call >= 0 && V.fold && sc.pending == V.call - 1 && sc.call_idx == V.call - 1;
+    if (!fold_here) VBA_SKIP_CALL(V, w);
+    const double* keys = V.absr + 2 * (size_t)w * V.m_max;
+    const int64_t count = 2 * (int64_t)V.m[w];
+    if ((int64_t)blockIdx.x * 256 * ITEMS >= count) return;         // (never block 0)
+    // the keys of a short block are loaded before anything is decided (latency)
+    constexpr bool PRELOAD = ITEMS <= 8;
+    unsigned long long pk[PRELOAD ? ITEMS : 1];
+    if (PRELOAD) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int64_t idx = ((int64_t)blockIdx.x * ITEMS + it) * 256 + t;
+            pk[it] = idx < count ? f64_bits(keys[idx]) : 0ull;
+        }
+    }
+    const unsigned* h0 = hist0_of(V, w, par);
+    const unsigned long long lo = sc.warm_lo[par];
+    if (fold_here) {
+        const DecideOut d = decide_eval(V, w, par ^ 1, V.prev, 0, 0.0, nullptr, 0, red);
+        if (!d.accept || (d.flags & (2u | 8u | 32u))) return;       // not a clean first trial: the host finishes that call
+        if (blockIdx.x == 0) {
+            const double lam32 = sc.lam32;      // of the decided call's solve
+            if (t < 81) sc.last_hessian[t] = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
+            if (t == 0) {
+                sc.lam[par] = d.lam_out;
+                sc.sum_in[par] = d.sum_next;
+                sc.init_residual = d.init_residual;
+                sc.trial_residual = d.residual;
+                sc.call_idx = V.call;
+                WinHead& hh = V.host_head[w];
+                hh.lamda = d.lam_out;
+                hh.trial_residual = d.residual;
+                hh.n_trials = 1;
+                hh.flags = d.flags;
+                hh.done = 1;
+                hh.call_idx = V.call;
+            }
+        }
+    }
+    unsigned long long prefix;
+    long long rank;
+    select_resolve(h0, kSelBins, 11, 0ull, (count - 1) / 2, prefix, rank, lds_u);
+    const unsigned bin = (unsigned)prefix;
+    const unsigned in_bin = h0[bin];
+    const bool hit = lo != ~0ull && bin >= 1u && bin <= 2046u && (int64_t)in_bin <= 2 * V.m_max && !V.warm_force_miss;
+    if (blockIdx.x == 0 && t == 0) {
+        begin_call_scalars(sc, par);
+        if (hit) {
+            sc.sel_mode = 1;
+            sc.sel_rank[2] = rank;
+            sc.warm_base = lo + ((unsigned long long)(bin - 1u) << V.warm_shift);
+        } else {
+            sc.miss = 1;
+            sc.fl[par] = 32u;
+            V.host_head[w].flags = 32u;
+            V.host_head[w].done = 0;
+        }
+    }
+    if (!hit) return;
+#pragma unroll 8
+    for (int it = 0; it < ITEMS; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * ITEMS + it) * 256 + t;
+        if (idx < count) {
+            const unsigned long long key = PRELOAD ? pk[it] : f64_bits(keys[idx]);
+            const bool match = warm_bin(key, lo, V.warm_shift) == bin;
+            const unsigned long long mask = __ballot(match);
+            if (mask) {     // wave-aggregated append: one atomic per wave instruction
+                const int lane = t & 63;
+                const int leader = __ffsll((long long)mask) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&sc.sel_cnt, (unsigned)__popcll(mask));
+                base = __shfl(base, leader, kWave);
+                if (match) V.ckeys[2 * (size_t)w * V.m_max + base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = bits_f64(key);
+            }
+        }
     }
 }
 
@@ -162,15 +277,17 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
 // c_obs to every thread of the (256-thread) block.  It is the prologue of k_obs_accumulate -- every block of a window
 // redoes it (a handful of keys: rank by counting) instead of one more single-block kernel on the critical path; long
 // lists (massive ties) take digits 3, 4, 5 with a block-local histogram each, the full key array if the list
-// overflowed.  The histograms it reads are cleared afterwards by k_assemble.
+// overflowed.  A list made by k_select_warm (one warm bin) is ranked by counting while short, by radix digits of the offset
+// inside the bin otherwise.
 __device__ __forceinline__ double select_finish(const DevView& V, int w, unsigned* lh /*[kSelBins]*/, unsigned* lds_u /*[260]*/,
                                                 unsigned long long* skeys /*[1024] + 1*/) {
     const WinScalars& sc = V.sc[w];
-    const unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
     // the list length, the wanted rank and the first 1024 list entries are loaded together (the entries
     // speculatively: the list is almost always that short)
     unsigned cnt = sc.sel_cnt;
     const long long want = sc.sel_rank[2];
+    const int mode = sc.sel_mode;
+    const unsigned long long warm_base = sc.warm_base;
     const double* ck = V.ckeys + 2 * (size_t)w * V.m_max;
     unsigned long long pre[4];
 #pragma unroll
@@ -178,9 +295,8 @@ __device__ __forceinline__ double select_finish(const DevView& V, int w, unsigne
         const unsigned q = threadIdx.x + 256u * j;
         pre[j] = (int64_t)q < 2 * V.m_max ? f64_bits(ck[q]) : 0ull;
     }
-    if (cnt <= 1024u) {
-        // every key of the list matches the 21 known bits and the wanted key is the one of rank sel_rank[2] among
-        // them -- rank each key by counting (ties broken by position)
+    if (cnt <= (mode ? (unsigned)kWarmCount : 1024u)) {
+        // the wanted key is the one of rank `want` among the list -- rank each key by counting (ties broken by position)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned q = threadIdx.x + 256u * j;
@@ -199,13 +315,38 @@ __device__ __forceinline__ double select_finish(const DevView& V, int w, unsigne
         __syncthreads();
         return bits_f64(skeys[1024]);
     }
+    if (mode == 1) {
+        // a long warm bin: every key is warm_base + rel with rel < 2^warm_shift; radix digits of rel from the top, 11 bits at
+        // a time, with a block-local histogram each
+        unsigned long long prefix = 0ull;
+        long long rank = want;
+        int remaining = V.warm_shift;
+        while (remaining > 0) {
+            const int width = remaining < 11 ? remaining : 11;
+            remaining -= width;
+            const int nbins = 1 << width;
+            for (int b = threadIdx.x; b < kSelBins; b += 256) lh[b] = 0u;
+            __syncthreads();
+            for (unsigned q = threadIdx.x; q < cnt; q += 256) {
+                const unsigned long long rel = f64_bits(ck[q]) - warm_base;
+                if ((rel >> (remaining + width)) == prefix) atomicAdd(&lh[(unsigned)(rel >> remaining) & (nbins - 1)], 1u);
+            }
+            __syncthreads();
+            unsigned long long np;
+            long long nr;
+            select_resolve(lh, nbins, width, prefix, rank, np, nr, lds_u);
+            prefix = np;
+            rank = nr;
+        }
+        return bits_f64(warm_base + prefix);
+    }
     if ((int64_t)cnt > 2 * V.m_max) {       // list overflowed: fall back to the full key array
         ck = V.abs_all ? V.abs_all : V.absr + 2 * (size_t)w * V.m_max;
         cnt = (unsigned)(V.abs_all ? V.abs_all_count : 2 * (int64_t)V.m[w]);
     }
     unsigned long long prefix;
     long long rank;
-    select_resolve(hist + 2 * kSelBins, 1 << sel_width(2), sel_width(2), sc.sel_prefix[2], sc.sel_rank[2], prefix, rank, lds_u);
+    select_resolve(histd_of(V, w, 2), 1 << sel_width(2), sel_width(2), sc.sel_prefix[2], sc.sel_rank[2], prefix, rank, lds_u);
 #pragma unroll
     for (int P = 3; P < 6; ++P) {
         const int nbins = 1 << sel_width(P);
@@ -304,7 +445,13 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     // Phase 2: the median (every block of the window finishes the select itself, see select_finish)
     RobustParams rp;
     rp.c = select_finish(V, w, sel_lh, sel_u, sel_keys);
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc.c_obs = rp.c;      // for the record (vba_debug_fetch)
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) sc.c_obs = rp.c;      // the trial kernel centres the next call's warm bins on it
+        // the select of this call is over (its last reader of the digit-0 histogram was the kernel in front): clean for
+        // the call after next, which shares the parity
+        unsigned* h0 = hist0_of(V, w, V.par);
+        for (int b = threadIdx.x; b < kSelBins; b += 256) h0[b] = 0u;
+    }
     rp.inv_c = 1.0 / rp.c;
     rp.inv_c2 = 1.0 / (rp.c * rp.c);
     rp.am2 = prm.am2;
@@ -385,53 +532,117 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 // ---------------------------------------------------------------------------------------------- A8: trial residuals
 // blocks [0, nblk_obs): sum |w (uv - est')| over the observations (BA_filtering.py:61, 66);
 // blocks [nblk_obs, nblk_obs + nblk_dyn): sqrt(sigma) sum |r_pred'| over the pose edges (BA_filtering.py:65, 67).
-// EMIT: the observation blocks also write the |r| keys, their exponent histogram (select digit 0, zeroed by this
-// call's k_assemble) and the block sums of |r| at the trial states -- the input of the next call if this trial
-// is accepted (k_decide clears the histogram again if it is not).
-template <bool EMIT>
+// EMIT: the observation blocks also write the |r| keys, their warm histogram (bins around this call's median, digit-0
+// slot of the NEXT call's parity) and the block sums of |r| at the trial states -- the input of the next call if this
+// trial is accepted (k_decide clears the histogram again if it is not).
+// FUSED (latency mode): the trial states do not exist yet -- every thread forms the step of the pose it needs itself
+// (vba_step.h: 1 = landmark-only 6x6 solve, 2 = recovery of the partitioned solve) and the pose-chain blocks, which own
+// one pose per thread, write states_new / dpose for everybody after them.
+template <bool EMIT, int FUSED>
 __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     __shared__ double red[kObsBlock / 64];
-    __shared__ unsigned lh[EMIT ? 1024 : 1];
+    __shared__ unsigned lh[EMIT ? kSelBins : 1];
+    __shared__ double snew[FUSED ? (kObsBlock + 1) * 10 : 1];
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
-    const WinScalars& sc = V.sc[w];
+    WinScalars& sc = V.sc[w];
     if (sc.done) return;
     const int n = V.n[w], m = V.m[w];
     const StepParams& prm = V.prm;
+    const int par = V.par;
     double s = 0.0, s_raw = 0.0;
     const size_t sb = (size_t)w * V.n_max;
     const bool obs_block = (int)blockIdx.x < V.nblk_obs;
+    const double lam32 = (double)(float)sc.lam[par];      // torch.eye() is float32 (BA_filtering.py:54)
+    // a window that has fallen back to the pivoted kernels (landmark-only phase) reads the trial states they wrote
+    const bool fz = FUSED == 2 || (FUSED == 1 && !(sc.fl[par] & 16u));
+    const double wmax = bits_f64(sc.wmax_bits);
+    const double inv_wmax = 1.0 / wmax;
+    unsigned long long wlo = 0ull;
+    if (EMIT) wlo = warm_range_start(f64_bits(sc.c_obs), V.warm_shift);
     if (EMIT && obs_block) {
-        for (int b = threadIdx.x; b < 1024; b += kObsBlock) lh[b] = 0u;
+        for (int b = threadIdx.x; b < kSelBins; b += kObsBlock) lh[b] = 0u;
         __syncthreads();
     }
+    if (blockIdx.x == 0) {
+        // digits 1, 2 of an exact select are dead since the accumulation; the list of the next warm select starts empty
+        unsigned* h12 = histd_of(V, w, 1);
+        for (int b = threadIdx.x; b < 2 * kSelBins; b += kObsBlock) h12[b] = 0u;
+        if (threadIdx.x == 0) {
+            sc.sel_cnt = 0u;
+            sc.pending = V.call;
+            if (EMIT) sc.warm_lo[par ^ 1] = wlo;
+            if (FUSED == 1 && fz) sc.lam32 = lam32;
+        }
+    }
+    unsigned bad = 0u;
     if (obs_block) {
         const int k = blockIdx.x * kObsBlock + threadIdx.x;
         if (k < m) {
             const size_t ob = (size_t)w * V.obs_stride, mb = (size_t)w * V.m_max;
             const int pose = V.opose[2 * ob + k];
             PoseCam pc;
-            pose_camera(V.states_new + (sb + pose) * 10, V.intr + (sb + pose) * 4, pc);
+            if (FUSED && fz) {
+                double o[10], d9[9];
+                pose_trial_state<FUSED ? FUSED : 1>(V, w, pose, inv_wmax, lam32, o, d9, bad);
+                pose_camera(o, V.intr + (sb + pose) * 4, pc);
+            } else {
+                pose_camera(V.states_new + (sb + pose) * 10, V.intr + (sb + pose) * 4, pc);
+            }
             double u, v, cam[3], d;
             project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
-            const double wk = (V.wraw[mb + k] / bits_f64(sc.wmax_bits)) * V.oconf[ob + k];
+            const double wk = (V.wraw[mb + k] / wmax) * V.oconf[ob + k];
             const double du = V.ou[ob + k] - u, dv = V.ov[ob + k] - v;
             s = fabs(du * wk) + fabs(dv * wk);
             if (EMIT) {
                 const double ru = fabs(du), rv = fabs(dv);
                 reinterpret_cast<double2*>(V.absr + 2 * mb)[k] = make_double2(ru, rv);
                 s_raw = ru + rv;
-                atomicAdd(&lh[(unsigned)(f64_bits(ru) >> 53) & 1023u], 1u);
-                atomicAdd(&lh[(unsigned)(f64_bits(rv) >> 53) & 1023u], 1u);
+                atomicAdd(&lh[warm_bin(f64_bits(ru), wlo, V.warm_shift)], 1u);
+                atomicAdd(&lh[warm_bin(f64_bits(rv), wlo, V.warm_shift)], 1u);
             }
         }
+        bad = 0u;       // reported once, by the pose-chain blocks
     } else {
         const int db = blockIdx.x - V.nblk_obs;
-        const int i = db * kObsBlock + threadIdx.x;
+        const int i0 = db * kObsBlock;
+        const int i = i0 + threadIdx.x;
         const bool reg = V.reg && !prm.initialize;
+        const double* st = V.states_new + (sb + i) * 10;
+        const double* sn = st + 10;
+        if (FUSED && fz) {
+            // thread t forms pose i0 + t, thread 0 also pose i0 + 256 (the far end of the block's last edge)
+            const int extra = threadIdx.x == 0 ? 2 : 1;
+            for (int q = 0; q < extra; ++q) {
+                const int j = q ? i0 + kObsBlock : i;
+                if (j < n) {
+                    double o[10], d9[9];
+                    unsigned b2 = 0u;
+                    pose_trial_state<FUSED ? FUSED : 1>(V, w, j, inv_wmax, lam32, o, d9, b2);
+                    double* dst = snew + (size_t)(q ? kObsBlock : (int)threadIdx.x) * 10;
+#pragma unroll
+                    for (int r = 0; r < 10; ++r) dst[r] = o[r];
+                    if (!q) {
+                        bad = b2;
+#pragma unroll
+                        for (int r = 0; r < 10; ++r) V.states_new[(sb + j) * 10 + r] = o[r];
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) V.dpose[(sb + j) * 9 + r] = d9[r];
+                        if (FUSED == 1 && j == n - 1) {     // last_hessian of a landmark-only call: H / w_max on the 6x6, zeros elsewhere
+                            const double* H = V.Hraw + (sb + j) * 21;
+                            for (int e = 0; e < 81; ++e) {
+                                const int a = e / 9, c = e % 9;
+                                V.lastD[(size_t)w * 81 + e] = (a < 6 && c < 6) ? H[sym6(a, c)] * inv_wmax : 0.0;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            st = snew + (size_t)threadIdx.x * 10;
+            sn = st + 10;
+        }
         if (!prm.initialize && i < n - 1) {
-            const double* st = V.states_new + (sb + i) * 10;
-            const double* sn = st + 10;
             double x[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
             const int steps = V.steps[sb + i];
             propagate_gap<false>(x, nullptr, steps, V.hop);
@@ -446,17 +657,21 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
         }
         if (reg && i < n) {     // sum |r_prior| at the trial states (BA_filtering.py:175, 178), not scaled by sigma
             double r6[6];
-            prior_residual(V.prior_H + (sb + i) * 36, V.prior_x + (sb + i) * 6, V.states_new + (sb + i) * 10, r6);
+            prior_residual(V.prior_H + (sb + i) * 36, V.prior_x + (sb + i) * 6, st, r6);
             s += fabs(r6[0]) + fabs(r6[1]) + fabs(r6[2]) + fabs(r6[3]) + fabs(r6[4]) + fabs(r6[5]);
         }
     }
     const double t = block_sum<kObsBlock>(s, red);
     if (threadIdx.x == 0) V.part_trial[(size_t)w * (V.nblk_obs + V.nblk_dyn) + blockIdx.x] = t;
+    if (FUSED && !obs_block) {
+        const unsigned long long bp = __ballot(bad & 1u), bn = __ballot(bad & 2u);
+        if ((threadIdx.x & 63) == 0 && (bp || bn)) atomicOr(&sc.fl[par], (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
+    }
     if (EMIT && obs_block) {
         const double t_raw = block_sum<kObsBlock>(s_raw, red);
         if (threadIdx.x == 0) V.part_next[(size_t)w * V.nblk_obs + blockIdx.x] = t_raw;
-        unsigned* hist = V.hist + (size_t)w * kSelPasses * kSelBins;
-        for (int b = threadIdx.x; b < 1024; b += kObsBlock) {
+        unsigned* hist = hist0_of(V, w, par ^ 1);
+        for (int b = threadIdx.x; b < kSelBins; b += kObsBlock) {
             const unsigned c = lh[b];
             if (c) atomicAdd(&hist[b], c);
         }
@@ -488,7 +703,7 @@ __global__ __launch_bounds__(256) void k_broadcast_states(DevView V, int n, doub
     double* dst = V.states + (size_t)w * V.n_max * 10;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (w > 0 && k < n * 10) dst[k] = src[k];
-    if (k == 0) V.sc[w].lamda = lamda;
+    if (k == 0) V.sc[w].lam[V.par] = lamda;
 }
 
 // pose / row counts of a freshly uploaded window (m < 0: keep)
@@ -499,16 +714,28 @@ __global__ void k_set_counts(int* n_arr, int* m_arr, int w, int n, int m) {
 
 __global__ void k_reset_calls(DevView V) {
     const int w = blockIdx.x * 64 + threadIdx.x;
-    if (w < V.W) V.sc[w].call_idx = 0;
+    if (w < V.W) {
+        V.sc[w].call_idx = 0;
+        V.sc[w].pending = -1;
+    }
 }
 
-// exponent histogram left behind by a k_trial<true> whose states were replaced before anybody used it
-__global__ __launch_bounds__(1024) void k_clear_hist0(DevView V) {
-    V.hist[(size_t)blockIdx.x * kSelPasses * kSelBins + threadIdx.x] = 0u;
+// Digit-0 histogram of parity V.par (a warm histogram left by a trial whose states were then replaced, or one that a
+// repeated select is about to rebuild by exponent) and, which == 1, digits 1 and 2 as well (an exact select that no
+// trial followed).  which == 2: only the windows whose warm select missed.
+__global__ __launch_bounds__(1024) void k_clear_hist(DevView V, int which) {
+    const int w = blockIdx.x;
+    if (which == 2 && !V.sc[w].miss) return;
+    unsigned* h0 = hist0_of(V, w, V.par);
+    for (int b = threadIdx.x; b < kSelBins; b += 1024) h0[b] = 0u;
+    if (which == 1) {
+        unsigned* h12 = histd_of(V, w, 1);
+        for (int b = threadIdx.x; b < 2 * kSelBins; b += 1024) h12[b] = 0u;
+    }
 }
 
-void launch_clear_hist0(const DevView& V, hipStream_t s) {
-    hipLaunchKernelGGL(k_clear_hist0, dim3(V.W), dim3(1024), 0, s, V);
+void launch_clear_hist(const DevView& V, int which, hipStream_t s) {
+    hipLaunchKernelGGL(k_clear_hist, dim3(V.W), dim3(1024), 0, s, V, which);
 }
 
 void launch_set_counts(const DevView& V, int w, int n, int m, hipStream_t s) {
@@ -531,20 +758,35 @@ void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s) {
     else hipLaunchKernelGGL(k_obs_residual<true>, dim3(V.nblk_obs, V.W), dim3(kObsBlock), 0, s, V, abs_out);
 }
 
-void launch_select(const DevView& V, hipStream_t s) {
+// exact select (digits 1 and 2 over the keys; digit 0 comes from k_obs_residual, or -- with_digit0 -- from a pass of its
+// own: sharded mode's gathered keys, a select repeated after a warm miss)
+void launch_select(const DevView& V, bool with_digit0, hipStream_t s) {
     const int64_t count = V.abs_all ? V.abs_all_count : 2 * V.m_max;
     const dim3 b(256);
     if (V.W >= 16) {
         const int nb = (int)((count + 256 * 32 - 1) / (256 * 32));
         const dim3 g(nb > 0 ? nb : 1, V.W);
+        if (with_digit0) hipLaunchKernelGGL((k_select_pass<0, false, 32>), g, b, 0, s, V);
         hipLaunchKernelGGL((k_select_pass<1, false, 32>), g, b, 0, s, V);
         hipLaunchKernelGGL((k_select_pass<2, true, 32>), g, b, 0, s, V);
     } else {
         const int nb = (int)((count + 256 * kSelItems - 1) / (256 * kSelItems));
         const dim3 g(nb > 0 ? nb : 1, V.W);
-        if (V.abs_all) hipLaunchKernelGGL((k_select_pass<0, false, kSelItems>), g, b, 0, s, V);   // sharded: digit 0 over the gathered keys
+        if (with_digit0) hipLaunchKernelGGL((k_select_pass<0, false, kSelItems>), g, b, 0, s, V);
         hipLaunchKernelGGL((k_select_pass<1, false, kSelItems>), g, b, 0, s, V);
         hipLaunchKernelGGL((k_select_pass<2, true, kSelItems>), g, b, 0, s, V);
+    }
+}
+
+// warm select on carried keys: one pass (plus, V.fold, the accept test of the call in front)
+void launch_select_warm(const DevView& V, hipStream_t s) {
+    const int64_t count = 2 * V.m_max;
+    if (V.W >= 16) {
+        const int nb = (int)((count + 256 * 32 - 1) / (256 * 32));
+        hipLaunchKernelGGL((k_select_warm<32>), dim3(nb > 0 ? nb : 1, V.W), dim3(256), 0, s, V);
+    } else {
+        const int nb = (int)((count + 256 * kSelItems - 1) / (256 * kSelItems));
+        hipLaunchKernelGGL((k_select_warm<kSelItems>), dim3(nb > 0 ? nb : 1, V.W), dim3(256), 0, s, V);
     }
 }
 
@@ -568,8 +810,16 @@ void launch_obs_accumulate(const DevView& V, hipStream_t s) {
 
 void launch_trial(const DevView& V, hipStream_t s) {
     const dim3 g(V.nblk_obs + V.nblk_dyn, V.W), b(kObsBlock);
-    if (V.emit) hipLaunchKernelGGL(k_trial<true>, g, b, 0, s, V);
-    else hipLaunchKernelGGL(k_trial<false>, g, b, 0, s, V);
+    const int f = V.fused_trial;
+    if (V.emit) {
+        if (f == 1) hipLaunchKernelGGL((k_trial<true, 1>), g, b, 0, s, V);
+        else if (f == 2) hipLaunchKernelGGL((k_trial<true, 2>), g, b, 0, s, V);
+        else hipLaunchKernelGGL((k_trial<true, 0>), g, b, 0, s, V);
+    } else {
+        if (f == 1) hipLaunchKernelGGL((k_trial<false, 1>), g, b, 0, s, V);
+        else if (f == 2) hipLaunchKernelGGL((k_trial<false, 2>), g, b, 0, s, V);
+        else hipLaunchKernelGGL((k_trial<false, 0>), g, b, 0, s, V);
+    }
 }
 
 void launch_debug_project(const DevView& V, int w, int m, double* est, double* J, double* wt, hipStream_t s) {

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_shard_reduce(DevView V, const double* a
             sa += all[q * stride + cnt + 1];
         }
         V.sc[0].wmax_bits = f64_bits(mx);
-        V.sc[0].sum_abs_robs = sa;
+        V.sc[0].sum_in[V.par] = sa;
     }
 }
 

@@ -23,8 +23,11 @@
 //                      separators), a reduced block-tridiagonal system over the P-1 separators is solved by one
 //                      wave, and the interiors are recovered in parallel: ~ n/P + P sequential block steps
 //                      instead of n.
+#include "vba_asm.h"
+#include "vba_decide.h"
 #include "vba_device.h"
 #include "vba_launch.h"
+#include "vba_step.h"
 
 namespace vba {
 
@@ -173,13 +176,13 @@ __device__ __forceinline__ void forward_step(const double* Lmat, const double (&
 template <bool PIVOT>
 __device__ __forceinline__ bool solver_mine(const DevView& V, const WinScalars& sc) {
     if (V.pivot == 1) return PIVOT;
-    return ((sc.flags & 16u) != 0) == PIVOT;
+    return ((sc.fl[V.par] & 16u) != 0) == PIVOT;
 }
 
 template <bool PIVOT>
-__device__ __forceinline__ void report_pivot(bool bad, WinScalars& sc, int lane) {
+__device__ __forceinline__ void report_pivot(bool bad, WinScalars& sc, int lane, int par) {
     const unsigned long long any = __ballot(bad);
-    if (lane == 0 && any) atomicOr(&sc.flags, PIVOT ? 4u : (8u | 16u));
+    if (lane == 0 && any) atomicOr(&sc.fl[par], PIVOT ? 4u : (8u | 16u));
 }
 
 // ================================================================================================== sequential
@@ -314,18 +317,18 @@ __global__ __launch_bounds__(64) void k_solve(DevView V) {
     const int n = V.n[w];
     const int lane = threadIdx.x;
     const size_t sb = (size_t)w * V.n_max;
-    const double lam32 = (double)(float)sc.lamda;      // torch.eye() is float32 (BA_filtering.py:54)
+    const double lam32 = (double)(float)sc.lam[V.par];      // torch.eye() is float32 (BA_filtering.py:54)
     if (lane == 0) {
         sc.lam32 = lam32;
-        if (PIVOT) atomicAnd(&sc.flags, ~8u);
+        if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
     }
     bool badp = false;
     const BandSource src{V.bands + sb * 243, V.rhs + sb * 9};
     chain_solve<PIVOT, true>(src, n, lam32, V.Xs + sb * 81, V.zs + sb * 9, V.dpose + sb * 9, blk, lane, badp);
-    report_pivot<PIVOT>(badp, sc, lane);
+    report_pivot<PIVOT>(badp, sc, lane, V.par);
     const bool bad = retract_range(V, sb, n, lane, 64);
     const unsigned long long anybad = __ballot(bad);
-    if (lane == 0 && anybad) atomicOr(&sc.flags, 2u);
+    if (lane == 0 && anybad) atomicOr(&sc.fl[V.par], 2u);
 }
 
 // ---------------------------------------------------------------------------------------------- packed
@@ -347,12 +350,12 @@ __global__ __launch_bounds__(64) void k_solve_packed(DevView V) {
     const bool w_ok = w0 + g < V.W;
     const int n = V.n[w0];
     WinScalars& sc = V.sc[wg];
-    const bool active = lane_ok && w_ok && !sc.done && (V.call < 0 || sc.call_idx == V.call) && solver_mine<PIVOT>(V, sc);
+    const bool active = lane_ok && w_ok && !sc.done && VBA_WINDOW_RUNS(V, wg) && solver_mine<PIVOT>(V, sc);
     const size_t sb = (size_t)wg * V.n_max;
-    const double lam32 = (double)(float)sc.lamda;
+    const double lam32 = (double)(float)sc.lam[V.par];
     if (active && ll == 0) {
         sc.lam32 = lam32;
-        if (PIVOT) atomicAnd(&sc.flags, ~8u);
+        if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
     }
     double a[9];
 #pragma unroll
@@ -453,12 +456,12 @@ __global__ __launch_bounds__(64) void k_solve_packed(DevView V) {
         const int w = w0 + q3;
         if (w >= V.W) break;
         WinScalars& s3 = V.sc[w];
-        if (s3.done || (V.call >= 0 && s3.call_idx != V.call) || !solver_mine<PIVOT>(V, s3)) continue;
+        if (s3.done || !VBA_WINDOW_RUNS(V, w) || !solver_mine<PIVOT>(V, s3)) continue;
         const unsigned long long gm = ((1ull << 19) - 1ull) << (19 * q3);
-        if (lane == 0 && (badmask & gm)) atomicOr(&s3.flags, PIVOT ? 4u : 8u);
+        if (lane == 0 && (badmask & gm)) atomicOr(&s3.fl[V.par], PIVOT ? 4u : 8u);
         const bool bad = retract_range(V, (size_t)w * V.n_max, n, lane, 64);
         const unsigned long long anybad = __ballot(bad);
-        if (lane == 0 && anybad) atomicOr(&s3.flags, 2u);
+        if (lane == 0 && anybad) atomicOr(&s3.fl[V.par], 2u);
     }
 }
 
@@ -657,15 +660,82 @@ __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
     const int lane = threadIdx.x;
     const size_t sb = (size_t)w * V.n_max;
     const size_t rb = (size_t)w * V.p_max;
-    const double lam32 = (double)(float)sc.lamda;
+    const double lam32 = (double)(float)sc.lam[V.par];
     if (c == 0 && lane == 0) {
         sc.lam32 = lam32;
-        if (PIVOT) atomicAnd(&sc.flags, ~8u);
+        if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
     }
     bool bad = false;
     const BandSource src{V.bands + sb * 243, V.rhs + sb * 9};
     chunk_eliminate<PIVOT, true>(src, n, s, c, lam32, V.csol + sb * 171, V.cL + rb * 171, V.cR + rb * 171, smem, lane, bad);
-    report_pivot<PIVOT>(bad, sc, lane);
+    report_pivot<PIVOT>(bad, sc, lane, V.par);
+}
+
+// Latency mode: the chunk's wave(s) build the blocks of the chunk themselves (no assembly launch, no round trip of the
+// bands through memory).  The 256 threads of the block stage the per-pose inputs of the chunk and of its two
+// neighbours in LDS and form the (at most s + 1) blocks  a - 1 .. b + 1  there; the first wave then eliminates the chunk
+// exactly as k_solve_chunks does, reading blocks from LDS.  What the later kernels need from the system itself -- the
+// diagonal block and right-hand side of the chunk's right separator (reduced system), the last pose's diagonal block
+// (last_hessian) -- is written out on the way.
+struct LdsBlockSource {
+    const double* blocks;   // [count][252]
+    int first;              // pose index of blocks[0]
+    __device__ double operator()(int i, int e) const { return blocks[(size_t)(i - first) * 252 + e]; }
+};
+
+template <bool PIVOT, bool REG>
+__global__ __launch_bounds__(256) void k_solve_chunks_fused(DevView V, int s) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int kAsmIn = kAsmBase + (REG ? kAsmPrior : 0);
+    const int w = blockIdx.y, c = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n = V.n[w];
+    if (c * s >= n) return;
+    const int tid = threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lam[V.par];
+    if (c == 0 && tid == 0) {
+        sc.lam32 = lam32;
+        if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
+    }
+    int a0, b0;
+    bool has_sep;
+    chunk_range(c, s, n, a0, b0, has_sep);
+    const int j0 = a0 > 0 ? a0 - 1 : 0, j1 = has_sep ? b0 + 1 : b0;         // blocks formed here
+    const int nblk = j1 - j0 + 1;
+    double* elim = smem;                                                     // scratch of chunk_eliminate
+    double* blocks = smem + (512 + (size_t)s * 252 + 162);                   // [s + 1][252]
+    double* in = blocks + (size_t)(s + 1) * 252;                             // [s + 2][kAsmIn]: poses j0 - 1 .. j1
+    asm_stage<REG>(V, w, n, true, j0 - 1, nblk + 1, in, tid, 256);
+    __syncthreads();
+    const double inv_wmax = 1.0 / bits_f64(sc.wmax_bits);
+    for (int idx = tid; idx < nblk * 252; idx += 256) {
+        const int q = idx / 252, e = idx % 252;
+        const int i = j0 + q;
+        const AsmRow R = asm_row<REG>(in + (size_t)(q + 1) * kAsmIn, in + (size_t)q * kAsmIn, i, n, true, V.prm.sigma, inv_wmax);
+        double v;
+        if (e >= 243) {
+            v = rhs_entry(R, e - 243);
+            if (has_sep && i == j1) V.rhs[(sb + i) * 9 + (e - 243)] = v;
+        } else {
+            const int which = e / 81, a = (e % 81) / 9, b = e % 9;
+            v = band_entry(R, which, a, b);
+            if (which == 1) {
+                if (has_sep && i == j1) V.bands[(sb + i) * 243 + e] = v;
+                if (i == n - 1) V.lastD[(size_t)w * 81 + (e - 81)] = v;
+            }
+        }
+        blocks[idx] = v;
+    }
+    __syncthreads();
+    if (tid >= 64) return;      // the elimination is one wave's work (its barriers count the surviving wave only)
+    bool bad = false;
+    const LdsBlockSource src{blocks, j0};
+    chunk_eliminate<PIVOT, true>(src, n, s, c, lam32, V.csol + sb * 171, V.cL + rb * 171, V.cR + rb * 171, elim, tid, bad);
+    report_pivot<PIVOT>(bad, sc, tid, V.par);
 }
 
 // level 2: the reduced system over the level-1 separators is itself cut into chunks of s2
@@ -681,11 +751,11 @@ __global__ __launch_bounds__(64) void k_solve_chunks2(DevView V, int s, int s2) 
     const int lane = threadIdx.x;
     const size_t sb = (size_t)w * V.n_max;
     const size_t rb = (size_t)w * V.p_max;
-    const double lam32 = (double)(float)sc.lamda;
+    const double lam32 = (double)(float)sc.lam[V.par];
     bool bad = false;
     const ReducedSource<BandSource> src{BandSource{V.bands + sb * 243, V.rhs + sb * 9}, V.cL + rb * 171, V.cR + rb * 171, s};
     chunk_eliminate<PIVOT, false>(src, n1, s2, c, lam32, V.csol2 + rb * 171, V.cL2 + rb * 171, V.cR2 + rb * 171, smem, lane, bad);
-    report_pivot<PIVOT>(bad, sc, lane);
+    report_pivot<PIVOT>(bad, sc, lane, V.par);
 }
 
 // Solves the last reduced block-tridiagonal system (one wave per window): over the level-1 separators (s2 == 0)
@@ -702,7 +772,7 @@ __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s, int s2) 
     const int lane = threadIdx.x;
     const size_t sb = (size_t)w * V.n_max;
     const size_t rb = (size_t)w * V.p_max;
-    const double lam32 = (double)(float)sc.lamda;
+    const double lam32 = (double)(float)sc.lam[V.par];
     const ReducedSource<BandSource> src1{BandSource{V.bands + sb * 243, V.rhs + sb * 9}, V.cL + rb * 171, V.cR + rb * 171, s};
     bool zero_pivot = false;
     if (s2 == 0) {
@@ -714,7 +784,7 @@ __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s, int s2) 
             chain_solve<PIVOT, false>(src2, n2, lam32, V.rXs + rb * 81, V.rzs + rb * 9, V.rx2 + rb * 9, blk, lane, zero_pivot);
         }
     }
-    report_pivot<PIVOT>(zero_pivot, sc, lane);
+    report_pivot<PIVOT>(zero_pivot, sc, lane, V.par);
 }
 
 // The reduced system over the separators by block cyclic reduction inside ONE workgroup (16 waves, the whole system
@@ -728,6 +798,7 @@ __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s, int s2) 
 // per-pivot check; PIVOT exchanges rows inside a block as everywhere else.
 // LDS: n1 blocks of 252 doubles [L | D | U | g]; x overwrites g.  n1 <= kCrMax.
 constexpr int kCrMax = 64;
+constexpr int kFusedChunkMax = 28;  // largest chunk whose blocks, staged inputs and elimination scratch fit 160 KiB of LDS
 constexpr int kCrThreads = 1024;
 constexpr int kCrSplitMin = 24;     // from this many separators on, the first level runs as its own multi-CU kernel
 
@@ -899,7 +970,7 @@ __global__ __launch_bounds__(64) void k_cr_level0(DevView V, int s) {
     if (n1 < kCrSplitMin || n1 > 2 * kCrMax || 2 * t >= n1) return;
     const int lane = threadIdx.x;
     const size_t rb = (size_t)w * V.p_max;
-    const double lam32 = (double)(float)sc.lamda;
+    const double lam32 = (double)(float)sc.lam[V.par];
     cr_fill<3>(V, w, s, n1, lam32, 2 * t, 1, blk, 1, lane);
     __syncthreads();
     const CrLanes g = cr_lanes(lane);
@@ -914,7 +985,7 @@ __global__ __launch_bounds__(64) void k_cr_level0(DevView V, int s) {
         double* R = V.cL2 + rb * 171 + (size_t)t * 252;
         for (int e = lane; e < 252; e += 64) R[e] = blk[252 + e];
     }
-    report_pivot<PIVOT>(bad, sc, lane);
+    report_pivot<PIVOT>(bad, sc, lane, V.par);
 }
 
 // PRE: the first level has been done by k_cr_level0; this kernel continues with the n1 / 2 folded blocks and finishes
@@ -933,7 +1004,7 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = kCrThreads / 64;
     const size_t rb = (size_t)w * V.p_max;
-    const double lam32 = (double)(float)sc.lamda;
+    const double lam32 = (double)(float)sc.lam[V.par];
     if (PRE) {
         const double* R = V.cL2 + rb * 171;
         for (int idx = tid; idx < n1 * 252; idx += kCrThreads) smem[idx] = R[idx];
@@ -1011,7 +1082,7 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
             V.rx[rb * 9 + idx] = x;
         }
     }
-    report_pivot<PIVOT>(bad, sc, lane);
+    report_pivot<PIVOT>(bad, sc, lane, V.par);
 }
 
 // Recovery of a partitioned chain: x_i = yhat_i - Vhat_i x_left - What_i x_right for interior blocks, separators
@@ -1107,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_solve_recover(DevView V, int s) {
         for (int q = 0; q < 10; ++q) V.states_new[(sb + i) * 10 + q] = o[q];
     }
     const unsigned long long anybad = __ballot(bad);
-    if ((threadIdx.x & 63) == 0 && anybad) atomicOr(&sc.flags, 2u);
+    if ((threadIdx.x & 63) == 0 && anybad) atomicOr(&sc.fl[V.par], 2u);
 }
 
 // Landmark-only phase (initialize): the dynamics factor is absent (BA_utils.py:463-466), the system is block
@@ -1124,10 +1195,10 @@ __global__ __launch_bounds__(64) void k_solve_blockdiag(DevView V, int PB) {
     if (i0 >= n) return;
     const int lane = threadIdx.x;
     const size_t sb = (size_t)w * V.n_max;
-    const double lam32 = (double)(float)sc.lamda;
+    const double lam32 = (double)(float)sc.lam[V.par];
     if (blockIdx.x == 0 && lane == 0) {
         sc.lam32 = lam32;
-        if (PIVOT) atomicAnd(&sc.flags, ~8u);
+        if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
     }
     const int cnt = min(PB, n - i0);
     bool badp = false;
@@ -1166,170 +1237,77 @@ __global__ __launch_bounds__(64) void k_solve_blockdiag(DevView V, int PB) {
         }
         __syncthreads();
     }
-    report_pivot<PIVOT>(badp, sc, lane);
+    report_pivot<PIVOT>(badp, sc, lane, V.par);
 }
 
 // ================================================================================================== accept test
-// LM accept test (BA_filtering.py:51, 66-79).  ranks == 0: sum this window's block partials; ranks > 0: the
-// observation part is the rank-ordered sum of the gathered per-rank sums (sharded mode).
-//
-// One block per window and nothing but latency: the kernel is a handful of dependent round trips to memory, so every
-// load whose address does not depend on loaded data (scalars, all block partials, the dynamics residuals, the states
-// to be committed) is issued up front, speculatively, and the four block sums share one reduction.  The sums are
-// formed in the same order as by block_sum (per-thread strided partials, wave butterflies, wave totals in order).
-constexpr int kDecideThreads = 1024;
-constexpr int kDecidePre = 5;       // state elements per thread loaded ahead of the decision (covers 512 poses)
-
-__global__ __launch_bounds__(kDecideThreads) void k_decide(DevView V, const double* trial_all, int ranks) {
-    __shared__ double red[5][kDecideThreads / 64];
-    __shared__ int bstop;
+// LM accept test (BA_filtering.py:51, 66-79) as its own launch, one block per window: vba_decide.h has the arithmetic.
+// ranks == 0: this window's block partials; ranks > 0: the observation part is the rank-ordered sum of the gathered
+// per-rank sums (sharded mode).  What a call hands to the next is written to the slots of the other parity; the states
+// need no copy (the buffer the last trial wrote IS the next call's input).
+__global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_all, int ranks) {
+    __shared__ double red[5][4];
     const int w = blockIdx.x;
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     const int t = threadIdx.x;
-    const StepParams& prm = V.prm;
-    const size_t sb = (size_t)w * V.n_max;
-    // ---- loads, all independent of each other
-    const int done = sc.done;
-    const unsigned flags = sc.flags;
+    const int par = V.par;
+    if (sc.done || (V.pending_only && sc.pending != V.call)) return;
     const int n_trials = sc.n_trials;
-    const double init_prev = sc.init_residual, lam_in = sc.lamda, lam32 = sc.lam32;
-    const double so_carried = sc.next_sum_abs_robs, so_sharded = sc.sum_abs_robs;
-    const int n = V.n[w], m = V.m[w];
-    double s_init = 0.0, s_pred = 0.0, s_trial = 0.0, s_next = 0.0, s_prior = 0.0;
-    const bool reg = V.reg && !prm.initialize;
-    if (V.m_total == 0 && !V.carry) {
-        const double* pi = V.part_init + (size_t)w * V.nblk_obs;
-        for (int b = t; b < V.nblk_obs; b += kDecideThreads) s_init += pi[b];
-    }
-    if (!prm.initialize) {
-        for (int i = t; i < V.n_max - 1; i += kDecideThreads) {
-            const double* ro = V.rorb + (sb + i) * 6;
-            const double v = fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]) + fabs(V.fatt[sb + i]);
-            if (i < n - 1) s_pred += v;
-        }
-    }
-    if (reg) {      // BA_reg: sum |r_prior| at the input states (BA_filtering.py:163)
-        for (int i = t; i < V.n_max; i += kDecideThreads) {
-            double r6[6];
-            prior_residual(V.prior_H + (sb + i) * 36, V.prior_x + (sb + i) * 6, V.states + (sb + i) * 10, r6);
-            const double v = fabs(r6[0]) + fabs(r6[1]) + fabs(r6[2]) + fabs(r6[3]) + fabs(r6[4]) + fabs(r6[5]);
-            if (i < n) s_prior += v;
-        }
-    }
-    if (ranks == 0) {
-        const double* pt = V.part_trial + (size_t)w * (V.nblk_obs + V.nblk_dyn);
-        for (int b = t; b < V.nblk_obs + V.nblk_dyn; b += kDecideThreads) s_trial += pt[b];
-    }
-    if (V.emit) {
-        const double* pn = V.part_next + (size_t)w * V.nblk_obs;
-        for (int b = t; b < V.nblk_obs; b += kDecideThreads) s_next += pn[b];
-    }
-    const double* s_new = V.states_new + sb * 10;
-    double* s_cur = V.states + sb * 10;
-    double* s_prev = V.states_prev + sb * 10;
-    double pre_new[kDecidePre], pre_cur[kDecidePre];
-#pragma unroll
-    for (int j = 0; j < kDecidePre; ++j) {
-        const int k = t + j * kDecideThreads;
-        const bool in = k < V.n_max * 10;
-        pre_new[j] = in ? s_new[k] : 0.0;
-        pre_cur[j] = in ? s_cur[k] : 0.0;
-    }
-    double sh_trial = 0.0;
-    if (ranks > 0) {
-        sh_trial = trial_all[1];
-        for (int q = 0; q < ranks; ++q) sh_trial += trial_all[2 * q];
-    }
-    // ---- decisions
-    if (done) return;
-    unsigned* hist0 = V.hist + (size_t)w * kSelPasses * kSelBins;     // digit 0, filled by k_trial<true>
-    if (flags & 8u) {               // the un-pivoted solve failed its check: the host repeats it with pivoting
-        if (V.emit) for (int b = t; b < 1024; b += kDecideThreads) hist0[b] = 0u;
+    const double lam32 = sc.lam32;
+    const DecideOut d = decide_eval(V, w, par, V.prm, n_trials, sc.init_residual, trial_all, ranks, red);
+    unsigned* hist_next = hist0_of(V, w, par ^ 1);      // filled by k_trial<true>
+    if (d.flags & 8u) {             // the un-pivoted solve failed its check: the host repeats it with pivoting
+        if (V.emit) for (int b = t; b < kSelBins; b += 256) hist_next[b] = 0u;
         if (t == 0) {
-            V.host_head[w].flags = flags;
+            sc.miss = 0;
+            V.host_head[w].flags = d.flags;
             V.host_head[w].done = 0;
         }
         return;
     }
-    const double D_last = t < 81 ? V.bands[(sb + n - 1) * 243 + 81 + t] : 0.0;
-    {   // four block sums with one pair of barriers
-        const double v5[5] = {wave_sum(s_init), wave_sum(s_pred), wave_sum(s_trial), wave_sum(s_next), wave_sum(s_prior)};
-        if ((t & 63) == 0) {
-#pragma unroll
-            for (int q = 0; q < 5; ++q) red[q][t >> 6] = v5[q];
-        }
+    if (d.stop) {
+        if (t < 81) sc.last_hessian[t] = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
+    } else if (V.emit) {            // rejected: the next trial histograms its own keys
+        for (int b = t; b < kSelBins; b += 256) hist_next[b] = 0u;
     }
-    __syncthreads();
-    const double lam = lam_in * 10.0;
     if (t == 0) {
-        double tot[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            double a = 0.0;
-#pragma unroll
-            for (int i = 0; i < kDecideThreads / 64; ++i) a += red[q][i];
-            tot[q] = a;
-        }
-        const double M = V.m_total ? (double)V.m_total : (double)m;
-        // BA_reg: the prior adds 7 entries per pose to both means (6 zeros per pose in the landmark-only phase); the 7th
-        // is prior_gpu's constant rotation residual quat_coeff: 1 in the initial residual, 100 in every trial, as the
-        // reference passes its coefficients (BA_filtering.py:121, 163 vs :175, 178-180)
-        const double denom = 2.0 * M + (prm.initialize ? 6.0 : 7.0) * (double)(n - 1) +
-                             (V.reg ? (prm.initialize ? 6.0 : 7.0) * (double)n : 0.0);
-        double init_residual = init_prev;
+        unsigned fl = d.flags;
         if (n_trials == 0) {
-            // init_residual = mean |[r_obs ; sqrt(Sigma) r_pred]| with UNweighted r_obs (BA_filtering.py:51)
-            // carried keys: the same block sums were added up the same way when that trial was accepted
-            const double so = V.m_total ? so_sharded : (V.carry ? so_carried : tot[0]);
-            const double sp = prm.initialize ? 0.0 : tot[1] * prm.sqrt_sigma;
-            init_residual = (so + sp + (reg ? tot[4] + 1.0 * (double)n : 0.0)) / denom;
-            sc.sum_abs_robs = so;
-            sc.sum_abs_rpred = sp;
-            sc.init_residual = init_residual;
+            sc.sum_abs_rpred = d.sum_pred;
+            sc.init_residual = d.init_residual;
         }
-        const double S = (ranks > 0 ? sh_trial : tot[2]) + (reg ? 100.0 * (double)n : 0.0);
-        const double residual = S / denom;
-        const bool accept = residual < init_residual;
-        const bool stop = accept || lam > 1e4;
-        bstop = stop ? 1 : 0;
-        unsigned fl = flags;
-        if (V.emit && stop) sc.next_sum_abs_robs = tot[3];
-        sc.trial_residual = residual;
+        sc.trial_residual = d.residual;
         sc.n_trials = n_trials + 1;
-        double lam_out = lam;
+        sc.pending = -1;
+        sc.miss = 0;
         int call_idx = sc.call_idx;
-        if (stop) {
+        double lam_now = d.lam_next;
+        if (d.stop) {
             sc.done = 1;
             if (V.call >= 0) sc.call_idx = call_idx = V.call + 1;
-            if (!accept) fl |= 1u;
-            if (!(residual == residual)) fl |= 2u;
-            sc.flags = fl;
-            lam_out = fmax(fmin(1e-1, lam * 0.01), 1e-4);
+            if (!d.accept) fl |= 1u;
+            if (!(d.residual == d.residual)) fl |= 2u;
+            sc.fl[par] = fl;
+            sc.lam[par ^ 1] = lam_now = d.lam_out;
+            if (V.emit) sc.sum_in[par ^ 1] = d.sum_next;
+        } else {
+            sc.lam[par] = lam_now;
         }
-        sc.lamda = lam_out;
         // read by the host after it has waited for the stream: no fence needed
         WinHead& hh = V.host_head[w];
-        hh.lamda = lam_out;
-        hh.trial_residual = residual;
+        hh.lamda = lam_now;
+        hh.trial_residual = d.residual;
         hh.n_trials = n_trials + 1;
         hh.flags = fl;
-        hh.done = stop ? 1 : 0;
+        hh.done = d.stop ? 1 : 0;
         hh.call_idx = call_idx;
     }
-    __syncthreads();
-    if (bstop) {
-#pragma unroll
-        for (int j = 0; j < kDecidePre; ++j) {
-            const int k = t + j * kDecideThreads;
-            if (k < n * 10) { s_prev[k] = pre_cur[j]; s_cur[k] = pre_new[j]; }
-        }
-        for (int k = t + kDecidePre * kDecideThreads; k < n * 10; k += kDecideThreads) { s_prev[k] = s_cur[k]; s_cur[k] = s_new[k]; }
-        if (t < 81) sc.last_hessian[t] = D_last + ((t / 9 == t % 9) ? lam32 : 0.0);
-    } else if (V.emit) {            // rejected: the next trial histograms its own keys
-        for (int b = t; b < 1024; b += kDecideThreads) hist0[b] = 0u;
-    }
 }
+
+// latency mode with a partitioned chain whose chunk (blocks + staged inputs + elimination scratch) fits the LDS of a CU:
+// the chunk kernel forms its blocks itself and k_assemble is not launched (vba_api.hip asks the same question)
+bool solve_forms_blocks(const DevView& V) { return V.lat && !V.prm.initialize && V.chunk >= 2 && V.chunk <= kFusedChunkMax; }
 
 template <bool PIVOT>
 static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s) {
@@ -1346,7 +1324,14 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
     const int cs = V.chunk, cs2 = V.chunk2;
     const int P = (V.n_max + cs - 1) / cs;
     const size_t lds = (512 + (size_t)cs * 252 + 162) * sizeof(double);
-    hipLaunchKernelGGL(k_solve_chunks<PIVOT>, dim3(P, V.W), dim3(64), lds, s, V, cs);
+    if (solve_forms_blocks(V)) {
+        const bool reg = V.reg != 0;
+        const size_t ldsf = lds + ((size_t)(cs + 1) * 252 + (size_t)(cs + 2) * (kAsmBase + (reg ? kAsmPrior : 0))) * sizeof(double);
+        if (reg) hipLaunchKernelGGL((k_solve_chunks_fused<PIVOT, true>), dim3(P, V.W), dim3(256), ldsf, s, V, cs);
+        else hipLaunchKernelGGL((k_solve_chunks_fused<PIVOT, false>), dim3(P, V.W), dim3(256), ldsf, s, V, cs);
+    } else {
+        hipLaunchKernelGGL(k_solve_chunks<PIVOT>, dim3(P, V.W), dim3(64), lds, s, V, cs);
+    }
     if (cs2 > 0) {      // second level over the P-1 separators
         const int P2 = (P - 1 + cs2 - 1) / cs2;
         const size_t lds2 = (512 + (size_t)cs2 * 252 + 162) * sizeof(double);
@@ -1372,7 +1357,10 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
 hipError_t configure_solver_device() {
     const int cap = (int)((512 + 60 * 252 + 162) * sizeof(double));     // chunks above ~30 poses exceed the default 64 KiB
     const int cap_cr = kCrMax * 252 * (int)sizeof(double);
+    const int cap_f = (int)((512 + kFusedChunkMax * 252 + 162 + (kFusedChunkMax + 1) * 252 + (kFusedChunkMax + 2) * (kAsmBase + kAsmPrior)) * sizeof(double));
     const struct { const void* fn; int bytes; } set[] = {
+        {reinterpret_cast<const void*>(k_solve_chunks_fused<false, false>), cap_f}, {reinterpret_cast<const void*>(k_solve_chunks_fused<true, false>), cap_f},
+        {reinterpret_cast<const void*>(k_solve_chunks_fused<false, true>), cap_f}, {reinterpret_cast<const void*>(k_solve_chunks_fused<true, true>), cap_f},
         {reinterpret_cast<const void*>(k_solve_chunks<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks<true>), cap},
         {reinterpret_cast<const void*>(k_solve_chunks2<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks2<true>), cap},
         {reinterpret_cast<const void*>(k_solve_reduced_cr<false, false>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, false>), cap_cr},
@@ -1391,12 +1379,13 @@ void launch_solve(const DevView& V, int initialize, hipStream_t s) {
     if (initialize) hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 15) / 16, V.W), dim3(256), 0, s, V, 0);
     else if (V.chunk > 0) {
         if (V.chunk2 > 0) hipLaunchKernelGGL(k_solve_recover2, dim3((V.p_max + 63) / 64, V.W), dim3(64), 0, s, V, V.chunk, V.chunk2);
-        hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 15) / 16, V.W), dim3(256), 0, s, V, V.chunk);
+        // latency mode: the trial kernel recovers the interiors and retracts (V.fused_trial == 2)
+        if (V.fused_trial != 2) hipLaunchKernelGGL(k_solve_recover, dim3((V.n_max + 15) / 16, V.W), dim3(256), 0, s, V, V.chunk);
     }
 }
 
 void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(V.W), dim3(kDecideThreads), 0, s, V, trial_all, ranks);
+    hipLaunchKernelGGL(k_decide, dim3(V.W), dim3(256), 0, s, V, trial_all, ranks);
 }
 
 }  // namespace vba

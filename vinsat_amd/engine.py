@@ -66,6 +66,16 @@ class BAEngine:
         """True (default): an accepted trial leaves the next call's |r| keys behind; False: every call recomputes them."""
         _lib.check(self.lib.vba_set_key_carry(self.h, int(bool(on))), self.lib)
 
+    def set_warm_select(self, on):
+        """True (default): carried keys are selected with one warm pass (and chained calls fold their accept test into it);
+        False: exact digit passes and a decide launch per call."""
+        _lib.check(self.lib.vba_set_warm_select(self.h, 2 if on == 2 else int(bool(on))), self.lib)
+
+    def warm_select_misses(self):
+        c = c_int()
+        _lib.check(self.lib.vba_warm_select_misses(self.h, byref(c)), self.lib)
+        return c.value
+
     def set_pivoting(self, always):
         """False (default): unpivoted fast path with checked pivots and automatic fallback; True: always pivot."""
         _lib.check(self.lib.vba_set_pivoting(self.h, int(bool(always))), self.lib)
