@@ -137,6 +137,15 @@ int vba_set_key_carry(vba_handle h, int on);
 int vba_set_warm_select(vba_handle h, int on);
 int vba_warm_select_misses(vba_handle h, int* count);
 
+/* Kernel fusion of the latency mode (fewer than 16 windows per handle), a bit mask; same results to rounding.
+ *   bit 0: the trial kernel forms the step of each pose itself (landmark-only phase: the 6x6 solve; full phase: the
+ *          recovery of the partitioned solve) -- no recovery launch and, in the landmark-only phase, no assembly + solve launch;
+ *   bit 1: the chunk elimination forms the blocks of its chunk in LDS itself -- no assembly launch in the full phase, the
+ *          bands never go through memory.
+ * Default 0: measured on MI355X, a kernel boundary (~2.5 us) is cheaper than the instructions either fusion adds to
+ * every wave of the fused kernel; the modes stay for comparison and are covered by the parity tests. */
+int vba_set_fusion(vba_handle h, int mask);
+
 /* Row pivoting inside the 9x9 diagonal blocks.  always == 0 (default): the blocks are eliminated without row
  * exchanges (the damped normal equations are positive definite up to a ~1e-6 non-symmetric term) while every pivot
  * is checked against the diagonal entry it started from; a failed check repeats that solve with pivoting, so the

@@ -34,7 +34,7 @@ def main():
         g = load_golden(fx)
         inp = golden_inputs(g)
         n, m = inp["K"].shape[0], inp["xyz"].shape[0]
-        calls = [k for k in range(20) if f"dpose_{k}" in g and g["n_trials"][k] == 1]
+        calls = [k for k in range(20) if f"dpose_{k}" in g]      # the device keeps the LAST trial's solution: compare with the reference's last
         for name, (c1, c2, piv) in VARIANTS.items():
             eng = BAEngine(n, m)
             if c2 is None:
@@ -48,14 +48,14 @@ def main():
             for k in calls:
                 st_in = g[f"states_in_{k}"][0] if f"states_in_{k}" in g else (g["states0"][0] if k == 0 else g[f"states_out_{k-1}"][0])
                 eng.iterate(int(g["iters"][k]), bool(g["initialize"][k]), float(g["lamda_in"][k]), st_in)
-                errs[k] = rel(eng.debug("dpose"), g[f"dpose_{k}"][0].reshape(n, 9))
+                errs[k] = rel(eng.debug("dpose"), g[f"dpose_{k}"][-1].reshape(n, 9))
             eng.close()
             table.setdefault(fx, {})[name] = {"max": max(errs.values()), "worst_call": max(errs, key=errs.get),
                                               "median": float(np.median(list(errs.values())))}
         errs = {}
         for k in calls:
-            A, b = g[f"A_bands_{k}"][0], g[f"JTr_{k}"][0].reshape(-1, 9)
-            errs[k] = rel(O.solve_tridiag(A, b, "banded"), g[f"dpose_{k}"][0].reshape(n, 9))
+            A, b = g[f"A_bands_{k}"][-1], g[f"JTr_{k}"][0].reshape(-1, 9)
+            errs[k] = rel(O.solve_tridiag(A, b, "banded"), g[f"dpose_{k}"][-1].reshape(n, 9))
         table[fx]["LAPACK banded LU on the captured system (NumPy oracle)"] = {"max": max(errs.values()), "worst_call": max(errs, key=errs.get),
                                                                                 "median": float(np.median(list(errs.values())))}
     print(json.dumps(table, indent=1))

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -88,6 +89,7 @@ struct vba_context {
     int no_pack = 0;                        // diagnostic: force one window per wavefront in the sequential driver
     int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
+    int fusion = 0;                         // vba_set_fusion
     int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
     size_t dbg_cap = 0;
@@ -394,6 +396,13 @@ int vba_set_key_carry(vba_handle h, int on) {
     return VBA_OK;
 }
 
+int vba_set_fusion(vba_handle h, int mask) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (mask < 0 || mask > 3) return fail(VBA_EINVAL, "mask must be in [0, 3]");
+    h->fusion = mask;
+    return VBA_OK;
+}
+
 int vba_set_warm_select(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     h->warm_enabled = on == 2 ? 2 : (on != 0);
@@ -665,10 +674,11 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     // who forms the step: latency mode lets the trial kernel do it (landmark-only: 6x6 solve per pose on the unpivoted
     // path; full phase: recovery of the partitioned solve)
     V.fused_trial = 0;
-    if (V.lat) {
+    if (V.lat && (h->fusion & 1)) {
         if (c.initialize) V.fused_trial = h->pivot_mode == 0 ? 1 : 0;
         else if (V.chunk > 0) V.fused_trial = 2;
     }
+    V.fuse_blocks = (h->fusion & 2) ? 1 : 0;
 }
 
 // the kernels in front of the first LM trial; ev (profiled variant): events that bracket the kernel classes
@@ -682,12 +692,17 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
     const bool ride = !init && !c.prof && h->W < 16;
     V.dyn_in_acc = ride ? 1 : 0;
     const bool overlap = !init && !c.prof && !ride;
-    if (overlap) {
+    auto fork_dynamics = [&]() -> int {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
         launch_dynamics(V, h->aux_stream);
         HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
-    }
+        return VBA_OK;
+    };
+    // a folding select is what moves the window on to this call (and reads the block sums the previous call's dynamics
+    // left): the second stream forks behind it, not in front
+    const bool fork_late = overlap && c.fold;
+    if (overlap && !fork_late) { if (int rc = fork_dynamics()) return rc; }
     mark(1);
     if (!c.carry) {
         launch_obs_residual(V, nullptr, s);
@@ -701,13 +716,14 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
         launch_clear_hist(V, exact_repeat ? 2 : 0, s);
         launch_select(V, true, s);
     }
+    if (fork_late) { if (int rc = fork_dynamics()) return rc; }
     mark(3);
     launch_obs_accumulate(V, s);
     mark(4);
     if (!init && !overlap && !ride) launch_dynamics(V, s);
     if (overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     mark(5);
-    C.fuse_assemble = init && h->pivot_mode == 0 && !V.lat;
+    C.fuse_assemble = init && h->pivot_mode == 0 && V.fused_trial != 1;
     C.assembled = false;
     const bool need_bands = init ? V.fused_trial != 1 : !solve_forms_blocks(V);
     if (need_bands) {
@@ -718,11 +734,14 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
     return VBA_OK;
 }
 
-// one LM trial: solve (unless the trial kernel or the assembly formed the step) + trial residuals
-void enqueue_trial(vba_handle h, CallCtx& C, const CallSpec& c, bool first) {
+// one LM trial: solve (unless the trial kernel or the assembly formed the step) + trial residuals; ev_solve (profiled
+// variant): recorded between the two
+void enqueue_trial(vba_handle h, CallCtx& C, const CallSpec& c, bool first, hipEvent_t ev_solve = nullptr, int solve_redo = -1) {
     DevView& V = C.V;
     hipStream_t s = h->stream;
     const bool init = c.initialize != 0;
+    const int redo_all = V.redo;
+    if (solve_redo >= 0) V.redo = solve_redo;       // which windows the solve kernels of this round take (see step_impl)
     if (init) {
         const bool pivoted_round = V.pivot != 0;
         if (V.fused_trial == 1) {
@@ -736,6 +755,8 @@ void enqueue_trial(vba_handle h, CallCtx& C, const CallSpec& c, bool first) {
     } else {
         launch_solve(V, 0, s);
     }
+    V.redo = redo_all;
+    if (ev_solve) (void)hipEventRecord(ev_solve, s);
     launch_trial(V, s);
 }
 
@@ -786,9 +807,10 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     // never reported an outcome (a fault, a skipped window)
     constexpr int kMaxTrials = 24;
     bool finished = false, first = true;
+    int solve_redo = -1;
     for (int trial = 0; trial < kMaxTrials; ++trial) {
-        enqueue_trial(h, C, c, first);
-        if (first) { mark(7); }
+        enqueue_trial(h, C, c, first, (first && prof) ? ev[7] : nullptr, solve_redo);
+        solve_redo = -1;
         if (first) mark(8);
         launch_decide(V, nullptr, 0, s);
         if (first) {
@@ -816,7 +838,9 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
             CallSpec cr = c;
             cr.prof = false;
             if (int rc = enqueue_front(h, C, cr, true, nullptr)) return rc;
-            V.redo = 2;             // this round: their first trial, the others' next one (the solve is launched for both)
+            V.redo = 2;             // this round: their first trial, the others' next one
+            // ... whose solve the repeating windows skip when the assembly they just ran has formed their first step already
+            solve_redo = (c.initialize && C.fuse_assemble) ? 0 : 2;
             continue;
         }
         V.redo = 0;
@@ -914,22 +938,30 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
         // After a pass over calls next .. ncalls-1 every window whose counter is below ncalls is stalled AT that call.
         // Every stalled call is finished with the ordinary LM loop -- each one, not only the earliest: a window left at a
         // later call would otherwise run that call again from its start when the chain is re-issued.
-        std::vector<int> stalled;
+        std::vector<int> stalled, stall_at((size_t)h->W);
         for (int w = 0; w < h->W; ++w) {
             const int c = (int)head(h, w)->call_idx;
+            stall_at[w] = c;        // a window that the loop below moves on INTO a later stalled call has not run that call's front: it waits for the re-issue
             if (c < ncalls && std::find(stalled.begin(), stalled.end(), c) == stalled.end()) stalled.push_back(c);
         }
         if (stalled.empty()) { complete = true; break; }
         std::sort(stalled.begin(), stalled.end());
+        static const bool trace = std::getenv("VBA_TRACE") != nullptr;
+        if (trace) {
+            std::fprintf(stderr, "[vba] pass from call %d:", next);
+            for (int w = 0; w < h->W && w < 8; ++w)
+                std::fprintf(stderr, " w%d(call %d done %d flags %u ntr %d)", w, head(h, w)->call_idx, head(h, w)->done, head(h, w)->flags, head(h, w)->n_trials);
+            std::fprintf(stderr, "\n");
+        }
         for (int sc_call : stalled) {
             const CallSpec q = spec(sc_call, false);
             CallCtx C;
             view_for_call(h, C.V, q);
             DevView& V = C.V;
             // the front of this call has run (for the windows that reached it); what is on the device of it:
-            C.fuse_assemble = q.initialize && h->pivot_mode == 0 && !V.lat;
+            C.fuse_assemble = q.initialize && h->pivot_mode == 0 && V.fused_trial != 1;
             C.assembled = q.initialize ? V.fused_trial != 1 : !solve_forms_blocks(V);
-            auto at_call = [&](int w) { return head(h, w)->call_idx == sc_call; };
+            auto at_call = [&](int w) { return stall_at[w] == sc_call && head(h, w)->call_idx == sc_call; };
             bool any_miss = false;
             for (int w = 0; w < h->W; ++w) any_miss = any_miss || (at_call(w) && (head(h, w)->flags & 32u));
             // (1) the first trial of the windows that got that far has been evaluated but not decided (the decision was left
@@ -966,6 +998,12 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
                 HIPCHK(hipGetLastError());
                 if (int rc = read_heads(h)) return rc;
                 ++trials;
+                if (trace) {
+                    std::fprintf(stderr, "[vba]   call %d round %d pivot %d:", sc_call, trial, V.pivot);
+                    for (int w = 0; w < h->W && w < 8; ++w)
+                        std::fprintf(stderr, " w%d(call %d done %d flags %u ntr %d lam %g)", w, head(h, w)->call_idx, head(h, w)->done, head(h, w)->flags, head(h, w)->n_trials, head(h, w)->lamda);
+                    std::fprintf(stderr, "\n");
+                }
             }
             if (!finished)
                 return fail(VBA_ESTATE, "LM loop of call " + std::to_string(sc_call) + " did not terminate (no outcome reported by the device)");

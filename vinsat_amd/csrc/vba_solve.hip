@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
 
 // latency mode with a partitioned chain whose chunk (blocks + staged inputs + elimination scratch) fits the LDS of a CU:
 // the chunk kernel forms its blocks itself and k_assemble is not launched (vba_api.hip asks the same question)
-bool solve_forms_blocks(const DevView& V) { return V.lat && !V.prm.initialize && V.chunk >= 2 && V.chunk <= kFusedChunkMax; }
+bool solve_forms_blocks(const DevView& V) { return V.lat && V.fuse_blocks && !V.prm.initialize && V.chunk >= 2 && V.chunk <= kFusedChunkMax; }
 
 template <bool PIVOT>
 static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s) {

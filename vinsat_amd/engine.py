@@ -66,6 +66,10 @@ class BAEngine:
         """True (default): an accepted trial leaves the next call's |r| keys behind; False: every call recomputes them."""
         _lib.check(self.lib.vba_set_key_carry(self.h, int(bool(on))), self.lib)
 
+    def set_fusion(self, mask):
+        """Latency-mode kernel fusion (bit 0: step inside the trial kernel, bit 1: blocks formed inside the chunk elimination)."""
+        _lib.check(self.lib.vba_set_fusion(self.h, int(mask)), self.lib)
+
     def set_warm_select(self, on):
         """True (default): carried keys are selected with one warm pass (and chained calls fold their accept test into it);
         False: exact digit passes and a decide launch per call."""
