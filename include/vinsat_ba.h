@@ -125,7 +125,7 @@ int vba_set_prior(vba_handle h, int on);
  * on == 0: every call recomputes them (same bits; for comparison). */
 int vba_set_key_carry(vba_handle h, int on);
 
-/* Warm select (default on).  The exact lower median of the 2m keys |r| (torch.median, BA_filtering.py:23) is found by
+/* Warm select (default: on for handles of fewer than 16 windows, off beyond).  The exact lower median of the 2m keys |r| (torch.median, BA_filtering.py:23) is found by
  * radix select.  On carried keys the trial that produced them has already binned them into 2046 narrow bins around the
  * median of its own call (consecutive calls move the median by a factor 0.3 .. 2.5), so ONE pass over the keys -- the
  * compaction of the bin that holds the wanted rank -- replaces the two digit passes; the short list is ranked exactly as
@@ -142,8 +142,10 @@ int vba_warm_select_misses(vba_handle h, int* count);
  *          recovery of the partitioned solve) -- no recovery launch and, in the landmark-only phase, no assembly + solve launch;
  *   bit 1: the chunk elimination forms the blocks of its chunk in LDS itself -- no assembly launch in the full phase, the
  *          bands never go through memory.
- * Default 0: measured on MI355X, a kernel boundary (~2.5 us) is cheaper than the instructions either fusion adds to
- * every wave of the fused kernel; the modes stay for comparison and are covered by the parity tests. */
+ * Default 1.  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
+ * formed by 16 lanes together (formed redundantly by every thread it was 6 us SLOWER: instruction issue of a single wave
+ * is the time in this mode); bit 1 gains nothing (the assembly costs the elimination's block what its own launch cost)
+ * and stays off.  All masks are covered by the parity tests. */
 int vba_set_fusion(vba_handle h, int mask);
 
 /* Row pivoting inside the 9x9 diagonal blocks.  always == 0 (default): the blocks are eliminated without row

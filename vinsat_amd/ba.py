@@ -65,6 +65,14 @@ def invalidate():
     _cache["resident"] = None
 
 
+def release():
+    """Close the cached engine (device memory, stream) -- e.g. before another handle takes over the device."""
+    eng = _cache.pop("eng", None)
+    if eng is not None:
+        eng.close()
+    invalidate()
+
+
 def _engine_for(args, n, m, device):
     """The cached engine with the window given by ``args`` = (imu_meas, landmarks, landmarks_xyz, ii, time_idx,
     intrinsics, confidences) on the device."""

@@ -77,7 +77,8 @@ struct vba_context {
     std::vector<std::vector<int64_t>> perm; // sorted position -> input row
     float last_ms = 0.f;
     bool stepped = false;
-    bool carry_ok = false;          // every window's keys / histogram / sum |r| for its current states are on the device (k_trial<true>)
+    int carry_ok = 0;               // every window's keys / histogram / sum |r| for its current states are on the device: 0 no, 1 with the
+                                    // exponent histogram, 2 with the warm histogram (the kind the last trial emitted)
     bool carry_enabled = true;
     bool hist_dirty = false;        // a k_trial<true> has left a warm histogram (digit-0 slot of parity `par`) behind that nobody consumed
     int warm_enabled = 1;           // carried keys are selected with the one-pass warm select (vba_set_warm_select; 2: forced misses, test knob)
@@ -89,7 +90,7 @@ struct vba_context {
     int no_pack = 0;                        // diagnostic: force one window per wavefront in the sequential driver
     int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
-    int fusion = 0;                         // vba_set_fusion
+    int fusion = 1;                         // vba_set_fusion (default: the trial kernel forms the step)
     int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
     size_t dbg_cap = 0;
@@ -177,6 +178,8 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     const size_t W = windows, N = n_max, M = (size_t)m_max;
     const int nblk_obs = (int)((M + kObsBlock - 1) / kObsBlock);
     const int nblk_dyn = (int)((N + kObsBlock - 1) / kObsBlock);
+    const int nblk_dyn16 = (int)((N - 1 + 14) / 15);      // pose-chain blocks of the 16-lanes-per-pose geometry (vba_set_fusion bit 0)
+    const int trial_stride = nblk_obs + std::max(nblk_dyn, nblk_dyn16);
     size_t bytes = 0;
     auto need = [&](size_t b) { bytes += ((b + 255) & ~size_t(255)) + 256; };
     need(W * 4); need(W * 4); need(W * sizeof(WinScalars));
@@ -188,7 +191,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     const int nblk_pred = (int)((N * kDynLanes + 255) / 256);
     need(W * nblk_pred * 8); need(W * nblk_pred * 8); need(W * 81 * 8);
     need(W * N * 36 * 8); need(W * N * 6 * 8);
-    need(W * 2 * M * 8); need(W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * (nblk_obs + nblk_dyn) * 8); need(W * nblk_obs * 8);
+    need(W * 2 * M * 8); need(W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * trial_stride * 8); need(W * nblk_obs * 8);
     need(W * kHistStride * 4);
     const size_t per_pose = 21 + 6 + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
     need(W * N * per_pose * 8 + 16 * 256);
@@ -230,7 +233,8 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.reg = 0;
     V.absr = A.take<double>(W * 2 * M); V.wraw = A.take<double>(W * M); V.ckeys = A.take<double>(W * 2 * M);
     V.acc_lanes = 8;    // set after construction by vba_set_accumulate_lanes(h, 0)
-    V.part_init = A.take<double>(W * nblk_obs); V.part_trial = A.take<double>(W * (nblk_obs + nblk_dyn));
+    V.part_init = A.take<double>(W * nblk_obs); V.part_trial = A.take<double>(W * trial_stride);
+    V.trial_stride = trial_stride;
     V.part_next = A.take<double>(W * nblk_obs);
     V.hist = A.take<unsigned>(W * kHistStride);
     V.Hraw = A.take<double>(W * N * 21); V.braw = A.take<double>(W * N * 6);
@@ -268,8 +272,11 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
             return fail(VBA_ENOMEM, "internal: device arena mis-carved");
         }
     }
+    // the second stream carries the dynamics factor beside the observation kernels and exists only where that is done (many
+    // windows): a process maps its streams onto a few hardware queues, and every idle stream of another handle is one more
+    // to share them with
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        (windows >= 16 && hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
@@ -291,6 +298,10 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     h->perm.resize(W);
     vba_set_accumulate_lanes(h, 0);
     vba_set_solver(h, -1);
+    // warm select: a latency-mode feature (one pass and no decide launch per chained call); with many windows per launch
+    // the ~1 global atomic per key of its 2048-bin histogram costs more than the second pass over the keys it saves
+    // (measured at 4096 windows: trial + select 5.2 ms against 4.8 ms)
+    h->warm_enabled = windows < 16 ? 1 : 0;
     *out = h;
     return VBA_OK;
 }
@@ -550,7 +561,7 @@ int vba_set_prior(vba_handle h, int on) {
 int vba_set_states(vba_handle h, int window, const double* states, double lamda) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (!states) return fail(VBA_EINVAL, "null states");
-    h->carry_ok = false;
+    h->carry_ok = 0;
     double* S = h->S[h->par];           // the input buffer of the next call
     if (window == -1) {     // the same states for every window (all windows must have the same number of poses)
         const int n = h->n[0];
@@ -636,8 +647,8 @@ struct CallSpec {
     int iter = 0, initialize = 0;
     int call = -1;          // index inside a chained schedule, -1: stand-alone
     int par = 0;
-    bool carry = false;     // the keys of the input states are on the device
-    bool emit = false;      // leave the next call's keys behind
+    int carry = 0;          // the keys of the input states are on the device: 0 no, 1 with their exponent histogram, 2 with a warm one
+    int emit = 0;           // leave the next call's keys behind: 0 no, 1 with the exponent histogram, 2 with the warm one
     bool fold = false;      // first kernel evaluates the accept test of call - 1
     bool prof = false;      // serialised schedule with an event between kernel classes
 };
@@ -658,8 +669,8 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     V.states = h->S[c.par];
     V.states_new = h->S[c.par ^ 1];
     V.states_prev = h->S[c.par];
-    V.emit = c.emit ? 1 : 0;
-    V.carry = c.carry ? 1 : 0;
+    V.emit = c.emit;
+    V.carry = c.carry;
     V.fold = c.fold ? 1 : 0;
     V.redo = 0;
     V.pending_only = 0;
@@ -674,9 +685,10 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     // who forms the step: latency mode lets the trial kernel do it (landmark-only: 6x6 solve per pose on the unpivoted
     // path; full phase: recovery of the partitioned solve)
     V.fused_trial = 0;
-    if (V.lat && (h->fusion & 1)) {
-        if (c.initialize) V.fused_trial = h->pivot_mode == 0 ? 1 : 0;
-        else if (V.chunk > 0) V.fused_trial = 2;
+    if (V.lat && (h->fusion & 1)) {     // every trial kernel of such a handle uses the 16-lanes-per-pose geometry
+        if (c.initialize) V.fused_trial = h->pivot_mode == 0 ? 1 : 3;
+        else V.fused_trial = V.chunk > 0 ? 2 : 3;
+        V.nblk_dyn = (V.n_max - 1 + 14) / 15;
     }
     V.fuse_blocks = (h->fusion & 2) ? 1 : 0;
 }
@@ -708,12 +720,15 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
         launch_obs_residual(V, nullptr, s);
         mark(2);
         launch_select(V, false, s);
-    } else if (h->warm_enabled && !exact_repeat) {
+    } else if (c.carry == 2 && !exact_repeat) {
         mark(2);
         launch_select_warm(V, s);
-    } else {            // carried keys, exact digits: the digit-0 slot holds a warm histogram (or nothing): rebuild it by exponent
+    } else if (c.carry == 1 && !exact_repeat) {     // the trial left digit 0 (exponent histogram) behind: two passes
         mark(2);
-        launch_clear_hist(V, exact_repeat ? 2 : 0, s);
+        launch_select(V, false, s);
+    } else {            // a warm select that missed: the digit-0 slot holds the warm histogram, rebuild it by exponent
+        mark(2);
+        launch_clear_hist(V, 2, s);
         launch_select(V, true, s);
     }
     if (fork_late) { if (int rc = fork_dynamics()) return rc; }
@@ -771,10 +786,11 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     hipStream_t s = h->stream;
     CallSpec c;
     c.iter = iter; c.initialize = initialize; c.call = -1; c.par = h->par;
-    c.emit = h->carry_enabled && emit;
-    c.carry = h->carry_enabled && h->carry_ok;
+    const int emit_kind = h->warm_enabled ? 2 : 1;
+    c.emit = (h->carry_enabled && emit) ? emit_kind : 0;
+    c.carry = h->carry_enabled ? h->carry_ok : 0;
     c.prof = prof != nullptr;
-    h->carry_ok = false;
+    h->carry_ok = 0;
     CallCtx C;
     view_for_call(h, C.V, c);
     DevView& V = C.V;
@@ -785,7 +801,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
         h->hist_dirty = false;
     }
     if (!c.carry && h->hist_dirty) launch_clear_hist(V, 0, s);     // the states were replaced after the last trial
-    h->hist_dirty = c.emit;
+    h->hist_dirty = c.emit != 0;
     struct ProfEvents {         // destroyed on every exit path, error returns included
         hipEvent_t e[VBA_NKERNELS + 1] = {};
         ~ProfEvents() { for (hipEvent_t q : e) if (q) (void)hipEventDestroy(q); }
@@ -797,7 +813,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     auto mark = [&](int k) { if (prof) (void)hipEventRecord(ev[k], s); };
     struct Abandon {            // any error return below leaves a half-run call behind
         vba_handle h; bool armed = true;
-        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = false; } }
+        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = 0; } }
     } abandon{h};
     HIPCHK(hipEventRecord(h->ev0, s));
     mark(0);
@@ -865,9 +881,12 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
             (void)hipEventElapsedTime(&prof[k], ev[k], ev[k + 1]);
         }
         if (c.carry) prof[VBA_K_RESIDUAL] = 0.f;        // not launched: the previous trial left the keys behind
+        if (c.initialize && (C.fuse_assemble || V.fused_trial == 1)) prof[VBA_K_SOLVE] = 0.f;   // no solve launch: formed inside k_assemble<true> / k_trial
+        if (!C.assembled) prof[VBA_K_ASSEMBLE] = 0.f;
+        if (c.initialize) prof[VBA_K_DYNAMICS] = 0.f;
     }
     h->par ^= 1;                    // the trial buffer is the next call's input
-    h->carry_ok = c.emit;
+    h->carry_ok = c.emit;           // (the kind of histogram that came with the keys)
     h->stepped = true;
     h->last_iter = iter;
     h->last_init = initialize;
@@ -888,17 +907,18 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const int par0 = h->par;
-    bool carry0 = h->carry_enabled && h->carry_ok;
-    h->carry_ok = false;
+    const int emit_kind = h->carry_enabled ? (h->warm_enabled ? 2 : 1) : 0;
+    const int carry0 = h->carry_enabled ? h->carry_ok : 0;
+    h->carry_ok = 0;
     struct Abandon {
         vba_handle h; bool armed = true;
-        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = false; } }
+        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = 0; } }
     } abandon{h};
     auto spec = [&](int c, bool fold) {
         CallSpec q;
         q.iter = iters[c]; q.initialize = inits[c]; q.call = c; q.par = (par0 + c) & 1;
-        q.carry = c == 0 ? carry0 : h->carry_enabled;       // every later call starts from a trial of this chain
-        q.emit = h->carry_enabled;
+        q.carry = c == 0 ? carry0 : emit_kind;              // every later call starts from a trial of this chain
+        q.emit = emit_kind;
         q.fold = fold;
         return q;
     };
@@ -914,7 +934,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
         if (!carry0 && h->hist_dirty) launch_clear_hist(V0, 0, s);
         launch_reset_calls(V0, s);
     }
-    h->hist_dirty = h->carry_enabled;
+    h->hist_dirty = emit_kind != 0;
     for (int w = 0; w < h->W; ++w) { h->h_head[w].call_idx = 0; h->h_head[w].done = 0; h->h_head[w].flags = 0; }
     long trials = 0;
     int next = 0;
@@ -922,14 +942,14 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     for (int guard = 0; guard <= ncalls; ++guard) {
         // speculative part: calls next .. ncalls-1, one trial each
         for (int c = next; c < ncalls; ++c) {
-            const bool fold = c > next && h->carry_enabled && h->warm_enabled;      // call c-1 of this pass left its decision to us
+            const bool fold = c > next && emit_kind == 2;       // call c-1 of this pass left its decision to this call's warm select
             const CallSpec q = spec(c, fold);
             CallCtx C;
             view_for_call(h, C.V, q);
             if (fold) fill_params(C.V.prev, iters[c - 1], inits[c - 1]);
             if (int rc = enqueue_front(h, C, q, false, nullptr)) return rc;
             enqueue_trial(h, C, q, true);
-            const bool next_folds = c + 1 < ncalls && h->carry_enabled && h->warm_enabled;
+            const bool next_folds = c + 1 < ncalls && emit_kind == 2;
             if (!next_folds) launch_decide(C.V, nullptr, 0, s);
         }
         HIPCHK(hipGetLastError());
@@ -1018,7 +1038,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     abandon.armed = false;
     if (trials_total) *trials_total = (int)trials;
     h->par = (par0 + ncalls) & 1;
-    h->carry_ok = h->carry_enabled;
+    h->carry_ok = emit_kind;
     h->stepped = true;
     h->last_iter = iters[ncalls - 1];
     h->last_init = inits[ncalls - 1];
@@ -1208,6 +1228,7 @@ static void sharded_view(vba_handle h, DevView& V) {
     view_for_call(h, V, c);
     V.lat = 0;
     V.fused_trial = 0;
+    V.nblk_dyn = h->V.nblk_dyn;
     V.m_total = h->V.m_total;
 }
 

@@ -45,7 +45,7 @@ __device__ __forceinline__ DecideOut decide_eval(const DevView& V, int w, int pc
         }
     }
     if (ranks == 0) {
-        const double* pt = V.part_trial + (size_t)w * (V.nblk_obs + V.nblk_dyn);
+        const double* pt = V.part_trial + (size_t)w * V.trial_stride;
         for (int b = t; b < V.nblk_obs + V.nblk_dyn; b += 256) s_trial += pt[b];
     }
     if (V.emit) {

@@ -140,7 +140,7 @@ struct DevView {
     double* ckeys;                  // [W][2 m_max]  keys surviving the first two select digits (usually a handful)
     int acc_lanes;                  // lanes per pose in k_obs_accumulate (4..64)
     double* part_init;              // [W][nblk_obs] block sums of |r_obs|
-    double* part_trial;             // [W][nblk_obs + nblk_dyn]
+    double* part_trial;             // [W][trial_stride]: nblk_obs observation blocks, then nblk_dyn pose-chain blocks
     double* part_next;              // [W][nblk_obs] block sums of |r_obs| at the trial states (carried keys)
     double* part_pred;              // [W][nblk_pred] block sums of |r_pred| at the input states (dynamics factor, 32 poses per block)
     double* part_prior;             // [W][nblk_pred] block sums of |r_prior| at the input states (BA_reg)
@@ -149,7 +149,7 @@ struct DevView {
     // Carried keys: the trial residual of an accepted trial is evaluated at exactly the states the next call starts
     // from, so k_trial<true> (emit) also leaves that call's |r| keys, their exponent histogram and sum |r| behind and
     // the next call (carry) starts at the select without re-reading the observations.
-    int emit, carry;
+    int emit, carry;                // emit: 0 no, 1 keys + exponent histogram, 2 keys + warm histogram; carry: 0 no, else the kind that was emitted
     int dyn_in_acc;                 // full-phase call with few windows: k_obs_accumulate's grid also runs the dynamics factor
     unsigned* hist;                 // [W][kHistStride]: digit 0 for parity 0, digit 0 for parity 1, digits 1..5
     double* Hraw;                   // [21]
@@ -177,7 +177,8 @@ struct DevView {
     double *cL, *cR;                // [W][p_max][19][9]  L_j / U_j times the neighbouring chunk solutions
     double *rXs, *rzs, *rx;         // reduced system over the separators, [W][p_max][81 | 9 | 9]
     double *csol2, *cL2, *cR2, *rx2;  // second level: chunk solutions over the level-1 separators, [W][p_max][...]
-    int nblk_dyn;                   // ceil(n_max / kObsBlock)
+    int nblk_dyn;                   // pose-chain blocks of k_trial: ceil(n_max / 256), or ceil((n_max - 1) / 15) in the 16-lanes-per-pose geometry
+    int trial_stride;               // doubles between the windows of part_trial (room for either geometry)
     // sharded mode: number of observation rows over all ranks (0 = not sharded) and external key buffer
     int64_t m_total;
     const double* abs_all;          // gathered |r| of all ranks or nullptr

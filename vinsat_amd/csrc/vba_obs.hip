@@ -462,9 +462,9 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 
     // Phase 3: weights and accumulation
     double wmax_l = 0.0;
-    double acc[27];
+    double acc[32];         // 21 + 6 sums, padded to a power of two for the halving reduction
 #pragma unroll
-    for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+    for (int q = 0; q < 32; ++q) acc[q] = 0.0;
     if (i < n) {
         auto process = [&](double ox_, double oy_, double oz_, double ou_, double ov_, double oc_, int k) {
             double u, v, cam[3], d, J[12];
@@ -507,18 +507,35 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             }
         }
     }
+    // Reduction over the G lanes of the pose by recursive halving: in step s (xor mask 2^s) a lane keeps the half of its
+    // values that bit s of its lane index selects and receives the partner's partial sums of that half -- 16 + 8 + 4 + 2 + 1
+    // shuffles for the (padded) 32 values instead of 27 per butterfly step; afterwards every lane owns the totals of
+    // 32 / min(G, 32) consecutive values.  The shape is fixed by G, so the sums are bit reproducible.
+    int own = 0;
 #pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) {
+    for (int cnt = 32, mask = 1; mask < G && cnt > 1; cnt >>= 1, mask <<= 1) {
+        const bool up = (sub & mask) != 0;
+        const int half = cnt >> 1;
 #pragma unroll
-        for (int q = 0; q < 27; ++q) acc[q] += shfl_xor_f64(acc[q], off);
+        for (int j = 0; j < 16; ++j) {
+            if (j < half) {
+                const double lo = acc[j], hi = acc[half + j];
+                acc[j] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, mask);
+            }
+        }
+        if (up) own += half;
     }
-    if (i < n) {
+    if (G == 64) acc[0] += shfl_xor_f64(acc[0], 32);
+    if (i < n && sub < 32) {
         double* H = V.Hraw + pb * 21;
         double* B = V.braw + pb * 6;
+        constexpr int kOwn = 32 / (G < 32 ? G : 32);
 #pragma unroll
-        for (int q = 0; q < 21; ++q) if (q % G == sub) H[q] = acc[q];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) if ((21 + q) % G == sub) B[q] = acc[21 + q];
+        for (int j = 0; j < kOwn; ++j) {
+            const int q = own + j;
+            if (q < 21) H[q] = acc[j];
+            else if (q < 27) B[q - 21] = acc[j];
+        }
     }
     wmax_l = wave_max(wmax_l);
     if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = wmax_l;
@@ -532,17 +549,26 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 // ---------------------------------------------------------------------------------------------- A8: trial residuals
 // blocks [0, nblk_obs): sum |w (uv - est')| over the observations (BA_filtering.py:61, 66);
 // blocks [nblk_obs, nblk_obs + nblk_dyn): sqrt(sigma) sum |r_pred'| over the pose edges (BA_filtering.py:65, 67).
-// EMIT: the observation blocks also write the |r| keys, their warm histogram (bins around this call's median, digit-0
-// slot of the NEXT call's parity) and the block sums of |r| at the trial states -- the input of the next call if this
-// trial is accepted (k_decide clears the histogram again if it is not).
-// FUSED (latency mode): the trial states do not exist yet -- every thread forms the step of the pose it needs itself
-// (vba_step.h: 1 = landmark-only 6x6 solve, 2 = recovery of the partitioned solve) and the pose-chain blocks, which own
-// one pose per thread, write states_new / dpose for everybody after them.
-template <bool EMIT, int FUSED>
+// EMIT: the observation blocks also write the |r| keys, their histogram (digit-0 slot of the NEXT call's parity) and the
+// block sums of |r| at the trial states -- the input of the next call if this trial is accepted (k_decide clears the
+// histogram again if it is not).  EMIT 2: warm histogram (bins around this call's median: the next call selects in one
+// pass); EMIT 1: the 10 exponent bits = digit 0 of the exact select (many windows per launch: the ~1 global atomic per
+// key that a 2048-bin histogram costs is dearer there than the second pass over the keys it saves).
+// FUSED (latency mode, vba_set_fusion bit 0): 0 = the trial states are in memory, pose-chain blocks of 256 edges;
+// 1 / 2 = the trial states do not exist yet and are formed here (vba_step.h: 1 landmark-only 6x6 solve, 2 recovery of the
+// partitioned solve), 16 lanes per pose: an observation block for the poses its rows belong to (a handful), a pose-chain
+// block for 16 poses = 15 edges, which also writes states_new / dpose for everybody after this kernel; 3 = the geometry
+// of 1 / 2 with the trial states read from memory (a call of such a handle that cannot fuse: pivoted landmark-only solve).
+constexpr int kEdgesPerBlock16 = 15;
+
+template <int EMIT, int FUSED>
 __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
+    constexpr bool FORM = FUSED == 1 || FUSED == 2;
     __shared__ double red[kObsBlock / 64];
-    __shared__ unsigned lh[EMIT ? kSelBins : 1];
-    __shared__ double snew[FUSED ? (kObsBlock + 1) * 10 : 1];
+    __shared__ unsigned lh[EMIT == 2 ? kSelBins : (EMIT == 1 ? 1024 : 1)];
+    __shared__ double snew[FORM ? (kObsBlock + 1) * 10 : 1];
+    __shared__ int lpose[FORM ? kObsBlock : 1];
+    __shared__ unsigned wlead[FORM ? 4 : 1];
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
@@ -550,6 +576,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     const int n = V.n[w], m = V.m[w];
     const StepParams& prm = V.prm;
     const int par = V.par;
+    const int tid = threadIdx.x;
     double s = 0.0, s_raw = 0.0;
     const size_t sb = (size_t)w * V.n_max;
     const bool obs_block = (int)blockIdx.x < V.nblk_obs;
@@ -558,37 +585,71 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     const bool fz = FUSED == 2 || (FUSED == 1 && !(sc.fl[par] & 16u));
     const double wmax = bits_f64(sc.wmax_bits);
     const double inv_wmax = 1.0 / wmax;
+    const int l16 = tid & 15, grp = tid >> 4, gbase = (tid & 63) & ~15;
     unsigned long long wlo = 0ull;
-    if (EMIT) wlo = warm_range_start(f64_bits(sc.c_obs), V.warm_shift);
+    constexpr int kEmitBins = EMIT == 2 ? kSelBins : 1024;     // warm bins, or the 10 exponent bits (digit 0 of the exact select)
+    if (EMIT == 2) wlo = warm_range_start(f64_bits(sc.c_obs), V.warm_shift);
     if (EMIT && obs_block) {
-        for (int b = threadIdx.x; b < kSelBins; b += kObsBlock) lh[b] = 0u;
+        for (int b = tid; b < kEmitBins; b += kObsBlock) lh[b] = 0u;
         __syncthreads();
     }
     if (blockIdx.x == 0) {
         // digits 1, 2 of an exact select are dead since the accumulation; the list of the next warm select starts empty
         unsigned* h12 = histd_of(V, w, 1);
-        for (int b = threadIdx.x; b < 2 * kSelBins; b += kObsBlock) h12[b] = 0u;
-        if (threadIdx.x == 0) {
+        for (int b = tid; b < 2 * kSelBins; b += kObsBlock) h12[b] = 0u;
+        if (tid == 0) {
             sc.sel_cnt = 0u;
             sc.pending = V.call;
-            if (EMIT) sc.warm_lo[par ^ 1] = wlo;
+            if (EMIT == 2) sc.warm_lo[par ^ 1] = wlo;
+            if (EMIT == 1) {        // digit 0 of the next call's exact select is the histogram this kernel leaves
+                sc.sel_prefix[0] = 0ull;
+                sc.sel_rank[0] = (2 * (long long)m - 1) / 2;
+            }
             if (FUSED == 1 && fz) sc.lam32 = lam32;
         }
     }
     unsigned bad = 0u;
     if (obs_block) {
-        const int k = blockIdx.x * kObsBlock + threadIdx.x;
-        if (k < m) {
-            const size_t ob = (size_t)w * V.obs_stride, mb = (size_t)w * V.m_max;
-            const int pose = V.opose[2 * ob + k];
-            PoseCam pc;
-            if (FUSED && fz) {
-                double o[10], d9[9];
-                pose_trial_state<FUSED ? FUSED : 1>(V, w, pose, inv_wmax, lam32, o, d9, bad);
-                pose_camera(o, V.intr + (sb + pose) * 4, pc);
-            } else {
-                pose_camera(V.states_new + (sb + pose) * 10, V.intr + (sb + pose) * 4, pc);
+        const int k = blockIdx.x * kObsBlock + tid;
+        const size_t ob = (size_t)w * V.obs_stride, mb = (size_t)w * V.m_max;
+        const bool have = k < m;
+        const int pose = have ? V.opose[2 * ob + k] : -1;
+        const double* stp = V.states_new + (sb + (have ? pose : 0)) * 10;
+        if (FORM && fz) {
+            // the poses of this block's rows (rows are pose sorted): the first row of every pose inside the block leads,
+            // leaders are numbered in row order and 16 lanes form the trial state of each
+            const int prev = (have && tid > 0) ? V.opose[2 * ob + k - 1] : -2;
+            const bool lead = have && (tid == 0 || prev != pose);
+            const unsigned long long lm = __ballot(lead);
+            const int lane = tid & 63, wv = tid >> 6;
+            if (lane == 0) wlead[wv] = (unsigned)__popcll(lm);
+            __syncthreads();
+            unsigned before = 0, nlead = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                before += q < wv ? wlead[q] : 0u;
+                nlead += wlead[q];
             }
+            const int slot = (int)(before + (unsigned)__popcll(lm & ((2ull << lane) - 1ull))) - 1;   // leaders up to and including me
+            if (lead) lpose[slot] = pose;
+            __syncthreads();
+            for (unsigned base = 0; base < nlead; base += 16) {
+                const unsigned idx = base + (unsigned)grp;
+                const bool live = idx < nlead;
+                double o[10], d9[9];
+                unsigned b2 = 0u;
+                pose_trial_state_group<FORM ? FUSED : 1>(V, w, live ? lpose[idx] : 0, live, l16, gbase, inv_wmax, lam32, o, d9, b2);
+                if (live && l16 == 0) {
+#pragma unroll
+                    for (int r = 0; r < 10; ++r) snew[(size_t)idx * 10 + r] = o[r];
+                }
+            }
+            __syncthreads();
+            stp = snew + (size_t)(slot < 0 ? 0 : slot) * 10;
+        }
+        if (have) {
+            PoseCam pc;
+            pose_camera(stp, V.intr + (sb + pose) * 4, pc);
             double u, v, cam[3], d;
             project(pc, V.ox[ob + k], V.oy[ob + k], V.oz[ob + k], u, v, cam, d);
             const double wk = (V.wraw[mb + k] / wmax) * V.oconf[ob + k];
@@ -598,51 +659,68 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
                 const double ru = fabs(du), rv = fabs(dv);
                 reinterpret_cast<double2*>(V.absr + 2 * mb)[k] = make_double2(ru, rv);
                 s_raw = ru + rv;
-                atomicAdd(&lh[warm_bin(f64_bits(ru), wlo, V.warm_shift)], 1u);
-                atomicAdd(&lh[warm_bin(f64_bits(rv), wlo, V.warm_shift)], 1u);
+                if (EMIT == 2) {
+                    atomicAdd(&lh[warm_bin(f64_bits(ru), wlo, V.warm_shift)], 1u);
+                    atomicAdd(&lh[warm_bin(f64_bits(rv), wlo, V.warm_shift)], 1u);
+                } else {
+                    atomicAdd(&lh[(unsigned)(f64_bits(ru) >> 53) & 1023u], 1u);
+                    atomicAdd(&lh[(unsigned)(f64_bits(rv) >> 53) & 1023u], 1u);
+                }
             }
         }
-        bad = 0u;       // reported once, by the pose-chain blocks
     } else {
         const int db = blockIdx.x - V.nblk_obs;
-        const int i0 = db * kObsBlock;
-        const int i = i0 + threadIdx.x;
         const bool reg = V.reg && !prm.initialize;
-        const double* st = V.states_new + (sb + i) * 10;
-        const double* sn = st + 10;
-        if (FUSED && fz) {
-            // thread t forms pose i0 + t, thread 0 also pose i0 + 256 (the far end of the block's last edge)
-            const int extra = threadIdx.x == 0 ? 2 : 1;
-            for (int q = 0; q < extra; ++q) {
-                const int j = q ? i0 + kObsBlock : i;
-                if (j < n) {
-                    double o[10], d9[9];
-                    unsigned b2 = 0u;
-                    pose_trial_state<FUSED ? FUSED : 1>(V, w, j, inv_wmax, lam32, o, d9, b2);
-                    double* dst = snew + (size_t)(q ? kObsBlock : (int)threadIdx.x) * 10;
+        // which pose / edge this thread evaluates, and where its two states are
+        int i;                      // pose; edge i -> i + 1
+        bool edge_thread;           // this thread evaluates the edge i -> i + 1
+        bool pose_thread;           // this thread accounts for pose i (prior residual; FORM: writes its trial state)
+        const double* st;
+        const double* sn;
+        if (FUSED == 0) {
+            i = db * kObsBlock + tid;
+            edge_thread = pose_thread = true;
+            st = V.states_new + (sb + i) * 10;
+            sn = st + 10;
+        } else {
+            const int i0 = db * kEdgesPerBlock16;
+            const int j = i0 + grp;                     // the pose of this 16-lane group
+            i = j;
+            edge_thread = l16 == 0 && grp < kEdgesPerBlock16;
+            // the block's 16th pose is the next block's first -- unless there is no next block
+            pose_thread = l16 == 0 && (grp < kEdgesPerBlock16 || j / kEdgesPerBlock16 >= V.nblk_dyn);
+            if (FORM && fz) {
+                const bool live = j < n;
+                double o[10], d9[9];
+                unsigned b2 = 0u;
+                pose_trial_state_group<FORM ? FUSED : 1>(V, w, j, live, l16, gbase, inv_wmax, lam32, o, d9, b2);
+                bad = b2;
+                if (live && l16 == 0) {
 #pragma unroll
-                    for (int r = 0; r < 10; ++r) dst[r] = o[r];
-                    if (!q) {
-                        bad = b2;
+                    for (int r = 0; r < 10; ++r) snew[(size_t)grp * 10 + r] = o[r];
+                    if (pose_thread) {
 #pragma unroll
                         for (int r = 0; r < 10; ++r) V.states_new[(sb + j) * 10 + r] = o[r];
 #pragma unroll
                         for (int r = 0; r < 9; ++r) V.dpose[(sb + j) * 9 + r] = d9[r];
-                        if (FUSED == 1 && j == n - 1) {     // last_hessian of a landmark-only call: H / w_max on the 6x6, zeros elsewhere
-                            const double* H = V.Hraw + (sb + j) * 21;
-                            for (int e = 0; e < 81; ++e) {
-                                const int a = e / 9, c = e % 9;
-                                V.lastD[(size_t)w * 81 + e] = (a < 6 && c < 6) ? H[sym6(a, c)] * inv_wmax : 0.0;
-                            }
-                        }
                     }
                 }
+                if (FUSED == 1 && live && j == n - 1) {     // last_hessian of a landmark-only call: H / w_max on the 6x6, zeros elsewhere
+                    const double* H = V.Hraw + (sb + j) * 21;
+                    for (int e = l16; e < 81; e += 16) {
+                        const int a = e / 9, c = e % 9;
+                        V.lastD[(size_t)w * 81 + e] = (a < 6 && c < 6) ? H[sym6(a, c)] * inv_wmax : 0.0;
+                    }
+                }
+                __syncthreads();
+                st = snew + (size_t)grp * 10;
+                sn = st + 10;
+            } else {
+                st = V.states_new + (sb + j) * 10;
+                sn = st + 10;
             }
-            __syncthreads();
-            st = snew + (size_t)threadIdx.x * 10;
-            sn = st + 10;
         }
-        if (!prm.initialize && i < n - 1) {
+        if (edge_thread && !prm.initialize && i < n - 1) {
             double x[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
             const int steps = V.steps[sb + i];
             propagate_gap<false>(x, nullptr, steps, V.hop);
@@ -655,23 +733,23 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             s += att;
             s *= prm.sqrt_sigma;
         }
-        if (reg && i < n) {     // sum |r_prior| at the trial states (BA_filtering.py:175, 178), not scaled by sigma
+        if (reg && pose_thread && i < n) {     // sum |r_prior| at the trial states (BA_filtering.py:175, 178), not scaled by sigma
             double r6[6];
             prior_residual(V.prior_H + (sb + i) * 36, V.prior_x + (sb + i) * 6, st, r6);
             s += fabs(r6[0]) + fabs(r6[1]) + fabs(r6[2]) + fabs(r6[3]) + fabs(r6[4]) + fabs(r6[5]);
         }
     }
     const double t = block_sum<kObsBlock>(s, red);
-    if (threadIdx.x == 0) V.part_trial[(size_t)w * (V.nblk_obs + V.nblk_dyn) + blockIdx.x] = t;
-    if (FUSED && !obs_block) {
+    if (tid == 0) V.part_trial[(size_t)w * V.trial_stride + blockIdx.x] = t;
+    if (FORM && !obs_block) {
         const unsigned long long bp = __ballot(bad & 1u), bn = __ballot(bad & 2u);
-        if ((threadIdx.x & 63) == 0 && (bp || bn)) atomicOr(&sc.fl[par], (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
+        if ((tid & 63) == 0 && (bp || bn)) atomicOr(&sc.fl[par], (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
     }
     if (EMIT && obs_block) {
         const double t_raw = block_sum<kObsBlock>(s_raw, red);
-        if (threadIdx.x == 0) V.part_next[(size_t)w * V.nblk_obs + blockIdx.x] = t_raw;
+        if (tid == 0) V.part_next[(size_t)w * V.nblk_obs + blockIdx.x] = t_raw;
         unsigned* hist = hist0_of(V, w, par ^ 1);
-        for (int b = threadIdx.x; b < kSelBins; b += kObsBlock) {
+        for (int b = tid; b < kEmitBins; b += kObsBlock) {
             const unsigned c = lh[b];
             if (c) atomicAdd(&hist[b], c);
         }
@@ -808,18 +886,20 @@ void launch_obs_accumulate(const DevView& V, hipStream_t s) {
     }
 }
 
-void launch_trial(const DevView& V, hipStream_t s) {
+template <int EMIT>
+static void launch_trial_emit(const DevView& V, hipStream_t s) {
     const dim3 g(V.nblk_obs + V.nblk_dyn, V.W), b(kObsBlock);
-    const int f = V.fused_trial;
-    if (V.emit) {
-        if (f == 1) hipLaunchKernelGGL((k_trial<true, 1>), g, b, 0, s, V);
-        else if (f == 2) hipLaunchKernelGGL((k_trial<true, 2>), g, b, 0, s, V);
-        else hipLaunchKernelGGL((k_trial<true, 0>), g, b, 0, s, V);
-    } else {
-        if (f == 1) hipLaunchKernelGGL((k_trial<false, 1>), g, b, 0, s, V);
-        else if (f == 2) hipLaunchKernelGGL((k_trial<false, 2>), g, b, 0, s, V);
-        else hipLaunchKernelGGL((k_trial<false, 0>), g, b, 0, s, V);
-    }
+    const int f = V.fused_trial;        // 0..3, see k_trial; V.nblk_dyn is the pose-chain block count of that geometry
+    if (f == 1) hipLaunchKernelGGL((k_trial<EMIT, 1>), g, b, 0, s, V);
+    else if (f == 2) hipLaunchKernelGGL((k_trial<EMIT, 2>), g, b, 0, s, V);
+    else if (f == 3) hipLaunchKernelGGL((k_trial<EMIT, 3>), g, b, 0, s, V);
+    else hipLaunchKernelGGL((k_trial<EMIT, 0>), g, b, 0, s, V);
+}
+
+void launch_trial(const DevView& V, hipStream_t s) {
+    if (V.emit == 2) launch_trial_emit<2>(V, s);
+    else if (V.emit == 1) launch_trial_emit<1>(V, s);
+    else launch_trial_emit<0>(V, s);
 }
 
 void launch_debug_project(const DevView& V, int w, int m, double* est, double* J, double* wt, hipStream_t s) {

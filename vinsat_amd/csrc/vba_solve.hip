@@ -712,23 +712,27 @@ __global__ __launch_bounds__(256) void k_solve_chunks_fused(DevView V, int s) {
     asm_stage<REG>(V, w, n, true, j0 - 1, nblk + 1, in, tid, 256);
     __syncthreads();
     const double inv_wmax = 1.0 / bits_f64(sc.wmax_bits);
-    for (int idx = tid; idx < nblk * 252; idx += 256) {
-        const int q = idx / 252, e = idx % 252;
-        const int i = j0 + q;
-        const AsmRow R = asm_row<REG>(in + (size_t)(q + 1) * kAsmIn, in + (size_t)q * kAsmIn, i, n, true, V.prm.sigma, inv_wmax);
-        double v;
-        if (e >= 243) {
-            v = rhs_entry(R, e - 243);
-            if (has_sep && i == j1) V.rhs[(sb + i) * 9 + (e - 243)] = v;
-        } else {
-            const int which = e / 81, a = (e % 81) / 9, b = e % 9;
-            v = band_entry(R, which, a, b);
-            if (which == 1) {
-                if (has_sep && i == j1) V.bands[(sb + i) * 243 + e] = v;
-                if (i == n - 1) V.lastD[(size_t)w * 81 + (e - 81)] = v;
+    // thread t forms entry t of every block of the chunk: which band / row / column it is is decoded once (as in k_assemble)
+    if (tid < 252) {
+        const int e = tid;
+        const bool is_rhs = e >= 243;
+        const int which = e / 81, a = is_rhs ? e - 243 : (e % 81) / 9, b = e % 9;
+        for (int q = 0; q < nblk; ++q) {
+            const int i = j0 + q;
+            const AsmRow R = asm_row<REG>(in + (size_t)(q + 1) * kAsmIn, in + (size_t)q * kAsmIn, i, n, true, V.prm.sigma, inv_wmax);
+            double v;
+            if (is_rhs) {
+                v = rhs_entry(R, a);
+                if (has_sep && i == j1) V.rhs[(sb + i) * 9 + a] = v;
+            } else {
+                v = band_entry(R, which, a, b);
+                if (which == 1) {
+                    if (has_sep && i == j1) V.bands[(sb + i) * 243 + e] = v;
+                    if (i == n - 1) V.lastD[(size_t)w * 81 + (e - 81)] = v;
+                }
             }
+            blocks[(size_t)q * 252 + e] = v;
         }
-        blocks[idx] = v;
     }
     __syncthreads();
     if (tid >= 64) return;      // the elimination is one wave's work (its barriers count the surviving wave only)

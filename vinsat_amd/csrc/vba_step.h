@@ -1,10 +1,11 @@
 // vba_step.h -- the step of ONE pose from the solved system and its retraction (A7 tail + A8 head), as device functions.
 //
-// Latency mode (few windows) has no kernel of its own for this: the trial kernel forms the step of every pose it needs
-// itself -- each observation thread for its own pose (redundantly: the ~100 observations of a pose compute the same
-// step), the pose-chain threads for the poses of their edges -- so the solve's recovery launch (full phase) and the whole
-// solve launch (landmark-only phase, a 6x6 system per pose) disappear from the chain.  Both forms are pure functions of
-// data that earlier kernels left in memory, so every thread that forms the step of a pose gets the same bits.
+// Latency mode (few windows) can do without a kernel of its own for this (vba_set_fusion bit 0): the trial kernel forms
+// the step of every pose it needs itself -- each observation block for the handful of poses its rows belong to, the
+// pose-chain blocks for the poses of their edges (16 lanes per pose either way) -- so the solve's recovery launch (full
+// phase) and the assembly + solve launch (landmark-only phase, a 6x6 system per pose) disappear from the chain.  Both
+// forms are pure functions of data that earlier kernels left in memory, so every block that forms the step of a pose gets
+// the same bits.
 #pragma once
 
 #include "vba_device.h"
@@ -80,21 +81,82 @@ __device__ __forceinline__ void step_recover(int i, int n, int s, const double* 
     }
 }
 
-// The trial state of pose i of window w (BA_filtering.py:55-60): MODE 1 landmark-only 6x6 solve, MODE 2 recovery of the
-// partitioned solve; o[10] = retracted state, d9 = the step.  bad: bit 0 pivot check failed, bit 1 non-finite step.
-template <int MODE>
-__device__ __forceinline__ void pose_trial_state(const DevView& V, int w, int i, double inv_wmax, double lam32, double* o,
-                                                 double* d9, unsigned& bad) {
-    const size_t sb = (size_t)w * V.n_max;
-    if (MODE == 1) {
-        if (!step_blockdiag6(V.Hraw + (sb + i) * 21, V.braw + (sb + i) * 6, inv_wmax, lam32, d9)) bad |= 1u;
-    } else {
-        step_recover(i, V.n[w], V.chunk, V.csol + sb * 171, V.rx + (size_t)w * V.p_max * 9, d9);
+// The same two forms of the step with the 16 lanes of a group working on ONE pose (l16 = lane inside the group, gbase =
+// wave lane of its lane 0): the serial versions above cost every wave that runs them their full instruction count, and
+// in latency mode instruction issue of a single wave IS the time.  Same arithmetic per element, so the same bits.
+//   landmark-only: lane c < 7 owns column c of [A | b] (Gauss-Jordan, pivot row broadcast from lane k);
+//   recovery:      lane r < 9 forms row r of the step.
+// d9 is returned to every lane of the group.  Returns false if a pivot check failed (landmark-only form).
+__device__ __forceinline__ bool step_blockdiag6_group(const double* H, const double* b, double inv_wmax, double lam32, int l16,
+                                                      int gbase, double* d9) {
+    double a[6];
+    const int c = l16 < 7 ? l16 : 6;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) a[r] = c < 6 ? H[sym6(r, c)] * inv_wmax + (r == c ? lam32 : 0.0) : b[r] * inv_wmax;
+    double d0 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) d0 = (r == c) ? a[r] : d0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double piv = __shfl(a[k], gbase + k, kWave);
+        if (l16 == k && !(piv > 1e-10 * d0)) ok = false;
+        const double inv = step_fast_rcp(piv);
+        double f[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) f[r] = (r != k) ? __shfl(a[r], gbase + k, kWave) : 0.0;
+        a[k] *= inv;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            if (r != k) a[r] -= f[r] * a[k];
     }
 #pragma unroll
-    for (int r = 0; r < 9; ++r)
-        if (!(fabs(d9[r]) <= 1.79e308)) bad |= 2u;
-    retract(V.states + (sb + i) * 10, d9, o);
+    for (int r = 0; r < 9; ++r) d9[r] = r < 6 ? __shfl(a[r], gbase + 6, kWave) : 0.0;
+    return ok;
+}
+
+__device__ __forceinline__ void step_recover_group(int i, int n, int s, const double* csol, const double* xsep, int l16, int gbase,
+                                                   double* d9) {
+    const int c = i / s;
+    const int P = (n + s - 1) / s;
+    const int r = l16 < 9 ? l16 : 0;
+    double v;
+    if ((c < P - 1) && (i == (c + 1) * s - 1)) {
+        v = xsep[(size_t)c * 9 + r];                // a separator: copied from the reduced solution
+    } else {
+        const double* so = csol + (size_t)i * 171;
+        v = so[r];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double xl = c > 0 ? xsep[(size_t)(c - 1) * 9 + k] : 0.0;
+            const double xr = c < P - 1 ? xsep[(size_t)c * 9 + k] : 0.0;
+            v -= so[(1 + k) * 9 + r] * xl + so[(10 + k) * 9 + r] * xr;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) d9[q] = __shfl(v, gbase + q, kWave);
+}
+
+// The trial state of pose i of window w (BA_filtering.py:55-60), formed by a 16-lane group: MODE 1 landmark-only 6x6 solve,
+// MODE 2 recovery of the partitioned solve.  o[10] (retracted state) and d9 (the step) are complete in lane 0 of the group;
+// every lane of the group must call (shuffles), `live` = the group has a pose.  bad: bit 0 pivot check failed (any lane
+// may carry it), bit 1 non-finite step.
+template <int MODE>
+__device__ __forceinline__ void pose_trial_state_group(const DevView& V, int w, int i, bool live, int l16, int gbase, double inv_wmax,
+                                                       double lam32, double* o, double* d9, unsigned& bad) {
+    const size_t sb = (size_t)w * V.n_max;
+    const int ii = live ? i : 0;
+    if (MODE == 1) {
+        if (!step_blockdiag6_group(V.Hraw + (sb + ii) * 21, V.braw + (sb + ii) * 6, inv_wmax, lam32, l16, gbase, d9) && live) bad |= 1u;
+    } else {
+        step_recover_group(ii, V.n[w], V.chunk, V.csol + sb * 171, V.rx + (size_t)w * V.p_max * 9, l16, gbase, d9);
+    }
+    if (live && l16 == 0) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+            if (!(fabs(d9[r]) <= 1.79e308)) bad |= 2u;
+        retract(V.states + (sb + ii) * 10, d9, o);
+    }
 }
 
 }  // namespace vba
