@@ -75,24 +75,30 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
         WinScalars& sc = V.sc[w];
         const double lam32 = (double)(float)sc.lam[V.par];      // torch.eye() is float32 (BA_filtering.py:54)
         if (blockIdx.x == 0 && threadIdx.x == 0) sc.lam32 = lam32;
+        // 16 lanes per pose: lane c < 7 owns column c of the 6x6 system [A | b] (vba_step.h); lane 0 retracts and stores
         bool badpiv = false, badnum = false;
-        if ((int)threadIdx.x < cnt) {
-            const int i = i0 + threadIdx.x;
-            const double* me = in + (threadIdx.x + 1) * kAsmIn;
-            double d9[9], o[10];
-            badpiv = !step_blockdiag6(me, me + 21, inv_wmax, lam32, d9);
+        if ((int)threadIdx.x < kAsmPoses * 16) {
+            const int grp = threadIdx.x >> 4, l16 = threadIdx.x & 15, gbase = (threadIdx.x & 63) & ~15;
+            const bool live = grp < cnt;
+            const double* me = in + ((live ? grp : 0) + 1) * kAsmIn;
+            double d9[9];
+            if (!step_blockdiag6_group(me, me + 21, inv_wmax, lam32, l16, gbase, d9) && live) badpiv = true;
+            if (live && l16 == 0) {
+                const int i = i0 + grp;
+                double o[10];
 #pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                badnum |= !(fabs(d9[r]) <= 1.79e308);
-                V.dpose[(sb + i) * 9 + r] = d9[r];
+                for (int r = 0; r < 9; ++r) {
+                    badnum |= !(fabs(d9[r]) <= 1.79e308);
+                    V.dpose[(sb + i) * 9 + r] = d9[r];
+                }
+                retract(V.states + (sb + i) * 10, d9, o);
+#pragma unroll
+                for (int r = 0; r < 10; ++r) V.states_new[(sb + i) * 10 + r] = o[r];
             }
-            retract(V.states + (sb + i) * 10, d9, o);
-#pragma unroll
-            for (int r = 0; r < 10; ++r) V.states_new[(sb + i) * 10 + r] = o[r];
         }
-        if (threadIdx.x < 64) {
+        {
             const unsigned long long bp = __ballot(badpiv), bn = __ballot(badnum);
-            if (threadIdx.x == 0 && (bp || bn)) atomicOr(&sc.fl[V.par], (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
+            if ((threadIdx.x & 63) == 0 && (bp || bn)) atomicOr(&sc.fl[V.par], (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
         }
     }
 }

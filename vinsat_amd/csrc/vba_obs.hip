@@ -122,13 +122,18 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
     for (int b = threadIdx.x; b < nbins; b += 256) lh[b] = 0u;
     // few keys per thread (single window, latency matters): their loads are issued before the histogram of the
     // previous digit is resolved, not after
+    // keys are read two at a time (16 bytes per lane: 8-byte accesses stream at little more than half that rate); the
+    // number of keys is even (two per observation row)
     constexpr bool PRELOAD = ITEMS <= 8;
-    unsigned long long pk[PRELOAD ? ITEMS : 1];
+    constexpr int PAIRS = ITEMS / 2;
+    const double2* keys2 = reinterpret_cast<const double2*>(keys);
+    const int64_t npair = count / 2;
+    double2 pk[PRELOAD ? PAIRS : 1];
     if (PRELOAD) {
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            const int64_t idx = ((int64_t)blockIdx.x * ITEMS + it) * 256 + threadIdx.x;
-            pk[it] = idx < count ? f64_bits(keys[idx]) : 0ull;
+        for (int it = 0; it < PAIRS; ++it) {
+            const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + threadIdx.x;
+            pk[it] = idx < npair ? keys2[idx] : make_double2(0.0, 0.0);
         }
     }
     unsigned long long prefix = 0ull;
@@ -146,32 +151,35 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
         V.sc[w].sel_rank[P] = rank;
         if (COMPACT) V.sc[w].sel_mode = 0;
     }
-#pragma unroll 8
-    for (int it = 0; it < ITEMS; ++it) {
-        const int64_t idx = ((int64_t)blockIdx.x * ITEMS + it) * 256 + threadIdx.x;
-        if (idx < count) {
-            const unsigned long long key = PRELOAD ? pk[it] : f64_bits(keys[idx]);
-            bool match = true;
-            if (P > 0) match = (key >> sel_shift(P > 0 ? P - 1 : 0)) == prefix;
-            if (match) atomicAdd(&lh[(unsigned)(key >> sel_shift(P)) & (nbins - 1)], 1u);
-            if (COMPACT) {
-                // wave-aggregated append: one atomic per wave instruction
-                const unsigned long long mask = __ballot(match);
-                if (mask) {
-                    const int lane = threadIdx.x & 63;
-                    const int leader = __ffsll((long long)mask) - 1;
-                    unsigned base = 0;
-                    if (lane == leader) base = atomicAdd(&V.sc[w].sel_cnt, (unsigned)__popcll(mask));
-                    base = __shfl(base, leader, kWave);
-                    if (match) {
-                        const unsigned off = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-                        // the list has room for 2 m_max keys; if more match (massive ties) select_finish sees
-                        // sel_cnt > capacity and rescans the full key array instead
-                        if ((int64_t)base + off < 2 * V.m_max) V.ckeys[2 * (size_t)w * V.m_max + base + off] = bits_f64(key);
-                    }
+    auto take = [&](unsigned long long key, bool have) {
+        bool match = have;
+        if (P > 0) match = have && (key >> sel_shift(P > 0 ? P - 1 : 0)) == prefix;
+        if (match) atomicAdd(&lh[(unsigned)(key >> sel_shift(P)) & (nbins - 1)], 1u);
+        if (COMPACT) {
+            // wave-aggregated append: one atomic per wave instruction
+            const unsigned long long mask = __ballot(match);
+            if (mask) {
+                const int lane = threadIdx.x & 63;
+                const int leader = __ffsll((long long)mask) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&V.sc[w].sel_cnt, (unsigned)__popcll(mask));
+                base = __shfl(base, leader, kWave);
+                if (match) {
+                    const unsigned off = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                    // the list has room for 2 m_max keys; if more match (massive ties) select_finish sees
+                    // sel_cnt > capacity and rescans the full key array instead
+                    if ((int64_t)base + off < 2 * V.m_max) V.ckeys[2 * (size_t)w * V.m_max + base + off] = bits_f64(key);
                 }
             }
         }
+    };
+#pragma unroll 8
+    for (int it = 0; it < PAIRS; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + threadIdx.x;
+        const bool have = idx < npair;
+        const double2 kk = PRELOAD ? pk[it] : (have ? keys2[idx] : make_double2(0.0, 0.0));
+        take(f64_bits(kk.x), have);
+        take(f64_bits(kk.y), have);
     }
     __syncthreads();
     unsigned* hist_out = digit_hist(P);
@@ -202,12 +210,15 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
     if ((int64_t)blockIdx.x * 256 * ITEMS >= count) return;         // (never block 0)
     // the keys of a short block are loaded before anything is decided (latency)
     constexpr bool PRELOAD = ITEMS <= 8;
-    unsigned long long pk[PRELOAD ? ITEMS : 1];
+    constexpr int PAIRS = ITEMS / 2;        // two keys (16 bytes) per load
+    const double2* keys2 = reinterpret_cast<const double2*>(keys);
+    const int64_t npair = count / 2;
+    double2 pk[PRELOAD ? PAIRS : 1];
     if (PRELOAD) {
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            const int64_t idx = ((int64_t)blockIdx.x * ITEMS + it) * 256 + t;
-            pk[it] = idx < count ? f64_bits(keys[idx]) : 0ull;
+        for (int it = 0; it < PAIRS; ++it) {
+            const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + t;
+            pk[it] = idx < npair ? keys2[idx] : make_double2(0.0, 0.0);
         }
     }
     const unsigned* h0 = hist0_of(V, w, par);
@@ -254,22 +265,25 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
         }
     }
     if (!hit) return;
-#pragma unroll 8
-    for (int it = 0; it < ITEMS; ++it) {
-        const int64_t idx = ((int64_t)blockIdx.x * ITEMS + it) * 256 + t;
-        if (idx < count) {
-            const unsigned long long key = PRELOAD ? pk[it] : f64_bits(keys[idx]);
-            const bool match = warm_bin(key, lo, V.warm_shift) == bin;
-            const unsigned long long mask = __ballot(match);
-            if (mask) {     // wave-aggregated append: one atomic per wave instruction
-                const int lane = t & 63;
-                const int leader = __ffsll((long long)mask) - 1;
-                unsigned base = 0;
-                if (lane == leader) base = atomicAdd(&sc.sel_cnt, (unsigned)__popcll(mask));
-                base = __shfl(base, leader, kWave);
-                if (match) V.ckeys[2 * (size_t)w * V.m_max + base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = bits_f64(key);
-            }
+    auto take = [&](unsigned long long key, bool have) {
+        const bool match = have && warm_bin(key, lo, V.warm_shift) == bin;
+        const unsigned long long mask = __ballot(match);
+        if (mask) {     // wave-aggregated append: one atomic per wave instruction
+            const int lane = t & 63;
+            const int leader = __ffsll((long long)mask) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&sc.sel_cnt, (unsigned)__popcll(mask));
+            base = __shfl(base, leader, kWave);
+            if (match) V.ckeys[2 * (size_t)w * V.m_max + base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = bits_f64(key);
         }
+    };
+#pragma unroll 8
+    for (int it = 0; it < PAIRS; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + t;
+        const bool have = idx < npair;
+        const double2 kk = PRELOAD ? pk[it] : (have ? keys2[idx] : make_double2(0.0, 0.0));
+        take(f64_bits(kk.x), have);
+        take(f64_bits(kk.y), have);
     }
 }
 
@@ -460,28 +474,66 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     rp.alpha_is_2 = prm.alpha_is_2;
     rp.expo_is_mhalf = prm.expo == -0.5;
 
-    // Phase 3: weights and accumulation
+    // Phase 3: weights and accumulation.
+    // J_k = [ -A R^T | 2 A hat(p_c) ] with A = d uv / d p_c (four non-zeros) and R the pose's rotation, the same for every row
+    // of the pose.  CAM (groups of <= 16 lanes: a lane sees a dozen rows or more): the lane sums in the CAMERA frame --
+    // G_k = [ -A | 2 A hat(p_c) ], whose translation part is the sparse A itself -- and rotates its sums once at the end
+    // (J^T J = T G^T G T^T, T = diag(R, I)): ~130 VALU instructions per row instead of ~215.  Few rows per lane (latency
+    // mode, 32 / 64 lanes per pose): the rotation per lane would cost what it saves, J is formed per row.
+    constexpr bool CAM = G <= 16;
     double wmax_l = 0.0;
     double acc[32];         // 21 + 6 sums, padded to a power of two for the halving reduction
 #pragma unroll
     for (int q = 0; q < 32; ++q) acc[q] = 0.0;
+    // CAM sums: M = sum wc A^T A (00, 02, 11, 12, 22; 01 = 0), T[j][c] = sum wc A[:,j] . Gr[:,c], Crr = sum wc Gr^T Gr (upper),
+    // st = sum wc A^T r, gr = sum wc Gr^T r
+    double cM[5] = {0, 0, 0, 0, 0}, cT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, cS[3] = {0, 0, 0};
     if (i < n) {
         auto process = [&](double ox_, double oy_, double oz_, double ou_, double ov_, double oc_, int k) {
-            double u, v, cam[3], d, J[12];
+            double u, v, cam[3], d;
             project(pc, ox_, oy_, oz_, u, v, cam, d);
-            project_jacobian(pc, cam, d, J);
             const double ru = ou_ - u, rv = ov_ - v;
             const double wr = robust_weight_raw(rp, ru, rv);
             V.wraw[mb + k] = wr;
             wmax_l = fmax(wmax_l, wr);
             const double wc = wr * oc_;
-            int q = 0;
+            if (CAM) {
+                const double live = cam[2] > kZMin ? 1.0 : 0.0;
+                const double a00 = pc.fx * d, a11 = pc.fy * d;
+                const double dl = d * live;
+                const double a02 = -(a00 * (cam[0] * dl)), a12 = -(a11 * (cam[1] * dl));
+                const double x = cam[0], y = cam[1], z = cam[2];
+                // Gr = 2 A hat(p_c): rows (g0..g2) and (h0..h2)
+                const double b00 = 2.0 * a00, b02 = 2.0 * a02, b11 = 2.0 * a11, b12 = 2.0 * a12;
+                const double g0 = -(b02 * y), g1 = fma(b02, x, -(b00 * z)), g2 = b00 * y;
+                const double h0 = fma(b11, z, -(b12 * y)), h1 = b12 * x, h2 = -(b11 * x);
+                const double w00 = wc * a00, w02 = wc * a02, w11 = wc * a11, w12 = wc * a12;
+                cM[0] = fma(w00, a00, cM[0]); cM[1] = fma(w00, a02, cM[1]);
+                cM[2] = fma(w11, a11, cM[2]); cM[3] = fma(w11, a12, cM[3]);
+                cM[4] = fma(w02, a02, fma(w12, a12, cM[4]));
+                cT[0] = fma(w00, g0, cT[0]); cT[1] = fma(w00, g1, cT[1]); cT[2] = fma(w00, g2, cT[2]);
+                cT[3] = fma(w11, h0, cT[3]); cT[4] = fma(w11, h1, cT[4]); cT[5] = fma(w11, h2, cT[5]);
+                cT[6] = fma(w02, g0, fma(w12, h0, cT[6])); cT[7] = fma(w02, g1, fma(w12, h1, cT[7]));
+                cT[8] = fma(w02, g2, fma(w12, h2, cT[8]));
+                const double wg0 = wc * g0, wg1 = wc * g1, wg2 = wc * g2, wh0 = wc * h0, wh1 = wc * h1, wh2 = wc * h2;
+                // rotation-rotation block straight into its place in the packed 6x6 (rows 3..5)
+                acc[15] = fma(wg0, g0, fma(wh0, h0, acc[15])); acc[16] = fma(wg0, g1, fma(wh0, h1, acc[16]));
+                acc[17] = fma(wg0, g2, fma(wh0, h2, acc[17])); acc[18] = fma(wg1, g1, fma(wh1, h1, acc[18]));
+                acc[19] = fma(wg1, g2, fma(wh1, h2, acc[19])); acc[20] = fma(wg2, g2, fma(wh2, h2, acc[20]));
+                cS[0] = fma(w00, ru, cS[0]); cS[1] = fma(w11, rv, cS[1]); cS[2] = fma(w02, ru, fma(w12, rv, cS[2]));
+                acc[24] = fma(wg0, ru, fma(wh0, rv, acc[24])); acc[25] = fma(wg1, ru, fma(wh1, rv, acc[25]));
+                acc[26] = fma(wg2, ru, fma(wh2, rv, acc[26]));
+            } else {
+                double J[12];
+                project_jacobian(pc, cam, d, J);
+                int q = 0;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const double ja = wc * J[a], jb = wc * J[6 + a];
+                for (int a = 0; a < 6; ++a) {
+                    const double ja = wc * J[a], jb = wc * J[6 + a];
 #pragma unroll
-                for (int b = a; b < 6; ++b) { acc[q] += ja * J[b] + jb * J[6 + b]; ++q; }
-                acc[21 + a] += ja * ru + jb * rv;
+                    for (int b = a; b < 6; ++b) { acc[q] = fma(ja, J[b], fma(jb, J[6 + b], acc[q])); ++q; }
+                    acc[21 + a] = fma(ja, ru, fma(jb, rv, acc[21 + a]));
+                }
             }
         };
         if (PAIR) {
@@ -505,6 +557,27 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
                 process(cur.x, cur.y, cur.z, cur.u, cur.v, cur.c, k);
                 k = kn;
             }
+        }
+    }
+    if (CAM) {
+        // the lane's camera-frame sums into the world frame (sums are linear, so before the reduction):
+        //   Htt = R M R^T, Htr = -R T, bt = -R st   (Jt = -A R^T; R[c][j] = pc.R[3 c + j])
+        const double* R = pc.R;
+        const double M[3][3] = {{cM[0], 0.0, cM[1]}, {0.0, cM[2], cM[3]}, {cM[1], cM[3], cM[4]}};
+        double Y[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) Y[a][kk] = fma(R[3 * a], M[0][kk], fma(R[3 * a + 1], M[1][kk], R[3 * a + 2] * M[2][kk]));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int b = a; b < 3; ++b)
+                acc[sym6(a, b)] = fma(Y[a][0], R[3 * b], fma(Y[a][1], R[3 * b + 1], Y[a][2] * R[3 * b + 2]));
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                acc[sym6(a, 3 + c)] = -fma(R[3 * a], cT[c], fma(R[3 * a + 1], cT[3 + c], R[3 * a + 2] * cT[6 + c]));
+            acc[21 + a] = -fma(R[3 * a], cS[0], fma(R[3 * a + 1], cS[1], R[3 * a + 2] * cS[2]));
         }
     }
     // Reduction over the G lanes of the pose by recursive halving: in step s (xor mask 2^s) a lane keeps the half of its
