@@ -703,7 +703,8 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
     // second stream, no cross-stream join), with many it runs beside the observation kernels on a second stream
     const bool ride = !init && !c.prof && h->W < 16;
     V.dyn_in_acc = ride ? 1 : 0;
-    const bool overlap = !init && !c.prof && !ride;
+    static const bool no_overlap = std::getenv("VBA_NO_OVERLAP") != nullptr;     // diagnostic: dynamics in line on the main stream
+    const bool overlap = !init && !c.prof && !ride && !no_overlap;
     auto fork_dynamics = [&]() -> int {
         HIPCHK(hipEventRecord(h->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));

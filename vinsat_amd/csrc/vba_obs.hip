@@ -303,11 +303,13 @@ __device__ __forceinline__ double select_finish(const DevView& V, int w, unsigne
     const int mode = sc.sel_mode;
     const unsigned long long warm_base = sc.warm_base;
     const double* ck = V.ckeys + 2 * (size_t)w * V.m_max;
+    // latency mode loads the first 1024 entries speculatively together with the length (one round trip instead of two);
+    // with many windows per launch every block of every window would drag 8 KB through the caches for a handful of keys
     unsigned long long pre[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned q = threadIdx.x + 256u * j;
-        pre[j] = (int64_t)q < 2 * V.m_max ? f64_bits(ck[q]) : 0ull;
+        pre[j] = ((int64_t)q < 2 * V.m_max && (V.lat || q < cnt)) ? f64_bits(ck[q]) : 0ull;
     }
     if (cnt <= (mode ? (unsigned)kWarmCount : 1024u)) {
         // the wanted key is the one of rank `want` among the list -- rank each key by counting (ties broken by position)
