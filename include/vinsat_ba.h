@@ -240,6 +240,37 @@ int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* 
  * (states/lamda updated).  Synchronous. */
 int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done);
 
+/* ---- free-landmark Schur-complement BA: ADD-ON, PARITY UNPINNED ------------------------------------------
+ * The reference keeps its landmarks fixed (BA_filtering.py:32-37) and has nothing to marginalise; this mode is the
+ * variant BASELINE.json's north_star describes on top of it and has NO counterpart in the reference.  Unknowns: 6 per
+ * pose (position, rotation; velocities untouched) and 3 per landmark, the landmarks held by a catalogue prior
+ * N(X0, sigma_prior^2 I); weights = confidences (the reference's alpha = 2 case).  One call of vba_schur_iterate builds the
+ * normal equations at the resident state, marginalises the landmarks (3x3 inversions), factorises the dense reduced
+ * camera system on the matrix cores (blocked Cholesky), back-substitutes, and keeps the step if the cost
+ * sum w |r|^2 + |X - X0|^2 / sigma^2 went down.  Validated against oracle/schur_oracle.py (this repository's own CPU
+ * restatement) only.  It shares nothing with a vba_handle and never runs inside vba_iterate.
+ *
+ * Structure arrays (built by the host once per window, vinsat_amd/schur.py): rows sorted by landmark with CSR lm_ptr[L+1];
+ * row_pose / row_lm [m]; the rows of every pose as CSR pose_ptr[n+1] -> pose_rows[m]; and, for every 6x6 block (i >= j) of
+ * the reduced system that two poses sharing a landmark touch (every diagonal block included), the list of row pairs
+ * (pair_k of pose i, pair_k2 of pose j, same landmark) as CSR blk_ptr[nblk+1], with blk_i / blk_j [nblk]. */
+typedef struct vba_schur_context* vba_schur_handle;
+const char* vba_schur_last_error(void);
+int vba_schur_create(int device, int n, int64_t m, int L, int nblk, int64_t npairs, vba_schur_handle* out);
+int vba_schur_destroy(vba_schur_handle h);
+int vba_schur_upload(vba_schur_handle h, const int* lm_ptr, const int* row_pose, const int* row_lm, const double* row_u,
+                     const double* row_v, const double* row_w, const int* pose_ptr, const int* pose_rows, const int* blk_i,
+                     const int* blk_j, const int* blk_ptr, const int* pair_k, const int* pair_k2, const double* intrinsics /*[n,4]*/,
+                     const double* X0 /*[L,3] catalogue positions*/, double sigma_prior);
+int vba_schur_set_state(vba_schur_handle h, const double* states /*[n,10]*/, const double* landmarks /*[L,3]*/);
+int vba_schur_get_state(vba_schur_handle h, double* states, double* landmarks);
+/* one LM trial at damping lamda (added to every diagonal entry of B and C); *accepted = the cost went down and the state moved */
+int vba_schur_iterate(vba_schur_handle h, double lamda, double* cost_before, double* cost_after, int* accepted);
+/* HIP-event times of the last iterate: build (blocks + Schur complement), factor (Cholesky), solve (substitutions + update) */
+int vba_schur_last_ms(vba_schur_handle h, float* build_ms, float* factor_ms, float* solve_ms);
+/* what = 0: the step of the last iterate [6 n + 3 L]; 1: its Cholesky factor, dense lower triangular [6n, 6n] */
+int vba_schur_debug_fetch(vba_schur_handle h, int what, double* out, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

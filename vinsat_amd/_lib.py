@@ -52,6 +52,16 @@ SIGNATURES = {
     "vba_sh_stage2": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "vba_sh_stage3": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "vba_sh_stage4": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int)]),
+    # free-landmark Schur add-on (parity unpinned: no counterpart in the reference)
+    "vba_schur_last_error": (c_char_p, []),
+    "vba_schur_create": (c_int, [c_int, c_int, c_int64, c_int, c_int, c_int64, POINTER(c_void_p)]),
+    "vba_schur_destroy": (c_int, [c_void_p]),
+    "vba_schur_upload": (c_int, [c_void_p] + [c_void_p] * 15 + [c_double]),
+    "vba_schur_set_state": (c_int, [c_void_p, PD, PD]),
+    "vba_schur_get_state": (c_int, [c_void_p, PD, PD]),
+    "vba_schur_iterate": (c_int, [c_void_p, c_double, PD, PD, POINTER(c_int)]),
+    "vba_schur_last_ms": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float)]),
+    "vba_schur_debug_fetch": (c_int, [c_void_p, c_int, PD, c_int64]),
 }
 
 _lib = None

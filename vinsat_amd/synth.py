@@ -163,6 +163,60 @@ def make_subwindow(cfg: WindowConfig | str, n_poses: int, **kw):
     return det[det[:, 0] < t_end].copy(), orbit[: t_end + 5].copy()
 
 
+def make_tracked_landmarks(n_poses=40, n_landmarks=600, stride=5, seed=0, pixel_noise=1.0, catalogue_sigma_km=0.05, t0=10):
+    """Synthetic free-landmark problem (the add-on of ``vinsat_amd/schur.py``; the reference has no such data): ground
+    landmarks scattered along the ground track, each seen from every frame whose footprint (+-1.2 deg latitude, +-2 deg
+    longitude around the sub-satellite point, as :func:`make_sequence`) contains it -- tracks of several frames.
+
+    Returns a dict: ``states_gt [n,10]`` (nadir attitude, finite-difference velocity), ``X_true [L,3]`` ECI km (a landmark is
+    taken at the Earth rotation angle of the first frame that sees it: the add-on treats landmarks as inertial points, so
+    frames are kept within ~1 minute where the ground moves less than the catalogue uncertainty would allow -- synthetic
+    data for the solver, not a model of the real scene), ``X0`` = truth + catalogue error, ``uv``, ``pose_of_row``,
+    ``landmark_of_row``, ``intrinsics [n,4]``.
+    """
+    rng = np.random.default_rng(seed)
+    n_sec = t0 + n_poses * stride + 5
+    traj = integrate_orbit(n_sec)
+    times = t0 + stride * np.arange(n_poses)
+    pos = traj[times, :3]
+    vel = traj[times, 3:]
+    quat = frames.nadir_quaternion(pos)
+    states = np.concatenate([pos, quat, vel], axis=1)
+    # landmarks: points on a sphere of Earth radius under the track, scattered across the footprint
+    sub = pos / np.linalg.norm(pos, axis=1, keepdims=True)
+    along = rng.uniform(0, n_poses - 1, n_landmarks)
+    i0 = np.floor(along).astype(int)
+    f = (along - i0)[:, None]
+    c = sub[i0] * (1 - f) + sub[np.minimum(i0 + 1, n_poses - 1)] * f
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    e1 = np.cross(c, np.array([0.0, 0.0, 1.0]))
+    e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    e2 = np.cross(c, e1)
+    off1, off2 = np.deg2rad(rng.uniform(-1.8, 1.8, n_landmarks)), np.deg2rad(rng.uniform(-1.0, 1.0, n_landmarks))
+    X = c + e1 * off1[:, None] + e2 * off2[:, None]
+    X = frames.A_EARTH_KM * X / np.linalg.norm(X, axis=1, keepdims=True)
+    rows_p, rows_l, uvs = [], [], []
+    for i in range(n_poses):
+        uv = project(np.repeat(pos[i:i + 1], n_landmarks, 0), np.repeat(quat[i:i + 1], n_landmarks, 0), X, INTRINSICS)
+        R = quat_to_matrix(quat[i])
+        depth = (X - pos[i]) @ R[:, 2]
+        vis = (uv[:, 0] > 50) & (uv[:, 0] < 4558) & (uv[:, 1] > 50) & (uv[:, 1] < 2542) & (depth > 1.0)
+        idx = np.nonzero(vis)[0]
+        rows_p.append(np.full(idx.size, i))
+        rows_l.append(idx)
+        uvs.append(uv[idx] + rng.normal(0.0, pixel_noise, (idx.size, 2)))
+    pose_of_row, landmark_of_row, uv = np.concatenate(rows_p), np.concatenate(rows_l), np.concatenate(uvs)
+    # drop landmarks nobody sees, renumber
+    seen = np.unique(landmark_of_row)
+    remap = -np.ones(n_landmarks, dtype=np.int64)
+    remap[seen] = np.arange(seen.size)
+    X = X[seen]
+    landmark_of_row = remap[landmark_of_row]
+    X0 = X + rng.normal(0.0, catalogue_sigma_km, X.shape)
+    return dict(states_gt=states, X_true=X, X0=X0, uv=uv, pose_of_row=pose_of_row, landmark_of_row=landmark_of_row,
+                intrinsics=np.repeat(INTRINSICS[None], n_poses, 0), sigma=catalogue_sigma_km)
+
+
 def make_two_pass_sequence(n_poses=12, obs_per_pose=6, stride=5, gap=1500, seed=4, pixel_noise=1.0, conf=0.95, tail=140):
     """Two ground-station-like passes separated by ``gap`` seconds without detections.
 
