@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = every core of this box)")
     ap.add_argument("--no-sharded", action="store_true")
+    ap.add_argument("--no-schur", action="store_true", help="skip the free-landmark Schur add-on leg (parity unpinned, not part of the metric)")
     ap.add_argument("--rank-timeout", type=float, default=900.0, help="launcher: seconds before hung rank processes are ended")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)     # internal: CPU baseline worker
     ap.add_argument("--dry-run", action="store_true", help="launcher / control-plane self-test without a GPU: ranks rendezvous "
@@ -531,6 +532,37 @@ def run_rank(args):
                     "pos_rmse_vs_truth_km": float(np.sqrt(((s_fin[:, :3] - gt[:, :3]) ** 2).sum(1).mean())),
                     "reference": "states after call 19 of the reference's own run on the same inputs (tests/golden)"}
 
+    # ---- free-landmark Schur-complement add-on (PARITY UNPINNED: no counterpart in the reference; not part of the metric)
+    schur = None
+    if rank == 0 and world == 1 and not args.no_schur and not force_dist:
+        try:
+            from vinsat_amd.schur import SchurBA
+            d = synth.make_tracked_landmarks(n_poses=500, n_landmarks=20000, seed=0)
+            rng = np.random.default_rng(1)
+            st_s = d["states_gt"].copy()
+            st_s[:, :3] += rng.normal(0, 2.0, st_s[:, :3].shape)
+            sb = SchurBA(st_s, d["X0"], d["uv"], np.full(d["uv"].shape[0], 0.95), d["pose_of_row"], d["landmark_of_row"], d["intrinsics"],
+                         sigma_prior=d["sigma"], device=device)
+            lam_s, ms_s, costs = 1e-4, [], []
+            for it in range(6):
+                c0, c1, ok = sb.iterate(lam_s)
+                ms_s.append(sb.last_ms())
+                costs.append(c0)
+                lam_s = max(lam_s * 0.1, 1e-9) if ok else lam_s * 10
+            Np = (6 * 500 + 63) // 64 * 64
+            fac = float(np.mean([x["factor"] for x in ms_s[1:]]))
+            schur = {"parity": "unpinned (the reference keeps landmarks fixed, BA_filtering.py:32-37: no counterpart)",
+                     "poses": 500, "landmarks": int(d["X_true"].shape[0]), "rows": int(d["uv"].shape[0]), "reduced_system": 3000,
+                     "ms_per_trial": {k: float(np.mean([x[k] for x in ms_s[1:]])) for k in ms_s[0]},
+                     "trials_per_s": 1e3 / float(np.mean([sum(x.values()) for x in ms_s[1:]])),
+                     "cholesky_TFLOPs": Np ** 3 / 3.0 / (fac * 1e-3) / 1e12, "fp64_matrix_peak_TFLOPs": MFMA_F64_PEAK_TFLOPS,
+                     "cost_first_last": [costs[0], costs[-1]],
+                     "note": "dense reduced camera system factorised on the matrix cores; the MFMA counters of the 2000-pose / "
+                             "12000 x 12000 case are in profiles/r02_schur_mfma.json (trailing update 13.9 TFLOP/s = 18 % of the fp64 matrix peak)"}
+            sb.close()
+        except Exception as exc:
+            schur = {"error": repr(exc)[:300]}
+
     em.payload = {
         "metric": METRIC,
         "value": value, "unit": "BA iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -549,6 +581,7 @@ def run_rank(args):
         "accuracy": accuracy,
         "cpu_baseline": cpu,
         "batched": batched,
+        "schur_addon": schur,
     }
 
     # ---- observation-sharded mode: ONE window whose rows are split over the ranks, collectives over RCCL

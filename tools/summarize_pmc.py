@@ -18,7 +18,7 @@ MFMA_F64_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix (vendor figure; the guide'
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     return name.replace("void ", "").replace("vba::", "").strip()
 
 

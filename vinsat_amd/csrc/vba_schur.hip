@@ -21,7 +21,7 @@
 //   k_pair_blocks   wave per (i, j) block of S: S_ij -= sum over the rows pairs sharing a landmark of Y_k E_k'^T
 //   k_potrf64       64x64 diagonal block: Cholesky factor and its inverse (one workgroup, LDS)
 //   k_gemm_abt      64x64x64 tiles on the matrix cores: panel = A inv(L)^T (MODE 0), trailing S_IJ -= L_I L_J^T (MODE 1)
-//   k_trsv          forward / backward substitution with the stored inverse diagonal factors (one workgroup)
+//   k_trsv_step     one tile step of the forward / backward substitution (stored inverse diagonal factors), a launch per step
 //   k_lm_update     dl, new landmarks, new poses (retraction as BA_filtering.py:56-60)
 //   k_cost          sum w |r|^2 + prior, block partials
 #include <algorithm>
@@ -74,7 +74,8 @@ struct SchurView {
     double* E;                      // [m][18] row major 6x3
     double* Y;                      // [m][18]
     double* S;                      // [Npad][Npad] row major, lower triangle used
-    double* g;                      // [Npad]
+    double* g;                      // [Npad] right-hand side, then the step of the poses
+    double* ybuf;                   // [Npad] intermediate of the two substitutions
     double* invL;                   // [nb][kT*kT] inverse of the diagonal Cholesky factors
     double* dl;                     // [L][3]
     double* part;                   // cost partials
@@ -257,51 +258,50 @@ __global__ void k_pad_identity(SchurView V) {
 }
 
 // ------------------------------------------------------------------------------------------------ dense Cholesky
-// Diagonal tile kb: A_kk = L L^T in place (lower), inverse of L into invL[kb] (row major, lower).  One workgroup.
-__global__ __launch_bounds__(256) void k_potrf64(SchurView V, int kb, int* info) {
-    __shared__ double A[kT][kT + 1];
-    __shared__ double Li[kT][kT + 1];
-    const int t = threadIdx.x;
+// Diagonal tile kb: A_kk = L L^T in place (lower), inverse of L into invL[kb] (row major, lower).  ONE WAVE, the tile in
+// registers: lane r holds row r (64 doubles); column j is scaled and the rank-1 update of the rows below runs with the
+// column entries broadcast from their lanes (v_readlane) -- no LDS, no barrier (the LDS version spent its 130 us in 192
+// workgroup barriers).  The inverse (needed so that the panel solve is a matrix product for the matrix cores) follows the
+// same way: lane c owns column c of L^-1, the entries L[r][k] are broadcast.
+__device__ __forceinline__ double bcast64(double v, int lane) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__global__ __launch_bounds__(64) void k_potrf64(SchurView V, int kb, int* info) {
+    const int r = threadIdx.x;
     double* At = V.S + (size_t)(kb * kT) * V.Npad + kb * kT;
-    for (int e = t; e < kT * kT; e += 256) {
-        const int r = e / kT, c = e % kT;
-        A[r][c] = c <= r ? At[(size_t)r * V.Npad + c] : 0.0;
-        Li[r][c] = 0.0;
-    }
-    __syncthreads();
+    double a[kT];
+#pragma unroll
+    for (int c = 0; c < kT; ++c) a[c] = At[(size_t)r * V.Npad + c];     // (the upper part is never used)
+    bool bad = false;
+#pragma unroll
     for (int j = 0; j < kT; ++j) {
-        const double d = A[j][j];
-        if (t == 0 && !(d > 0.0)) *info = kb * kT + j + 1;
+        const double d = bcast64(a[j], j);
+        if (!(d > 0.0)) bad = true;
         const double sd = sqrt(d > 0.0 ? d : 1.0), isd = 1.0 / sd;
-        __syncthreads();
-        if (t < kT) {
-            if (t == j) A[j][j] = sd;
-            else if (t > j) A[t][j] *= isd;
-        }
-        __syncthreads();
-        // trailing update of the lower triangle: A[r][c] -= A[r][j] A[c][j], j < c <= r
-        for (int e = t; e < kT * kT; e += 256) {
-            const int r = e / kT, c = e % kT;
-            if (c > j && r >= c) A[r][c] -= A[r][j] * A[c][j];
-        }
-        __syncthreads();
+        a[j] = r == j ? sd : a[j] * isd;            // column j: L[r][j] for r > j (rows above j hold garbage there, never read)
+#pragma unroll
+        for (int c = j + 1; c < kT; ++c) a[c] = fma(-a[j], bcast64(a[j], c), a[c]);     // A[r][c] -= L[r][j] L[c][j]; used for r >= c
     }
-    // inverse of the lower-triangular factor, column c by thread c (forward substitution)
-    if (t < kT) {
-        const int c = t;
-        for (int r = c; r < kT; ++r) {
-            double s = r == c ? 1.0 : 0.0;
-            for (int k = c; k < r; ++k) s -= A[r][k] * Li[k][c];
-            Li[r][c] = s / A[r][r];
-        }
+    if (bad && r == 0) *info = kb * kT + 1;
+#pragma unroll
+    for (int c = 0; c < kT; ++c)
+        if (c <= r) At[(size_t)r * V.Npad + c] = a[c];
+    // inverse: lane c owns column c of X = L^-1 (x[k] = X[k][c]); X[rr][c] = (delta - sum_{k < rr} L[rr][k] X[k][c]) / L[rr][rr]
+    double x[kT];
+#pragma unroll
+    for (int rr = 0; rr < kT; ++rr) {
+        double s = rr == r ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < rr; ++k) s = fma(-bcast64(a[k], rr), x[k], s);
+        x[rr] = s / bcast64(a[rr], rr);
     }
-    __syncthreads();
     double* out = V.invL + (size_t)kb * kT * kT;
-    for (int e = t; e < kT * kT; e += 256) {
-        const int r = e / kT, c = e % kT;
-        if (c <= r) At[(size_t)r * V.Npad + c] = A[r][c];
-        out[e] = Li[r][c];
-    }
+#pragma unroll
+    for (int rr = 0; rr < kT; ++rr) out[(size_t)rr * kT + r] = r <= rr ? x[rr] : 0.0;
 }
 
 // One 64x64 tile of  out = alpha * (C + sign * A B^T)  on the matrix cores.  A, B: 64x64 row major with leading dimension
@@ -370,36 +370,50 @@ __global__ __launch_bounds__(256) void k_gemm_abt(SchurView V, int kb) {
             }
 }
 
-// forward (L y = g) and backward (L^T x = y) substitution by tiles with the stored inverse diagonal factors; one workgroup
-__global__ __launch_bounds__(1024) void k_trsv(SchurView V, int backward) {
+// One tile step of the forward (L y = g) / backward (L^T x = y) substitution, a launch per step (as the factorisation):
+// block 0 forms the step's 64 solution entries from the stored inverse diagonal factor, every other block forms them too
+// (a 64x64 product, cheaper than a hand-off) and updates ONE tile of the right-hand side with them.  Tiles further than bw
+// from the diagonal are zero (the factor of a banded matrix keeps its band) and get no block.
+//   forward:  y_kb = invL_kb g_kb (-> ybuf),  g_I    -= L_{I,kb}   y_kb   for kb < I <= kb + bw
+//   backward: x_kb = invL_kb^T ybuf_kb (-> g), ybuf_J -= L_{kb,J}^T x_kb   for kb - bw <= J < kb
+__global__ __launch_bounds__(256) void k_trsv_step(SchurView V, int kb, int backward) {
     __shared__ double xb[kT];
-    const int t = threadIdx.x;
-    const int nb = V.nb;
-    for (int step = 0; step < nb; ++step) {
-        const int kb = backward ? nb - 1 - step : step;
-        const double* Li = V.invL + (size_t)kb * kT * kT;
-        if (t < kT) {       // x_kb = invL g_kb  (forward)  /  invL^T g_kb  (backward)
-            double s = 0.0;
-            if (!backward) { for (int c = 0; c <= t; ++c) s += Li[t * kT + c] * V.g[kb * kT + c]; }
-            else { for (int c = t; c < kT; ++c) s += Li[c * kT + t] * V.g[kb * kT + c]; }
-            xb[t] = s;
+    __shared__ double gb[kT];
+    __shared__ double part[4][kT];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const double* Li = V.invL + (size_t)kb * kT * kT;
+    const double* rhs = backward ? V.ybuf : V.g;
+    if (t < kT) gb[t] = rhs[kb * kT + t];
+    __syncthreads();
+    for (int e = wv; e < kT; e += 4) {      // entry e: a 64-term dot product by one wave
+        double sdot = backward ? Li[(size_t)lane * kT + e] * gb[lane] : Li[(size_t)e * kT + lane] * gb[lane];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+        if (lane == 0) xb[e] = sdot;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (t < kT) (backward ? V.g : V.ybuf)[kb * kT + t] = xb[t];
+        return;
+    }
+    if (!backward) {
+        const int I = kb + (int)blockIdx.x;
+        // rows of the tile over the waves, lanes over its columns (64 consecutive doubles per load)
+        for (int rr = wv; rr < kT; rr += 4) {
+            const size_t row = (size_t)I * kT + rr;
+            double sdot = V.S[row * V.Npad + kb * kT + lane] * xb[lane];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+            if (lane == 0) V.g[row] -= sdot;
         }
+    } else {
+        const int J = kb - (int)blockIdx.x;
+        // lanes over the tile's columns (= entries of ybuf_J), the 64 rows split over the waves, partial sums through LDS
+        double sdot = 0.0;
+        for (int c = wv; c < kT; c += 4) sdot = fma(V.S[(size_t)(kb * kT + c) * V.Npad + J * kT + lane], xb[c], sdot);
+        part[wv][lane] = sdot;
         __syncthreads();
-        if (t < kT) V.g[kb * kT + t] = xb[t];
-        // g_I -= L_{I,kb} x_kb (forward, I > kb)   /   g_J -= L_{kb,J}^T x_kb (backward, J < kb)
-        const int rows = backward ? kb * kT : (nb - kb - 1) * kT;
-        for (int r = t; r < rows; r += 1024) {
-            double s = 0.0;
-            if (!backward) {
-                const double* Lr = V.S + (size_t)((kb + 1) * kT + r) * V.Npad + kb * kT;
-                for (int c = 0; c < kT; ++c) s += Lr[c] * xb[c];
-                V.g[(kb + 1) * kT + r] -= s;
-            } else {
-                for (int c = 0; c < kT; ++c) s += V.S[(size_t)(kb * kT + c) * V.Npad + r] * xb[c];
-                V.g[r] -= s;
-            }
-        }
-        __syncthreads();
+        if (wv == 0) V.ybuf[J * kT + lane] -= ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     }
 }
 
@@ -483,6 +497,7 @@ struct vba_schur_context {
     bool uploaded = false, have_state = false;
     float ms[4] = {0, 0, 0, 0};
     int64_t npairs = 0;
+    int bw = 1 << 30;           // tile bandwidth of the reduced system (max |I - J| over its non-zero tiles), from the block list
 };
 
 extern "C" {
@@ -515,7 +530,7 @@ int vba_schur_create(int device, int n, int64_t m, int L, int nblk, int64_t npai
     const size_t o_intr = need((size_t)n * 32), o_X0 = need((size_t)L * 24);
     const size_t o_s0 = need((size_t)n * 80), o_s1 = need((size_t)n * 80), o_x0 = need((size_t)L * 24), o_x1 = need((size_t)L * 24);
     const size_t o_ci = need((size_t)L * 48), o_wl = need((size_t)L * 24), o_E = need(m * 144), o_Y = need(m * 144);
-    const size_t o_S = need((size_t)V.Npad * V.Npad * 8), o_g = need((size_t)V.Npad * 8), o_iL = need((size_t)V.nb * kT * kT * 8);
+    const size_t o_S = need((size_t)V.Npad * V.Npad * 8), o_g = need((size_t)V.Npad * 8), o_y = need((size_t)V.Npad * 8), o_iL = need((size_t)V.nb * kT * kT * 8);
     const size_t o_dl = need((size_t)L * 24), o_part = need((size_t)V.npart * 8), o_info = need(256);
     if (hipMalloc(&h->arena, bytes) != hipSuccess) { delete h; return sfail(VBA_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
     if (hipMemset(h->arena, 0, bytes) != hipSuccess) { hipFree(h->arena); delete h; return sfail(VBA_EHIP, "hipMemset failed"); }
@@ -527,7 +542,7 @@ int vba_schur_create(int device, int n, int64_t m, int L, int nblk, int64_t npai
     V.intr = (double*)(A + o_intr); V.X0 = (double*)(A + o_X0);
     h->S0 = (double*)(A + o_s0); h->S1 = (double*)(A + o_s1); h->X0buf = (double*)(A + o_x0); h->X1buf = (double*)(A + o_x1);
     V.Cinv = (double*)(A + o_ci); V.wl = (double*)(A + o_wl); V.E = (double*)(A + o_E); V.Y = (double*)(A + o_Y);
-    V.S = (double*)(A + o_S); V.g = (double*)(A + o_g); V.invL = (double*)(A + o_iL);
+    V.S = (double*)(A + o_S); V.g = (double*)(A + o_g); V.ybuf = (double*)(A + o_y); V.invL = (double*)(A + o_iL);
     V.dl = (double*)(A + o_dl); V.part = (double*)(A + o_part); h->d_info = (int*)(A + o_info);
     h->h_part.resize(V.npart);
     bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
@@ -581,6 +596,8 @@ int vba_schur_upload(vba_schur_handle h, const int* lm_ptr, const int* row_pose,
     SCHK(up(V.pair_k, pair_k, h->npairs * 4)); SCHK(up(V.pair_k2, pair_k2, h->npairs * 4));
     SCHK(up(V.intr, intrinsics, (size_t)V.n * 32)); SCHK(up(V.X0, X0, (size_t)V.L * 24));
     h->V.inv_sigma2 = 1.0 / (sigma_prior * sigma_prior);
+    h->bw = 0;
+    for (int b = 0; b < V.nblk; ++b) h->bw = std::max(h->bw, (6 * blk_i[b] + 5) / kT - (6 * blk_j[b]) / kT);
     h->uploaded = true;
     return VBA_OK;
 }
@@ -637,7 +654,7 @@ int vba_schur_iterate(vba_schur_handle h, double lamda, double* cost_before, dou
     if (V.Npad > V.N) hipLaunchKernelGGL(k_pad_identity, dim3(1), dim3(64), 0, s, V);
     SCHK(hipEventRecord(h->ev[1], s));
     for (int kb = 0; kb < V.nb; ++kb) {
-        hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, V, kb, h->d_info);
+        hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, s, V, kb, h->d_info);
         const int rest = V.nb - kb - 1;
         if (rest > 0) {
             hipLaunchKernelGGL((k_gemm_abt<0>), dim3(rest), dim3(256), 0, s, V, kb);
@@ -645,8 +662,10 @@ int vba_schur_iterate(vba_schur_handle h, double lamda, double* cost_before, dou
         }
     }
     SCHK(hipEventRecord(h->ev[2], s));
-    hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), 0, s, V, 0);
-    hipLaunchKernelGGL(k_trsv, dim3(1), dim3(1024), 0, s, V, 1);
+    for (int kb = 0; kb < V.nb; ++kb)
+        hipLaunchKernelGGL(k_trsv_step, dim3(1 + std::min(h->bw, V.nb - 1 - kb)), dim3(256), 0, s, V, kb, 0);
+    for (int kb = V.nb - 1; kb >= 0; --kb)
+        hipLaunchKernelGGL(k_trsv_step, dim3(1 + std::min(h->bw, kb)), dim3(256), 0, s, V, kb, 1);
     hipLaunchKernelGGL(k_lm_update, dim3((std::max(V.L, V.n) + 255) / 256), dim3(256), 0, s, V);
     SCHK(hipEventRecord(h->ev[3], s));
     SCHK(hipGetLastError());

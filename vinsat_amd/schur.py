@@ -47,6 +47,9 @@ def build_structure(pose_of_row, landmark_of_row, n, L):
     pose_ptr = np.cumsum(pose_ptr)
     # row pairs (k, k') of one landmark with pose(k) >= pose(k'): rows of a landmark are sorted by pose, so k >= k'
     cnt = np.diff(lm_ptr)
+    npairs = int((cnt * (cnt + 1) // 2).sum())
+    if npairs > 400_000_000:
+        raise ValueError(f"{npairs} row pairs: tracks this long are not a bundle-adjustment window (check the visibility model)")
     ks, k2s = [], []
     for t in np.unique(cnt):
         if t == 0:

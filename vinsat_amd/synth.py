@@ -200,7 +200,8 @@ def make_tracked_landmarks(n_poses=40, n_landmarks=600, stride=5, seed=0, pixel_
         uv = project(np.repeat(pos[i:i + 1], n_landmarks, 0), np.repeat(quat[i:i + 1], n_landmarks, 0), X, INTRINSICS)
         R = quat_to_matrix(quat[i])
         depth = (X - pos[i]) @ R[:, 2]
-        vis = (uv[:, 0] > 50) & (uv[:, 0] < 4558) & (uv[:, 1] > 50) & (uv[:, 1] < 2542) & (depth > 1.0)
+        horizon = np.sqrt(max(pos[i] @ pos[i] - frames.A_EARTH_KM ** 2, 1.0))      # beyond it the Earth is in the way
+        vis = (uv[:, 0] > 50) & (uv[:, 0] < 4558) & (uv[:, 1] > 50) & (uv[:, 1] < 2542) & (depth > 1.0) & (depth < horizon)
         idx = np.nonzero(vis)[0]
         rows_p.append(np.full(idx.size, i))
         rows_l.append(idx)
