@@ -56,3 +56,15 @@ def test_no_gpu_is_reported_not_hidden(lib_path):
         from vinsat_amd.engine import BAEngine
         with pytest.raises(_lib.VbaError):
             BAEngine(16, 256)
+
+
+def test_one_hip_runtime_in_the_process_whichever_is_imported_first():
+    """The wheel of PyTorch bundles its own HIP runtime; the library binds to that copy (vinsat_amd/_lib.py), so that a
+    process that calls BA() on numpy arrays first and touches torch.cuda later does not end up with two ROCr instances
+    (the second one cannot open the device)."""
+    import subprocess, sys
+    code = ("from vinsat_amd import _lib; _lib.load(); import torch; "
+            "maps = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}; print(len(maps))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "1"

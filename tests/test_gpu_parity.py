@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import golden_inputs, load_golden, rel_err
+from conftest import ROOT, golden_inputs, load_golden, rel_err
 from oracle import ba_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -1293,3 +1293,13 @@ def test_latency_mode_fusions_vs_reference(c2, mask):
             e.close()
         assert outs[0][3] == outs[1][3] and outs[0][1] == outs[1][1] and outs[0][4] == outs[1][4]
         assert rel_err(outs[1][0], outs[0][0]) < 1e-7
+
+
+def test_torch_cuda_initialises_after_the_library_has_used_the_gpu():
+    """Load order: the library first (numpy call surface), torch.cuda afterwards, in a fresh process."""
+    import subprocess, sys
+    code = ("import numpy as np; from vinsat_amd.engine import BAEngine; e = BAEngine(4, 8); e.close(); "
+            "import torch; x = torch.zeros(3, device='cuda'); print(int(x.sum().item()))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "0"

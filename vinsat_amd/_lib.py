@@ -71,6 +71,23 @@ class VbaError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64 / libhsa-runtime64; a process that
+    loads the system copy first (through this library) and torch's afterwards ends up with two ROCr instances, and the
+    second one cannot open the device (``No HIP GPUs are available``).  Both copies carry the SONAME libamdhip64.so.7,
+    so loading torch's copy first makes the dynamic loader bind this library to it, whichever is imported first."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load the shared library and set the prototypes (raises if it has not been built)."""
     global _lib
@@ -79,6 +96,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VbaError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "or `make -C vinsat_amd/csrc` (there is no CPU fallback)")
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the .so is stale

@@ -19,6 +19,105 @@ __global__ __launch_bounds__(256) void k_dynamics(DevView V) {
     dynamics_block(V, w, blockIdx.x);
 }
 
+// Batched windows: TWO lanes per pose, three tangents each, 128 poses per block.  With thousands of windows there are
+// poses enough to fill the chip without spreading one pose over eight lanes, and the eight-lane form pays for that
+// spread: the base trajectory is integrated by all six tangent lanes, and the attitude term and the prior are divergent
+// sections that a wave runs for 8 poses at a time (here for 32).  Per tangent the arithmetic is that of dynamics_block
+// (rk4_step_multi); the block sums of |r_pred| / |r_prior| are formed in the order of the eight-lane layout (a wave_sum
+// over the 64 slots of 8 poses, four of them added in sequence), so the accept test sees the same bits in both modes.
+__global__ __launch_bounds__(256) void k_dynamics_pair(DevView V) {
+    __shared__ double slot[128 * 3];        // per pose: sum |r_orbit|, |f_att|, sum |r_prior|
+    __shared__ double vw[2][16];
+    const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
+    const int n = V.n[w];
+    const int lp = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int i = blockIdx.x * 128 + lp;
+    const size_t pb = (size_t)w * V.n_max + (i < n ? i : 0);
+    const double* st = V.states + pb * 10;
+    double s_orb = 0.0, s_att = 0.0, s_pri = 0.0;
+    if (i < n) {
+        if (i < n - 1) {            // the last pose's propagation is discarded by the reference (BA_utils.py:476)
+            double x[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
+            double t[3][6];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) t[j][r] = (r == 3 * half + j) ? 1.0 : 0.0;
+            propagate_gap_multi<3>(x, t, V.steps[pb], V.hop);
+            double* Phi = V.Phi + pb * 36;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) Phi[6 * r + 3 * half + j] = t[j][r];
+            if (half == 1) {
+                const double* sn = st + 10;
+                double* xh = V.xhat + pb * 6;
+                double* ro = V.rorb + pb * 6;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) xh[r] = x[r];
+                ro[0] = x[0] - sn[0];
+                ro[1] = x[1] - sn[1];
+                ro[2] = x[2] - sn[2];
+                ro[3] = (x[3] - sn[7]) * kVelCoeff;
+                ro[4] = (x[4] - sn[8]) * kVelCoeff;
+                ro[5] = (x[5] - sn[9]) * kVelCoeff;
+                s_orb = fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]);
+            }
+        }
+        if (half == 0) {
+            const double* qp = i > 0 ? st - 10 + 3 : nullptr;
+            const double* cp = i > 0 ? V.cumrot + (pb - 1) * 4 : nullptr;
+            const double* qn = i < n - 1 ? st + 10 + 3 : nullptr;
+            double f, qg[3], Hd[9], Hu[9], Hl[9];
+            attitude_term(qp, cp, st + 3, V.cumrot + pb * 4, qn, f, qg, Hd, Hu, Hl);
+            V.fatt[pb] = f;
+            if (i < n - 1) s_att = fabs(f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) V.qgrad[pb * 3 + k] = qg[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                V.Hd[pb * 9 + k] = Hd[k];
+                V.Hu[pb * 9 + k] = Hu[k];
+                V.Hl[pb * 9 + k] = Hl[k];
+            }
+        } else if (V.reg) {         // sum |r_prior| at the input states (BA_filtering.py:163)
+            double r6[6];
+            prior_residual(V.prior_H + pb * 36, V.prior_x + pb * 6, st, r6);
+            s_pri = fabs(r6[0]) + fabs(r6[1]) + fabs(r6[2]) + fabs(r6[3]) + fabs(r6[4]) + fabs(r6[5]);
+        }
+    }
+    if (half == 0) slot[lp * 3 + 1] = s_att;
+    else { slot[lp * 3 + 0] = s_orb; slot[lp * 3 + 2] = s_pri; }
+    __syncthreads();
+    // the sums of dynamics_block: 32 poses per partial, 8 slots per pose (slot 0 the orbit residual, 6 the attitude
+    // residual, 7 the prior), a butterfly over the 64 slots of 8 poses, then those four in sequence
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int vwave = wv * 4 + q;
+        const int pl = vwave * 8 + (lane >> 3), c = lane & 7;
+        const double a = c == 0 ? slot[pl * 3] : (c == 6 ? slot[pl * 3 + 1] : 0.0);
+        const double sa = wave_sum(a);
+        if (lane == 0) vw[0][vwave] = sa;
+        if (V.reg) {
+            const double sb2 = wave_sum(c == 7 ? slot[pl * 3 + 2] : 0.0);
+            if (lane == 0) vw[1][vwave] = sb2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int vb = blockIdx.x * 4 + threadIdx.x;
+        if (vb < V.nblk_pred) {
+            double tp = 0.0, tq = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { tp += vw[0][threadIdx.x * 4 + k]; tq += vw[1][threadIdx.x * 4 + k]; }
+            V.part_pred[(size_t)w * V.nblk_pred + vb] = tp;
+            if (V.reg) V.part_prior[(size_t)w * V.nblk_pred + vb] = tq;
+        }
+    }
+}
+
 // Block-tridiagonal assembly (BA_filtering.py:40-48): 3 x 81 band entries + 9 right-hand-side entries per pose.
 // A block of 256 threads takes kAsmPoses consecutive poses (4 for a few windows: more blocks, shorter; 16 when
 // batched windows fill the chip anyway: the decode of an entry and the halo slot are amortised over more poses): the per-pose inputs (141 doubles each, plus the
@@ -104,6 +203,10 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
 }
 
 void launch_dynamics(const DevView& V, hipStream_t s) {
+    if (V.W >= 16) {
+        hipLaunchKernelGGL(k_dynamics_pair, dim3((V.n_max + 127) / 128, V.W), dim3(256), 0, s, V);
+        return;
+    }
     const int nb = (V.n_max * kDynLanes + 255) / 256;
     hipLaunchKernelGGL(k_dynamics, dim3(nb, V.W), dim3(256), 0, s, V);
 }

@@ -209,6 +209,63 @@ VBA_HD void propagate_gap(double* x, double* t, int steps, int hop) {
     if (rem) rk4_step<TANGENT>(x, t, (double)rem);
 }
 
+// The same step carrying NT tangents in one thread (batched windows: two lanes per pose with three tangents each instead
+// of six lanes with one -- the base trajectory is integrated twice per pose instead of six times).  Same operations per
+// element in the same order as rk4_step: the stage derivatives are added into the weighted sum as they appear instead
+// of being kept (k1 + 2 k2 + 2 k3 + k4 is evaluated left to right either way), which keeps 3 x 18 instead of 3 x 42
+// doubles of tangent state live.
+template <int NT>
+VBA_HD void rk4_step_multi(double* x /*[6]*/, double (*t)[6], double h) {
+    double xs[6], ax[6], ts[NT][6], at[NT][6], k[6], d[NT][6];
+    // stage 1 at (x, t)
+    for (int i = 0; i < 3; ++i) k[i] = x[3 + i];
+    for (int j = 0; j < NT; ++j) {
+        for (int i = 0; i < 3; ++i) d[j][i] = t[j][3 + i];
+        accel_jvp(x, t[j], k + 3, d[j] + 3, true);
+    }
+    for (int i = 0; i < 6; ++i) { ax[i] = k[i]; xs[i] = x[i] + 0.5 * h * k[i]; }
+    for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < 6; ++i) { at[j][i] = d[j][i]; ts[j][i] = t[j][i] + 0.5 * h * d[j][i]; }
+    // stage 2
+    for (int i = 0; i < 3; ++i) k[i] = xs[3 + i];
+    for (int j = 0; j < NT; ++j) {
+        for (int i = 0; i < 3; ++i) d[j][i] = ts[j][3 + i];
+        accel_jvp(xs, ts[j], k + 3, d[j] + 3, true);
+    }
+    for (int i = 0; i < 6; ++i) { ax[i] = ax[i] + 2 * k[i]; xs[i] = x[i] + 0.5 * h * k[i]; }
+    for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < 6; ++i) { at[j][i] = at[j][i] + 2 * d[j][i]; ts[j][i] = t[j][i] + 0.5 * h * d[j][i]; }
+    // stage 3
+    for (int i = 0; i < 3; ++i) k[i] = xs[3 + i];
+    for (int j = 0; j < NT; ++j) {
+        for (int i = 0; i < 3; ++i) d[j][i] = ts[j][3 + i];
+        accel_jvp(xs, ts[j], k + 3, d[j] + 3, true);
+    }
+    for (int i = 0; i < 6; ++i) { ax[i] = ax[i] + 2 * k[i]; xs[i] = x[i] + h * k[i]; }
+    for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < 6; ++i) { at[j][i] = at[j][i] + 2 * d[j][i]; ts[j][i] = t[j][i] + h * d[j][i]; }
+    // stage 4
+    for (int i = 0; i < 3; ++i) k[i] = xs[3 + i];
+    for (int j = 0; j < NT; ++j) {
+        for (int i = 0; i < 3; ++i) d[j][i] = ts[j][3 + i];
+        accel_jvp(xs, ts[j], k + 3, d[j] + 3, true);
+    }
+    for (int i = 0; i < 6; ++i) x[i] = x[i] + (h / 6.0) * (ax[i] + k[i]);
+    for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < 6; ++i) t[j][i] = t[j][i] + (h / 6.0) * (at[j][i] + d[j][i]);
+}
+
+template <int NT>
+VBA_HD void propagate_gap_multi(double* x, double (*t)[6], int steps, int hop) {
+    if (!hop) {
+        for (int q = 0; q < steps; ++q) rk4_step_multi<NT>(x, t, 1.0);
+        return;
+    }
+    const int nfull = steps / 100, rem = steps % 100;
+    for (int q = 0; q < nfull; ++q) rk4_step_multi<NT>(x, t, 100.0);
+    if (rem) rk4_step_multi<NT>(x, t, (double)rem);
+}
+
 // ------------------------------------------------------------------------------------------------ attitude
 VBA_HD void quat_mul(const double* a, const double* b, double* o) {   // BA_utils.py:992-1000
     const double x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3];
