@@ -656,7 +656,8 @@ struct CallSpec {
 struct CallCtx {
     DevView V;
     bool fuse_assemble = false;     // first trial's landmark-only solve rides in k_assemble<true> (batched windows)
-    bool assembled = false;         // bands / rhs are in memory
+    bool assembled = false;         // an assembly kernel ran (profile bookkeeping)
+    bool bands_ready = false;       // bands / rhs are in memory (the fused landmark-only assembly does not write them)
 };
 
 void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
@@ -741,10 +742,12 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
     mark(5);
     C.fuse_assemble = init && h->pivot_mode == 0 && V.fused_trial != 1;
     C.assembled = false;
+    C.bands_ready = false;
     const bool need_bands = init ? V.fused_trial != 1 : !solve_forms_blocks(V);
     if (need_bands) {
         launch_assemble(V, C.fuse_assemble, s);
         C.assembled = true;
+        C.bands_ready = !C.fuse_assemble;
     }
     mark(6);
     return VBA_OK;
@@ -757,17 +760,18 @@ void enqueue_trial(vba_handle h, CallCtx& C, const CallSpec& c, bool first, hipE
     hipStream_t s = h->stream;
     const bool init = c.initialize != 0;
     const int redo_all = V.redo;
+    const bool pivoted_round = V.pivot != 0;
+    // landmark-only phase: does a solve kernel run, i.e. does anything read the diagonal blocks from memory?  Not in the
+    // first trial when the trial kernel or the fused assembly formed the step -- unless some window fell back to the
+    // pivoted kernels
+    const bool init_solve = init && (V.fused_trial == 1 ? pivoted_round : !(first && C.fuse_assemble));
+    if (init_solve && !C.bands_ready) {
+        launch_assemble(V, 0, s);
+        C.assembled = C.bands_ready = true;
+    }
     if (solve_redo >= 0) V.redo = solve_redo;       // which windows the solve kernels of this round take (see step_impl)
     if (init) {
-        const bool pivoted_round = V.pivot != 0;
-        if (V.fused_trial == 1) {
-            if (pivoted_round) {        // some window fell back to the pivoted kernels, which read the diagonal blocks from memory
-                if (!C.assembled) { launch_assemble(V, 0, s); C.assembled = true; }
-                launch_solve(V, 1, s);
-            }
-        } else if (!(first && C.fuse_assemble)) {
-            launch_solve(V, 1, s);
-        }
+        if (init_solve) launch_solve(V, 1, s);
     } else {
         launch_solve(V, 0, s);
     }
@@ -982,6 +986,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             // the front of this call has run (for the windows that reached it); what is on the device of it:
             C.fuse_assemble = q.initialize && h->pivot_mode == 0 && V.fused_trial != 1;
             C.assembled = q.initialize ? V.fused_trial != 1 : !solve_forms_blocks(V);
+            C.bands_ready = C.assembled && !C.fuse_assemble;
             auto at_call = [&](int w) { return stall_at[w] == sc_call && head(h, w)->call_idx == sc_call; };
             bool any_miss = false;
             for (int w = 0; w < h->W; ++w) any_miss = any_miss || (at_call(w) && (head(h, w)->flags & 32u));

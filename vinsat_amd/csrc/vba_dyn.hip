@@ -162,6 +162,13 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
             const AsmRow R = asm_row<REG>(me, pv, i, n, dyn, prm.sigma, inv_wmax);
             // landmark-only phase: the off-diagonal blocks are zero and nobody reads them (k_solve_blockdiag takes
             // the diagonal block only; vba_debug_fetch reports them as zeros)
+            // FUSE: the step is formed below from the staged inputs, so the diagonal blocks and right-hand sides are not
+            // written at all (872 -> 152 bytes per pose); a later trial of the call -- the rare one -- has the host run the
+            // plain assembly first.  Only the last pose's diagonal block leaves (last_hessian).
+            if (FUSE) {
+                if (which == 1 && !is_rhs && i == n - 1) V.lastD[(size_t)w * 81 + (t - 81)] = band_entry(R, which, a, b);
+                continue;
+            }
             if (is_rhs) V.rhs[(sb + i) * 9 + a] = rhs_entry(R, a);
             else if (dyn || which == 1) {
                 const double e = band_entry(R, which, a, b);
