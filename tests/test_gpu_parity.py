@@ -1303,3 +1303,44 @@ def test_torch_cuda_initialises_after_the_library_has_used_the_gpu():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == "0"
+
+
+@pytest.mark.parametrize("reg", [False, True])
+def test_batched_walk_forming_its_own_blocks_gives_the_bits_of_the_assembled_path(c2, reg):
+    """vba_set_fusion bit 2 (default for 16 windows and more): in the full phase the sequential solve forms each block
+    from the per-pose inputs itself and the assembly launch is gone.  Same entries, same elimination: 16 windows -- the
+    golden one, one that rejects trials and exhausts lamda, one whose blocks send the unpivoted path to the pivoted
+    kernels, perturbed copies -- through the chained schedule, bit for bit against the assembled path; plain BA and
+    BA_reg (prior staged with the inputs)."""
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    gr = load_golden("reg_c2")
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    W = 16
+    rng = np.random.default_rng(3)
+    confs = [inp["conf"], np.full_like(inp["conf"], 3.0), np.where(inp["ii"] % 3 == 0, -0.5, inp["conf"])]
+    confs += [inp["conf"] * rng.uniform(0.5, 1.5, m) for _ in range(W - 3)]
+    iters, inits = list(range(20)), [k < 10 for k in range(20)]
+    outs, dbg = [], []
+    for mask in (1, 5):
+        e = BAEngine(n, m, windows=W)
+        e.set_fusion(mask)
+        for k in range(W):
+            e.upload_observations(inp["xyz"], inp["uv"], confs[k], inp["ii"], n, window=k)
+            e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"], window=k)
+            if reg:
+                e.upload_prior(gr["states_prior"][0], gr["hessian_state_t"][0] * (1.0 + 0.1 * k), window=k)
+            e.set_states(g["states0"][0], 1e-4, window=k)
+        e.set_prior(reg)
+        e.run_schedule(iters, inits)
+        outs.append([e.get_states(window=k) for k in range(W)])
+        dbg.append((e.debug("bands", window=0), e.debug("dpose", window=0)))
+        e.close()
+    for k in range(W):
+        a, b = outs[0][k], outs[1][k]
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[3] == b[3] and a[4] == b[4], k
+        assert np.array_equal(a[2], b[2]), k            # last_hessian: written by the walk itself
+    assert np.array_equal(dbg[0][0], dbg[1][0]) and np.array_equal(dbg[0][1], dbg[1][1])
+    if not reg:
+        assert rel_err(outs[1][0][0], g["states_out_19"][0]) < 1e-7
+        assert outs[1][1][3] > 1                         # the rejection window really rejected

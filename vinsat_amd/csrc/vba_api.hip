@@ -409,7 +409,7 @@ int vba_set_key_carry(vba_handle h, int on) {
 
 int vba_set_fusion(vba_handle h, int mask) {
     if (!h) return fail(VBA_EINVAL, "null handle");
-    if (mask < 0 || mask > 3) return fail(VBA_EINVAL, "mask must be in [0, 3]");
+    if (mask < 0 || mask > 7) return fail(VBA_EINVAL, "mask must be in [0, 7]");
     h->fusion = mask;
     return VBA_OK;
 }
@@ -692,6 +692,7 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
         V.nblk_dyn = (V.n_max - 1 + 14) / 15;
     }
     V.fuse_blocks = (h->fusion & 2) ? 1 : 0;
+    V.fuse_walk = ((h->fusion & 4) && h->W >= 16) ? 1 : 0;
 }
 
 // the kernels in front of the first LM trial; ev (profiled variant): events that bracket the kernel classes
@@ -1233,6 +1234,7 @@ static void sharded_view(vba_handle h, DevView& V) {
     c.iter = h->last_iter; c.initialize = h->last_init; c.call = -1; c.par = h->par;
     view_for_call(h, V, c);
     V.lat = 0;
+    V.fuse_walk = 0;
     V.fused_trial = 0;
     V.nblk_dyn = h->V.nblk_dyn;
     V.m_total = h->V.m_total;

@@ -10,6 +10,30 @@ namespace vba {
 constexpr int kAsmBase = 21 + 6 + 36 + 6 + 3 + 27;    // Hraw, braw, Phi, rorb, qgrad, Hd|Hu|Hl
 constexpr int kAsmPrior = 36 + 6;                     // BA_reg: prior H, prior r
 
+// input q (0 .. kAsmBase [+ kAsmPrior]) of pose pb = w * n_max + i, as the assembly stages it
+template <bool REG>
+__device__ __forceinline__ double asm_input(const DevView& V, size_t pb, int q, bool dyn) {
+    if (q < 21) return V.Hraw[pb * 21 + q];
+    if (q < 27) return V.braw[pb * 6 + (q - 21)];
+    if (!dyn) return 0.0;
+    if (q < 63) return V.Phi[pb * 36 + (q - 27)];
+    if (q < 69) return V.rorb[pb * 6 + (q - 63)];
+    if (q < 72) return V.qgrad[pb * 3 + (q - 69)];
+    if (q < 81) return V.Hd[pb * 9 + (q - 72)];
+    if (q < 90) return V.Hu[pb * 9 + (q - 81)];
+    if (q < 99) return V.Hl[pb * 9 + (q - 90)];
+    if (REG) {
+        if (q < 135) return V.prior_H[pb * 36 + (q - 99)];
+        // one component of r = H [p_prior - p ; v_prior - v]
+        const double* Hr = V.prior_H + pb * 36 + (q - 135) * 6;
+        const double* xp = V.prior_x + pb * 6;
+        const double* st = V.states + pb * 10;
+        return Hr[0] * (xp[0] - st[0]) + Hr[1] * (xp[1] - st[1]) + Hr[2] * (xp[2] - st[2]) +
+               Hr[3] * (xp[3] - st[7]) + Hr[4] * (xp[4] - st[8]) + Hr[5] * (xp[5] - st[9]);
+    }
+    return 0.0;
+}
+
 // slots [0, slots) of `in` receive the inputs of poses first .. first + slots - 1 (zeros outside [0, n)); every thread
 // of the block takes part (stride = block size); the caller synchronises
 template <bool REG>
@@ -20,31 +44,7 @@ __device__ __forceinline__ void asm_stage(const DevView& V, int w, int n, bool d
     for (int e = tid; e < slots * kAsmIn; e += nthreads) {
         const int slot = e / kAsmIn, q = e % kAsmIn;
         const int i = first + slot;
-        double v = 0.0;
-        if (i >= 0 && i < n) {
-            const size_t pb = sb + i;
-            if (q < 21) v = V.Hraw[pb * 21 + q];
-            else if (q < 27) v = V.braw[pb * 6 + (q - 21)];
-            else if (dyn) {
-                if (q < 63) v = V.Phi[pb * 36 + (q - 27)];
-                else if (q < 69) v = V.rorb[pb * 6 + (q - 63)];
-                else if (q < 72) v = V.qgrad[pb * 3 + (q - 69)];
-                else if (q < 81) v = V.Hd[pb * 9 + (q - 72)];
-                else if (q < 90) v = V.Hu[pb * 9 + (q - 81)];
-                else if (q < 99) v = V.Hl[pb * 9 + (q - 90)];
-                else if (REG) {
-                    if (q < 135) v = V.prior_H[pb * 36 + (q - 99)];
-                    else {      // one component of r = H [p_prior - p ; v_prior - v]
-                        const double* Hr = V.prior_H + pb * 36 + (q - 135) * 6;
-                        const double* xp = V.prior_x + pb * 6;
-                        const double* st = V.states + pb * 10;
-                        v = Hr[0] * (xp[0] - st[0]) + Hr[1] * (xp[1] - st[1]) + Hr[2] * (xp[2] - st[2]) +
-                            Hr[3] * (xp[3] - st[7]) + Hr[4] * (xp[4] - st[8]) + Hr[5] * (xp[5] - st[9]);
-                    }
-                }
-            }
-        }
-        in[e] = v;
+        in[e] = (i >= 0 && i < n) ? asm_input<REG>(V, sb + i, q, dyn) : 0.0;
     }
 }
 

@@ -195,6 +195,16 @@ struct BandSource {
     __device__ double operator()(int i, int e) const { return e < 243 ? bands[(size_t)i * 243 + e] : rhs[(size_t)i * 9 + (e - 243)]; }
 };
 
+// A source may stage its own inputs beside the walk (RawSource): prefetch(i) starts the loads of what block i needs,
+// commit(i) puts them where operator() finds them; the barrier of the walk's step orders the two.  No-ops otherwise.
+template <class S> __device__ __forceinline__ auto src_prefetch(const S& s, int i, int) -> decltype(s.prefetch(i), void()) { s.prefetch(i); }
+template <class S> __device__ __forceinline__ void src_prefetch(const S&, int, long) {}
+template <class S> __device__ __forceinline__ auto src_commit(const S& s, int i, int) -> decltype(s.commit(i), void()) { s.commit(i); }
+template <class S> __device__ __forceinline__ void src_commit(const S&, int, long) {}
+// a source that COMPUTES its entries takes them behind the elimination step (nothing of it is live across the step)
+template <class S> constexpr auto src_late(int) -> decltype(S::kLateFetch) { return S::kLateFetch; }
+template <class S> constexpr bool src_late(long) { return false; }
+
 #ifdef VBA_STAMPS
 #define VBA_STAMP(k) do { if (stamps && lane == 0) stamps[k] = clock64(); } while (0)
 #else
@@ -238,7 +248,9 @@ __device__ __forceinline__ void chain_solve(const Src& src, int n, double lam32,
     __syncthreads();
     for (int i = 0; i < n; ++i) {
         const int buf = i & 1;
-        if (i + 1 < n) fetch(i + 1);
+        constexpr bool late = src_late<Src>(0);
+        src_prefetch(src, i + 2, 0);
+        if (!late && i + 1 < n) fetch(i + 1);
         double base[9];
         if (buf == 0) {
             load_base(blk[0], 0, base);
@@ -257,7 +269,16 @@ __device__ __forceinline__ void chain_solve(const Src& src, int n, double lam32,
 #pragma unroll
             for (int r = 0; r < 9; ++r) z[r] = a[r];
         }
-        if (i + 1 < n) stash(buf ^ 1);
+        if (late) {
+            if (i + 1 < n) {    // one entry at a time, straight into the other buffer: keeps the register count of the plain walk
+#pragma unroll 1
+                for (int q = 0; q < 4; ++q) {
+                    const int e = lane + 64 * q;
+                    blk[buf ^ 1][e] = e < 252 ? src(i + 1, e) : 0.0;
+                }
+            }
+        } else if (i + 1 < n) stash(buf ^ 1);
+        src_commit(src, i + 2, 0);
         __syncthreads();
     }
     __threadfence_block();
@@ -325,6 +346,77 @@ __global__ __launch_bounds__(64) void k_solve(DevView V) {
     bool badp = false;
     const BandSource src{V.bands + sb * 243, V.rhs + sb * 9};
     chain_solve<PIVOT, true>(src, n, lam32, V.Xs + sb * 81, V.zs + sb * 9, V.dpose + sb * 9, blk, lane, badp);
+    report_pivot<PIVOT>(badp, sc, lane, V.par);
+    const bool bad = retract_range(V, sb, n, lane, 64);
+    const unsigned long long anybad = __ballot(bad);
+    if (lane == 0 && anybad) atomicOr(&sc.fl[V.par], 2u);
+}
+
+// Batched windows, full phase (vba_set_fusion bit 2): the walk forms the blocks itself.  The assembly kernel wrote 2 kB
+// per pose that this kernel read straight back -- 8 GB per call at 4096 windows of 500 poses; here the wave keeps the
+// inputs of three consecutive poses (141 doubles each, BA_reg 183) in an LDS ring, loads the next pose's while it
+// eliminates, and every lane forms the four entries of the next block it used to load.  Same band_entry / rhs_entry,
+// so the same system to the bit; ~200 more instructions per block step in a kernel that is issue-bound at four waves
+// per SIMD, against a whole launch and its traffic.
+template <bool REG>
+struct RawSource {
+    static constexpr int kIn = kAsmBase + (REG ? kAsmPrior : 0);
+    static constexpr int kPer = (kIn + 63) / 64;
+    static constexpr bool kLateFetch = true;
+    const DevView& V;
+    size_t sb;
+    int n, lane;
+    double sigma, inv_wmax;
+    double* ring;               // [3][kIn]: pose i lives in slot i % 3
+    mutable double hold[kPer];
+    __device__ void prefetch(int i) const {
+        if (i >= n) return;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int q = lane + 64 * k;
+            hold[k] = q < kIn ? asm_input<REG>(V, sb + i, q, true) : 0.0;
+        }
+    }
+    __device__ void commit(int i) const {
+        if (i >= n) return;
+        double* slot = ring + (i % 3) * kIn;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int q = lane + 64 * k;
+            if (q < kIn) slot[q] = hold[k];
+        }
+    }
+    __device__ double operator()(int i, int e) const {
+        const AsmRow R = asm_row<REG>(ring + (i % 3) * kIn, ring + ((i + 2) % 3) * kIn, i, n, true, sigma, inv_wmax);
+        if (e >= 243) return rhs_entry(R, e - 243);
+        return band_entry(R, e / 81, (e % 81) / 9, e % 9);
+    }
+};
+
+template <bool PIVOT, bool REG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_solve_forming(DevView V) {
+    __shared__ double blk[2][256];
+    __shared__ double ring[3 * RawSource<REG>::kIn];
+    const int w = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n = V.n[w];
+    const int lane = threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const double lam32 = (double)(float)sc.lam[V.par];      // torch.eye() is float32 (BA_filtering.py:54)
+    if (lane == 0) {
+        sc.lam32 = lam32;
+        if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
+    }
+    bool badp = false;
+    const RawSource<REG> src{V, sb, n, lane, V.prm.sigma, 1.0 / bits_f64(sc.wmax_bits), ring, {}};
+    src.prefetch(0); src.commit(0);
+    src.prefetch(1); src.commit(1);
+    __syncthreads();
+    chain_solve<PIVOT, true>(src, n, lam32, V.Xs + sb * 81, V.zs + sb * 9, V.dpose + sb * 9, blk, lane, badp);
+    // the ring still holds poses n-3 .. n-1: the last diagonal block leaves for last_hessian (BA_filtering.py:97)
+    for (int e = 81 + lane; e < 162; e += 64) V.lastD[(size_t)w * 81 + (e - 81)] = src(n - 1, e);
     report_pivot<PIVOT>(badp, sc, lane, V.par);
     const bool bad = retract_range(V, sb, n, lane, 64);
     const unsigned long long anybad = __ballot(bad);
@@ -1311,7 +1403,11 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
 
 // latency mode with a partitioned chain whose chunk (blocks + staged inputs + elimination scratch) fits the LDS of a CU:
 // the chunk kernel forms its blocks itself and k_assemble is not launched (vba_api.hip asks the same question)
-bool solve_forms_blocks(const DevView& V) { return V.lat && V.fuse_blocks && !V.prm.initialize && V.chunk >= 2 && V.chunk <= kFusedChunkMax; }
+// ... and the sequential walk of the batched mode forms them pose by pose (vba_set_fusion bit 2)
+static bool walk_forms_blocks(const DevView& V) { return !V.lat && V.fuse_walk && !V.prm.initialize && V.chunk <= 0 && !V.pack; }
+bool solve_forms_blocks(const DevView& V) {
+    return walk_forms_blocks(V) || (V.lat && V.fuse_blocks && !V.prm.initialize && V.chunk >= 2 && V.chunk <= kFusedChunkMax);
+}
 
 template <bool PIVOT>
 static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s) {
@@ -1322,7 +1418,10 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
     }
     if (V.chunk <= 0) {
         if (V.pack) hipLaunchKernelGGL(k_solve_packed<PIVOT>, dim3((V.W + kPack - 1) / kPack), dim3(64), 0, s, V);   // equal pose counts: three windows per wavefront
-        else hipLaunchKernelGGL(k_solve<PIVOT>, dim3(V.W), dim3(64), 0, s, V);
+        else if (walk_forms_blocks(V)) {
+            if (V.reg) hipLaunchKernelGGL((k_solve_forming<PIVOT, true>), dim3(V.W), dim3(64), 0, s, V);
+            else hipLaunchKernelGGL((k_solve_forming<PIVOT, false>), dim3(V.W), dim3(64), 0, s, V);
+        } else hipLaunchKernelGGL(k_solve<PIVOT>, dim3(V.W), dim3(64), 0, s, V);
         return;
     }
     const int cs = V.chunk, cs2 = V.chunk2;
