@@ -148,6 +148,12 @@ int vba_warm_select_misses(vba_handle h, int* count);
  * and stays off.  All masks are covered by the parity tests. */
 int vba_set_fusion(vba_handle h, int mask);
 
+/* Partitioned solve: waves per chunk.  2 (default): every chunk of 4 or more blocks is eliminated from both ends by two
+ * waves that meet at its middle block -- half the dependent block steps of the kernel that is the longest of a
+ * full-phase call in latency mode.  1: one wave walks the chunk left to right.  The two orders round differently
+ * (~1e-9 relative on the step, the order of the difference to the reference's dense LU); each is deterministic. */
+int vba_set_chunk_waves(vba_handle h, int waves);
+
 /* Row pivoting inside the 9x9 diagonal blocks.  always == 0 (default): the blocks are eliminated without row
  * exchanges (the damped normal equations are positive definite up to a ~1e-6 non-symmetric term) while every pivot
  * is checked against the diagonal entry it started from; a failed check repeats that solve with pivoting, so the

@@ -1344,3 +1344,35 @@ def test_batched_walk_forming_its_own_blocks_gives_the_bits_of_the_assembled_pat
     if not reg:
         assert rel_err(outs[1][0][0], g["states_out_19"][0]) < 1e-7
         assert outs[1][1][3] > 1                         # the rejection window really rejected
+
+
+@pytest.mark.parametrize("chunk", [4, 5, 8, 13])
+@pytest.mark.parametrize("pivot", [False, True])
+def test_two_sided_chunk_elimination_vs_one_wave(c2, chunk, pivot):
+    """vba_set_chunk_waves: chunks eliminated from both ends by two waves that meet in the middle (default) against one
+    wave walking them left to right -- every chunk length the sizes produce (even, odd, the short last chunk that falls
+    back to one wave), unpivoted and pivoted blocks, plain BA and the rejection window.  Same system, another
+    elimination order: the step agrees to rounding, trial counts and lamda exactly, and each order repeats its own bits."""
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    iters, inits = list(range(20)), [k < 10 for k in range(20)]
+    for conf in (inp["conf"], np.full_like(inp["conf"], 3.0)):
+        outs, steps = [], []
+        for waves in (1, 2, 2):
+            e = BAEngine(n, m)
+            e.set_solver(chunk, -1)
+            e.set_pivoting(pivot)
+            e.set_chunk_waves(waves)
+            e.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
+            e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+            e.iterate(10, False, float(g["lamda_in"][10]), g["states_out_9"][0])
+            steps.append(e.debug("dpose"))
+            outs.append(_schedule_states(e, g["states0"][0], iters, inits, True))
+            e.close()
+        assert rel_err(steps[1], steps[0]) < (2e-7 if pivot else 3e-8)     # row exchanges: each order is ~1e-7 from the dense LU
+        assert np.array_equal(steps[1], steps[2]) and np.array_equal(outs[1][0], outs[2][0])
+        assert outs[0][3] == outs[1][3] and outs[0][1] == outs[1][1] and outs[0][4] == outs[1][4]
+        assert rel_err(outs[1][0], outs[0][0]) < 1e-7
+        if conf is inp["conf"]:
+            assert rel_err(steps[1], g["dpose_10"][0].reshape(n, 9)) < (DPOSE_TOL_PIVOTED if pivot else DPOSE_TOL)

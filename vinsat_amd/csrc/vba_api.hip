@@ -90,6 +90,7 @@ struct vba_context {
     int no_pack = 0;                        // diagnostic: force one window per wavefront in the sequential driver
     int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
+    int chunk_waves = 2;                    // vba_set_chunk_waves
     int fusion = 1;                         // vba_set_fusion (default: the trial kernel forms the step)
     int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
@@ -414,6 +415,13 @@ int vba_set_fusion(vba_handle h, int mask) {
     return VBA_OK;
 }
 
+int vba_set_chunk_waves(vba_handle h, int waves) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (waves != 1 && waves != 2) return fail(VBA_EINVAL, "waves must be 1 or 2");
+    h->chunk_waves = waves;
+    return VBA_OK;
+}
+
 int vba_set_warm_select(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     h->warm_enabled = on == 2 ? 2 : (on != 0);
@@ -692,6 +700,7 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
         V.nblk_dyn = (V.n_max - 1 + 14) / 15;
     }
     V.fuse_blocks = (h->fusion & 2) ? 1 : 0;
+    V.chunk_waves = h->chunk_waves;
     V.fuse_walk = ((h->fusion & 4) && h->W >= 16) ? 1 : 0;
 }
 

@@ -105,6 +105,7 @@ struct DevView {
     int redo;                       // 1: this launch repeats the call for the windows whose warm select missed (sc.miss), others skip
     int lat;                        // latency mode (few windows): fused kernels, see vba_api.hip
     int fuse_blocks;                // latency mode: the chunk elimination forms the blocks of its chunk itself (vba_set_fusion bit 1)
+    int chunk_waves;                // partitioned solve: waves per chunk (2: eliminated from both ends, vba_set_chunk_waves)
     int fuse_walk;                  // batched mode: the sequential walk forms the blocks itself (vba_set_fusion bit 2)
     int warm_shift;                 // log2 of the bit-pattern width of a warm bin
     int warm_force_miss;            // test knob: every warm select reports a miss (exercises the repeat with the exact digits)

@@ -736,6 +736,224 @@ __device__ __forceinline__ void chunk_eliminate(const Src& src, int n, int s, in
     }
 }
 
+// The same elimination by TWO waves per chunk that meet in the middle.  The elimination of a chunk is a chain of dependent
+// block steps (~2 us each on a single wave) and in latency mode that chain IS the time of the kernel: wave 0 eliminates
+// blocks a .. m-1 left to right, wave 1 blocks b .. m+1 right to left -- the same step on the mirrored chain (sub and super
+// diagonal swap roles; the coupling to the right separator enters at its first block the way the left one enters wave 0's)
+// -- then wave 0 solves block m with both neighbours folded in,
+//     (D_m - L_m X_{m-1} - U_m X'_{m+1}) x_m = g_m - L_m z_{m-1} - U_m z'_{m+1}      (19 right-hand sides),
+// and both waves substitute outwards from x_m on the matrix cores.  Half the dependent steps (7 interior blocks: 3 + 1
+// + the two substitutions side by side instead of 7 + 6).  Chunks with fewer than 3 interior blocks take the one-wave
+// path.  tid: 0 .. 127.
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__host__ __device__ constexpr int twosided_half(int s) { return (s + 1) / 2; }
+__host__ __device__ constexpr int twosided_region(int s) { return 512 + twosided_half(s) * (81 + 171); }
+__host__ __device__ constexpr int twosided_lds_doubles(int s) {
+    const int two = 2 * twosided_region(s) + 162 + 256 + 171, one = 512 + s * 252 + 162;
+    return two > one ? two : one;
+}
+
+template <bool PIVOT, bool SPARSE_L, class Src>
+__device__ __forceinline__ void chunk_eliminate_twosided(const Src& src, int n, int s, int c, double lam32, double* csol, double* cL,
+                                                         double* cR, double* smem, int tid, bool& zero_pivot) {
+    int a0, b0;
+    bool has_sep;
+    chunk_range(c, s, n, a0, b0, has_sep);
+    const int len = b0 - a0 + 1;
+    const int side = tid >> 6, lane = tid & 63;
+    if (len < 3) {      // (uniform over the workgroup) nothing to share: one wave, the other leaves
+        if (side == 0) chunk_eliminate<PIVOT, SPARSE_L>(src, n, s, c, lam32, csol, cL, cR, smem, lane, zero_pivot);
+        return;
+    }
+    const int lenL = len / 2, lenR = len - 1 - lenL, m = a0 + lenL;
+    const int lenS = side ? lenR : lenL;
+    const int hs = twosided_half(s), RS = twosided_region(s);
+    double* reg0 = smem;
+    double* reg1 = smem + RS;
+    double* reg = side ? reg1 : reg0;
+    double (*blk)[256] = reinterpret_cast<double (*)[256]>(reg);            // [2][256]
+    double* Xb = reg + 512;                                                  // [hs][81]
+    double* Zb = Xb + (size_t)hs * 81;                                       // [hs][19][9]
+    double* Cm = smem + 2 * (size_t)RS;                                      // [2][81]: L of the right separator, U of the left one
+    double* blkM = Cm + 162;                                                 // block m
+    double* xm = blkM + 256;                                                 // [19][9] its solution
+    // entry e of real block i as this side's sweep sees it
+    auto entry = [&](int i, int e) {
+        const int ee = side ? (e < 81 ? e + 162 : ((e >= 162 && e < 243) ? e - 162 : e)) : e;
+        return src(i, ee);
+    };
+    auto block_of = [&](int t) { return side ? b0 - t : a0 + t; };
+    for (int e = lane; e < 81; e += 64) {
+        if (side) Cm[e] = has_sep ? src(b0 + 1, e) : 0.0;
+        else Cm[81 + e] = c > 0 ? src(a0 - 1, 162 + e) : 0.0;
+    }
+    double mid[4] = {0.0, 0.0, 0.0, 0.0};
+    if (side == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q;
+            mid[q] = e < 252 ? src(m, e) : 0.0;
+        }
+    }
+    double a[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) a[j] = 0.0;
+    double pre[4];
+    auto fetch = [&](int t) {
+        const int i = block_of(t);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q;
+            pre[q] = e < 252 ? entry(i, e) : 0.0;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) blk[buf][lane + 64 * q] = pre[q];
+    };
+    // lanes as in chunk_eliminate: D/U groups in 0..17 (alternating), V = 18..26, W = 27..35, y = 36.  "V" is the coupling
+    // that enters at the sweep's FIRST block: the left separator for wave 0, the right one for wave 1 (columns swapped
+    // back when the results are stored); the W columns stay zero during the sweeps.
+    const bool isV = lane >= 18 && lane < 27, isW = lane >= 27 && lane < 36, isY = lane == 36;
+    const int zcol = isY ? 0 : (isV ? 1 + (lane - 18) : (isW ? 10 + (lane - 27) : 0));
+    auto load_base = [&](const double* b, int db, bool first, double (&base)[9]) {
+        const int ub = 9 - db;
+        const bool isD = lane >= db && lane < db + 9, isU = lane >= ub && lane < ub + 9;
+        const int cc = isD ? lane - db : (isU ? lane - ub : (isV ? lane - 18 : 0));
+        const bool ok = isD || isU || isY || (isV && first);
+        const int off = isD ? 81 + cc : (isU ? 162 + cc : (isY ? 243 : cc));
+        const int stride = isY ? 1 : 9;
+        const double* p = b + (ok ? off : 0);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = p[r * stride];
+            v = ok ? v : 0.0;
+            if (isD && r == cc) v += lam32;
+            base[r] = v;
+        }
+    };
+    fetch(0);
+    stash(0);
+    wave_sync_lds();
+    for (int t = 0; t < lenS; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < lenS) fetch(t + 1);
+        double base[9];
+        if (buf == 0) {
+            load_base(blk[0], 0, t == 0, base);
+            forward_step<0, 19, PIVOT, SPARSE_L>(t > 0 ? blk[0] : nullptr, base, a, lane, zero_pivot);
+        } else {
+            load_base(blk[1], 9, false, base);
+            forward_step<9, 19, PIVOT, SPARSE_L>(blk[1], base, a, lane, zero_pivot);
+        }
+        const int ub = buf == 0 ? 9 : 0;
+        if (lane >= ub && lane < ub + 9) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) Xb[(size_t)t * 81 + r * 9 + (lane - ub)] = a[r];
+        } else if (isV || isW || isY) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) Zb[((size_t)t * 19 + zcol) * 9 + r] = a[r];
+        }
+        if (t + 1 < lenS) stash(buf ^ 1);
+        wave_sync_lds();
+    }
+    if (side == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) blkM[lane + 64 * q] = mid[q];
+    }
+    __syncthreads();
+    // block m: both neighbours folded in, then the same Gauss-Jordan step on [M | 19 right-hand sides]
+    if (side == 0) {
+        const double* XL = reg0 + 512 + (size_t)(lenL - 1) * 81;
+        const double* ZL = reg0 + 512 + (size_t)hs * 81 + (size_t)(lenL - 1) * 171;
+        const double* XR = reg1 + 512 + (size_t)(lenR - 1) * 81;
+        const double* ZR = reg1 + 512 + (size_t)hs * 81 + (size_t)(lenR - 1) * 171;
+        const bool isD = lane < 9, isR = isV || isW || isY;
+        // column of the left / right sweep's results this lane folds in (wave 1 keeps the right coupling in ITS columns 1..9)
+        const int cl = isY ? 0 : (isV ? 1 + (lane - 18) : (isW ? 10 + (lane - 27) : 0));
+        const int cr = isY ? 0 : (isV ? 10 + (lane - 18) : (isW ? 1 + (lane - 27) : 0));
+        const double* pl = isD ? XL + lane : ZL + (size_t)cl * 9;
+        const double* pr = isD ? XR + lane : ZR + (size_t)cr * 9;
+        const int st = isD ? 9 : 1;
+        double base[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = 0.0;
+            if (isD) v = blkM[81 + r * 9 + lane] + (r == lane ? lam32 : 0.0);
+            else if (isY) v = blkM[243 + r];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const bool rot_r = (r >= 3 && r < 6), rot_j = (j >= 3 && j < 6);
+                if (!SPARSE_L || rot_r == rot_j) {
+                    v -= blkM[r * 9 + j] * pl[j * st];
+                    v -= blkM[162 + r * 9 + j] * pr[j * st];
+                }
+            }
+            base[r] = (isD || isR) ? v : 0.0;
+        }
+        forward_step<0, 19, PIVOT, SPARSE_L>(nullptr, base, a, lane, zero_pivot);
+        if (isR) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) xm[(size_t)zcol * 9 + r] = a[r];
+        }
+    }
+    __syncthreads();
+    // outward substitution on the matrix cores (see chunk_eliminate): x_t = Z_t - X_t x_{t+1}
+    const int lr = lane & 15, lk = lane >> 4;
+    auto colperm = [&](int col) { return side ? (col == 0 ? 0 : (col < 10 ? col + 9 : col - 9)) : col; };
+    auto load_cols = [&](const double* Z, int tile, bool perm) {
+        vf4 z;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lk + 4 * i, col = 16 * tile + lr;
+            const bool ok = row < 9 && col < 19;
+            const double v = Z[ok ? (size_t)(perm ? colperm(col) : col) * 9 + row : 0];
+            z[i] = ok ? v : 0.0;
+        }
+        return z;
+    };
+    auto mul_sub = [&](const double* M, double sign, vf4& acc0, vf4& acc1, const vf4& b0v, const vf4& b1v) {
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const int k = 4 * st + lk;
+            const bool ok = lr < 9 && k < 9;
+            const double mm = M[ok ? lr * 9 + k : 0];
+            const double am = ok ? sign * mm : 0.0;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b0v[st], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b1v[st], acc1, 0, 0, 0);
+        }
+    };
+    // the real column a value of this side's column `col` belongs to
+    auto store_cols = [&](double* dst, size_t col_stride, size_t row_stride, const vf4& v0, const vf4& v1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lk + 4 * i;
+            if (row < 9) {
+                dst[(size_t)colperm(lr) * col_stride + (size_t)row * row_stride] = v0[i];
+                if (lr < 3) dst[(size_t)colperm(16 + lr) * col_stride + (size_t)row * row_stride] = v1[i];
+            }
+        }
+    };
+    vf4 x0 = load_cols(xm, 0, true), x1 = load_cols(xm, 1, true);
+    if (side == 0) store_cols(csol + (size_t)m * 171, 9, 1, x0, x1);
+    for (int t = lenS - 1; t >= 0; --t) {
+        vf4 n0 = load_cols(Zb + (size_t)t * 171, 0, false), n1 = load_cols(Zb + (size_t)t * 171, 1, false);
+        mul_sub(Xb + (size_t)t * 81, -1.0, n0, n1, x0, x1);
+        x0 = n0;
+        x1 = n1;
+        store_cols(csol + (size_t)block_of(t) * 171, 9, 1, x0, x1);
+    }
+    // x is now the solution next to this side's separator: its contribution to that row of the reduced system
+    if (side == 0 ? c > 0 : has_sep) {
+        vf4 p0 = {0.0, 0.0, 0.0, 0.0}, p1 = {0.0, 0.0, 0.0, 0.0};
+        mul_sub(side ? Cm : Cm + 81, 1.0, p0, p1, x0, x1);
+        store_cols(side ? cL + (size_t)c * 171 : cR + (size_t)(c - 1) * 171, 1, 19, p0, p1);
+    }
+}
+
 // number of separators of a chain of n blocks cut into chunks of s
 __device__ __forceinline__ int n_separators(int n, int s) { return (n + s - 1) / s - 1; }
 
@@ -761,6 +979,29 @@ __global__ __launch_bounds__(64) void k_solve_chunks(DevView V, int s) {
     const BandSource src{V.bands + sb * 243, V.rhs + sb * 9};
     chunk_eliminate<PIVOT, true>(src, n, s, c, lam32, V.csol + sb * 171, V.cL + rb * 171, V.cR + rb * 171, smem, lane, bad);
     report_pivot<PIVOT>(bad, sc, lane, V.par);
+}
+
+template <bool PIVOT>
+__global__ __launch_bounds__(128) void k_solve_chunks_ts(DevView V, int s) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int w = blockIdx.y, c = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n = V.n[w];
+    if (c * s >= n) return;
+    const int tid = threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lam[V.par];
+    if (c == 0 && tid == 0) {
+        sc.lam32 = lam32;
+        if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
+    }
+    bool bad = false;
+    const BandSource src{V.bands + sb * 243, V.rhs + sb * 9};
+    chunk_eliminate_twosided<PIVOT, true>(src, n, s, c, lam32, V.csol + sb * 171, V.cL + rb * 171, V.cR + rb * 171, smem, tid, bad);
+    report_pivot<PIVOT>(bad, sc, tid & 63, V.par);
 }
 
 // Latency mode: the chunk's wave(s) build the blocks of the chunk themselves (no assembly launch, no round trip of the
@@ -1432,6 +1673,8 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
         const size_t ldsf = lds + ((size_t)(cs + 1) * 252 + (size_t)(cs + 2) * (kAsmBase + (reg ? kAsmPrior : 0))) * sizeof(double);
         if (reg) hipLaunchKernelGGL((k_solve_chunks_fused<PIVOT, true>), dim3(P, V.W), dim3(256), ldsf, s, V, cs);
         else hipLaunchKernelGGL((k_solve_chunks_fused<PIVOT, false>), dim3(P, V.W), dim3(256), ldsf, s, V, cs);
+    } else if (V.chunk_waves == 2 && cs >= 4) {
+        hipLaunchKernelGGL(k_solve_chunks_ts<PIVOT>, dim3(P, V.W), dim3(128), (size_t)twosided_lds_doubles(cs) * sizeof(double), s, V, cs);
     } else {
         hipLaunchKernelGGL(k_solve_chunks<PIVOT>, dim3(P, V.W), dim3(64), lds, s, V, cs);
     }
@@ -1465,6 +1708,7 @@ hipError_t configure_solver_device() {
         {reinterpret_cast<const void*>(k_solve_chunks_fused<false, false>), cap_f}, {reinterpret_cast<const void*>(k_solve_chunks_fused<true, false>), cap_f},
         {reinterpret_cast<const void*>(k_solve_chunks_fused<false, true>), cap_f}, {reinterpret_cast<const void*>(k_solve_chunks_fused<true, true>), cap_f},
         {reinterpret_cast<const void*>(k_solve_chunks<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks<true>), cap},
+        {reinterpret_cast<const void*>(k_solve_chunks_ts<false>), twosided_lds_doubles(60) * 8}, {reinterpret_cast<const void*>(k_solve_chunks_ts<true>), twosided_lds_doubles(60) * 8},
         {reinterpret_cast<const void*>(k_solve_chunks2<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks2<true>), cap},
         {reinterpret_cast<const void*>(k_solve_reduced_cr<false, false>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, false>), cap_cr},
         {reinterpret_cast<const void*>(k_solve_reduced_cr<false, true>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, true>), cap_cr}};

@@ -70,6 +70,10 @@ class BAEngine:
         """Latency-mode kernel fusion (bit 0: step inside the trial kernel, bit 1: blocks formed inside the chunk elimination)."""
         _lib.check(self.lib.vba_set_fusion(self.h, int(mask)), self.lib)
 
+    def set_chunk_waves(self, waves):
+        """Partitioned solve: 2 (default) = every chunk is eliminated from both ends by two waves, 1 = one wave."""
+        _lib.check(self.lib.vba_set_chunk_waves(self.h, int(waves)), self.lib)
+
     def set_warm_select(self, on):
         """True (default): carried keys are selected with one warm pass (and chained calls fold their accept test into it);
         False: exact digit passes and a decide launch per call."""
