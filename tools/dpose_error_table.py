@@ -19,9 +19,10 @@ from conftest import golden_inputs, load_golden  # noqa: E402
 from oracle import ba_oracle as O  # noqa: E402
 from vinsat_amd.engine import BAEngine  # noqa: E402
 
-VARIANTS = {"default (chunks + cyclic reduction)": (-1, None, False), "sequential (one wave)": (0, None, False),
-            "default, pivoted": (-1, None, True), "sequential, pivoted": (0, None, True), "chunk 7, one level": (7, 0, False),
-            "two-level 5/4": (5, 4, False), "cyclic 3, pivoted": (3, -1, True)}
+VARIANTS = {"default (two-sided chunks + cyclic reduction)": (-1, None, False, 2), "chunks walked by one wave": (-1, None, False, 1),
+            "sequential (one wave)": (0, None, False, 2), "default, pivoted": (-1, None, True, 2),
+            "one wave per chunk, pivoted": (-1, None, True, 1), "sequential, pivoted": (0, None, True, 2),
+            "chunk 7, one level": (7, 0, False, 2), "two-level 5/4": (5, 4, False, 2), "cyclic 3, pivoted": (3, -1, True, 2)}
 
 
 def rel(a, b):
@@ -35,13 +36,14 @@ def main():
         inp = golden_inputs(g)
         n, m = inp["K"].shape[0], inp["xyz"].shape[0]
         calls = [k for k in range(20) if f"dpose_{k}" in g]      # the device keeps the LAST trial's solution: compare with the reference's last
-        for name, (c1, c2, piv) in VARIANTS.items():
+        for name, (c1, c2, piv, waves) in VARIANTS.items():
             eng = BAEngine(n, m)
             if c2 is None:
                 eng.set_solver(c1)
             else:
                 eng.set_solver(c1, c2)
             eng.set_pivoting(piv)
+            eng.set_chunk_waves(waves)
             eng.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
             eng.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
             errs = {}
