@@ -137,11 +137,14 @@ int vba_set_key_carry(vba_handle h, int on);
 int vba_set_warm_select(vba_handle h, int on);
 int vba_warm_select_misses(vba_handle h, int* count);
 
-/* Kernel fusion of the latency mode (fewer than 16 windows per handle), a bit mask; same results to rounding.
+/* Kernel fusion, a bit mask (bits 0 and 1: latency mode, fewer than 16 windows per handle); same results to rounding.
  *   bit 0: the trial kernel forms the step of each pose itself (landmark-only phase: the 6x6 solve; full phase: the
  *          recovery of the partitioned solve) -- no recovery launch and, in the landmark-only phase, no assembly + solve launch;
  *   bit 1: the chunk elimination forms the blocks of its chunk in LDS itself -- no assembly launch in the full phase, the
  *          bands never go through memory.
+ *   bit 2: (16 windows and more) the sequential solve of the full phase forms each block from the per-pose inputs itself --
+ *          no assembly launch, the bands never go through memory.  Bit-exact; measured slower (the generic per-entry
+ *          evaluation costs more instructions than the launch it removes), off by default.
  * Default 1.  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
  * formed by 16 lanes together (formed redundantly by every thread it was 6 us SLOWER: instruction issue of a single wave
  * is the time in this mode); bit 1 gains nothing (the assembly costs the elimination's block what its own launch cost)
