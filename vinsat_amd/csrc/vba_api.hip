@@ -90,6 +90,7 @@ struct vba_context {
     int no_pack = 0;                        // diagnostic: force one window per wavefront in the sequential driver
     int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
+    int inline_select = 1;                  // latency mode: warm select inside the accumulation (bin buckets); vba_set_warm_select(h, 3) turns it off
     int chunk_waves = 2;                    // vba_set_chunk_waves
     int fusion = 1;                         // vba_set_fusion (default: the trial kernel forms the step)
     int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
@@ -190,10 +191,20 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     need(W * N * 10 * 8); need(W * N * 10 * 8);
     need(W * N * 4 * 8); need(W * N * 4 * 8); need(W * N * 4);
     const int nblk_pred = (int)((N * kDynLanes + 255) / 256);
-    need(W * nblk_pred * 8); need(W * nblk_pred * 8); need(W * 81 * 8);
+    need(W * 2 * nblk_pred * 8); need(W * 2 * nblk_pred * 8); need(W * 81 * 8);
     need(W * N * 36 * 8); need(W * N * 6 * 8);
     need(W * 2 * M * 8); need(W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * trial_stride * 8); need(W * nblk_obs * 8);
     need(W * kHistStride * 4);
+    // bin buckets of the carried keys (latency mode only): capacity ~6x the count of the densest warm bin -- the bin of the
+    // median holds ~0.13 % of the keys with 1/256-binade bins, half of that with 1/512 (see warm_shift below)
+    const int warm_shift = 2 * m_max <= 300000 ? 44 : 43;
+    int bucket_cap = 0;
+    if (windows < 16) {
+        const double expect = 2.0 * (double)m_max * (warm_shift == 44 ? 0.0013 : 0.00065) * 6.0;
+        bucket_cap = 256;
+        while (bucket_cap < expect && bucket_cap < 4096) bucket_cap *= 2;
+        need(W * 2 * (size_t)kSelBins * bucket_cap * 8);
+    }
     const size_t per_pose = 21 + 6 + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
     need(W * N * per_pose * 8 + 16 * 256);
     need(W * N * 171 * 8);
@@ -224,7 +235,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.pose_ptr = V.opose + m_pad;
     h->S[0] = A.take<double>(W * N * 10); h->S[1] = A.take<double>(W * N * 10);
     V.states = V.states_prev = h->S[0]; V.states_new = h->S[1];
-    V.part_pred = A.take<double>(W * nblk_pred); V.part_prior = A.take<double>(W * nblk_pred); V.nblk_pred = nblk_pred;
+    V.part_pred = A.take<double>(W * 2 * nblk_pred); V.part_prior = A.take<double>(W * 2 * nblk_pred); V.nblk_pred = nblk_pred;
     V.lastD = A.take<double>(W * 81);
     V.intr = h->d_intr = A.take<double>(W * N * 4);
     V.cumrot = h->d_cumrot = A.take<double>(W * N * 4);
@@ -238,6 +249,9 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.trial_stride = trial_stride;
     V.part_next = A.take<double>(W * nblk_obs);
     V.hist = A.take<unsigned>(W * kHistStride);
+    V.wbucket = bucket_cap ? A.take<double>(W * 2 * (size_t)kSelBins * bucket_cap) : nullptr;
+    V.bucket_cap = bucket_cap;
+    V.sel_inline = 0;
     V.Hraw = A.take<double>(W * N * 21); V.braw = A.take<double>(W * N * 6);
     V.xhat = A.take<double>(W * N * 6); V.Phi = A.take<double>(W * N * 36); V.rorb = A.take<double>(W * N * 6);
     V.fatt = A.take<double>(W * N); V.qgrad = A.take<double>(W * N * 3);
@@ -257,7 +271,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.lat = windows < 16 ? 1 : 0;       // latency mode: few windows cannot fill the chip, the kernel COUNT of a call is what costs
     // warm bins: 2^44 bit patterns (1/256 of a binade, range [c/16, c*8)) while a bin of the median's density stays short,
     // 2^43 (1/512, [c/4, c*2)) for the big windows
-    V.warm_shift = 2 * m_max <= 300000 ? 44 : 43;
+    V.warm_shift = warm_shift;
     V.chunk = 0; V.chunk2 = 0;      // set after construction by vba_set_solver(h, -1)
     {   // every device array a kernel may touch must have been carved: a null here would fault on the GPU
         const void* must[] = {V.n, V.m, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
@@ -425,6 +439,7 @@ int vba_set_chunk_waves(vba_handle h, int waves) {
 int vba_set_warm_select(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     h->warm_enabled = on == 2 ? 2 : (on != 0);
+    h->inline_select = on != 3;     // 3: warm select as its own kernel (k_select_warm), the round-2 mid-point; comparison / tests
     return VBA_OK;
 }
 
@@ -681,6 +696,7 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     V.emit = c.emit;
     V.carry = c.carry;
     V.fold = c.fold ? 1 : 0;
+    V.sel_inline = 0;
     V.redo = 0;
     V.pending_only = 0;
     V.warm_force_miss = h->warm_enabled == 2;
@@ -710,6 +726,7 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
     hipStream_t s = h->stream;
     auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], s); };
     const bool init = c.initialize != 0;
+    V.sel_inline = 0;       // (a repeat of the front after a missed warm select takes the exact digits and the plain prologue)
     // the dynamics factor depends only on the states: with few windows its blocks ride in the accumulation's grid (no
     // second stream, no cross-stream join), with many it runs beside the observation kernels on a second stream
     const bool ride = !init && !c.prof && h->W < 16;
@@ -734,7 +751,10 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
         launch_select(V, false, s);
     } else if (c.carry == 2 && !exact_repeat) {
         mark(2);
-        launch_select_warm(V, s);
+        // bin buckets (latency mode): the accumulation resolves the histogram and ranks the wanted bin's bucket in its own
+        // prologue -- and, in a chained schedule, evaluates the accept test of the call in front there: no select kernel
+        V.sel_inline = (V.wbucket && h->inline_select) ? 1 : 0;
+        if (!V.sel_inline) launch_select_warm(V, s);
     } else if (c.carry == 1 && !exact_repeat) {     // the trial left digit 0 (exponent histogram) behind: two passes
         mark(2);
         launch_select(V, false, s);
@@ -1126,7 +1146,7 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
     WinScalars sc;
     HIPCHK(hipMemcpy(&sc, V.sc + window, sizeof(sc), hipMemcpyDeviceToHost));
     double wmax;
-    std::memcpy(&wmax, &sc.wmax_bits, 8);
+    std::memcpy(&wmax, &sc.wmax_bits[V.par], 8);
     switch (what) {
         case VBA_DBG_EST:
         case VBA_DBG_WEIGHT:

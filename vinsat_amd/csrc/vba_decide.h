@@ -37,10 +37,10 @@ __device__ __forceinline__ DecideOut decide_eval(const DevView& V, int w, int pc
     const bool reg = V.reg && !prm.initialize;
     double s_pred = 0.0, s_trial = 0.0, s_next = 0.0, s_prior = 0.0;
     if (!prm.initialize) {
-        const double* pp = V.part_pred + (size_t)w * V.nblk_pred;
+        const double* pp = V.part_pred + ((size_t)w * 2 + pc) * V.nblk_pred;
         for (int b = t; b < V.nblk_pred; b += 256) s_pred += pp[b];
         if (reg) {
-            const double* pq = V.part_prior + (size_t)w * V.nblk_pred;
+            const double* pq = V.part_prior + ((size_t)w * 2 + pc) * V.nblk_pred;
             for (int b = t; b < V.nblk_pred; b += 256) s_prior += pq[b];
         }
     }

@@ -64,7 +64,8 @@ struct WinScalars {
     unsigned fl[2];                 // flags of that call
     double lam32;                   // float32-rounded damping of the last trial (BA_filtering.py:54)
     double c_obs;                   // lower median of |r_obs|
-    unsigned long long wmax_bits;   // max raw weight, as ordered bits
+    unsigned long long wmax_bits[2];    // max raw weight of the call of that parity, as ordered bits (reset by the kernel in front of
+                                        // the accumulation, or -- inline select -- by the previous call's trial kernel)
     double init_residual;
     double trial_residual;
     double sum_abs_rpred;           // sqrt(sigma) * sum |r_pred|
@@ -105,6 +106,9 @@ struct DevView {
     int redo;                       // 1: this launch repeats the call for the windows whose warm select missed (sc.miss), others skip
     int lat;                        // latency mode (few windows): fused kernels, see vba_api.hip
     int fuse_blocks;                // latency mode: the chunk elimination forms the blocks of its chunk itself (vba_set_fusion bit 1)
+    double* wbucket;                // [W][2 (parity)][kSelBins][bucket_cap] carried keys by warm bin (latency mode; null: none)
+    int bucket_cap;
+    int sel_inline;                 // this call's accumulation starts the call: inline warm select on the buckets (+ folded accept test)
     int chunk_waves;                // partitioned solve: waves per chunk (2: eliminated from both ends, vba_set_chunk_waves)
     int fuse_walk;                  // batched mode: the sequential walk forms the blocks itself (vba_set_fusion bit 2)
     int warm_shift;                 // log2 of the bit-pattern width of a warm bin
@@ -144,8 +148,8 @@ struct DevView {
     double* part_init;              // [W][nblk_obs] block sums of |r_obs|
     double* part_trial;             // [W][trial_stride]: nblk_obs observation blocks, then nblk_dyn pose-chain blocks
     double* part_next;              // [W][nblk_obs] block sums of |r_obs| at the trial states (carried keys)
-    double* part_pred;              // [W][nblk_pred] block sums of |r_pred| at the input states (dynamics factor, 32 poses per block)
-    double* part_prior;             // [W][nblk_pred] block sums of |r_prior| at the input states (BA_reg)
+    double* part_pred;              // [W][2 (call parity)][nblk_pred] block sums of |r_pred| at the input states (dynamics factor, 32 poses per block)
+    double* part_prior;             // [W][2][nblk_pred] block sums of |r_prior| at the input states (BA_reg)
     int nblk_pred;
     double* lastD;                  // [W][81] undamped diagonal block of the last pose (BA_filtering.py:97: last_hessian)
     // Carried keys: the trial residual of an accepted trial is evaluated at exactly the states the next call starts
@@ -233,20 +237,24 @@ __device__ __forceinline__ double bits_f64(unsigned long long b) { return __long
 
 // Resolve one radix-select digit: given the histogram of digit p among keys matching the prefix and the
 // rank wanted inside that set, every thread of the block gets (new prefix, new rank).  256 threads.
-__device__ __forceinline__ void select_resolve(const unsigned* hist, int nbins, int width, unsigned long long prefix,
-                                               long long rank, unsigned long long& prefix_out, long long& rank_out,
-                                               unsigned* lds_u /*[260]*/) {
+// this thread's bins of a histogram of nbins (t * per + j, j < per = nbins / 256): loaded apart from the resolve so that a
+// caller can have them in flight while it does something else
+__device__ __forceinline__ void select_load(const unsigned* hist, int nbins, unsigned (&loc)[8]) {
     const int t = threadIdx.x;
     const int per = nbins / 256 > 0 ? nbins / 256 : 1;      // bins per thread (8, 4 or 2)
-    unsigned loc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) loc[j] = (j < per && t * per + j < nbins) ? hist[t * per + j] : 0u;
+}
+
+// count_out (optional): the count of the bin that was found
+__device__ __forceinline__ void select_resolve_loaded(const unsigned (&loc)[8], int nbins, int width, unsigned long long prefix,
+                                                      long long rank, unsigned long long& prefix_out, long long& rank_out,
+                                                      unsigned* lds_u /*[260]*/, unsigned* count_out = nullptr) {
+    const int t = threadIdx.x;
+    const int per = nbins / 256 > 0 ? nbins / 256 : 1;
     unsigned s = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        unsigned h = 0;
-        if (j < per && t * per + j < nbins) h = hist[t * per + j];
-        loc[j] = h;
-        s += h;
-    }
+    for (int j = 0; j < 8; ++j) s += loc[j];
     // inclusive scan over 256 threads: wave scan + 4 wave totals
     unsigned inc = s;
 #pragma unroll
@@ -255,7 +263,7 @@ __device__ __forceinline__ void select_resolve(const unsigned* hist, int nbins, 
         if ((t & 63) >= o) inc += v;
     }
     if ((t & 63) == 63) lds_u[t >> 6] = inc;
-    if (t == 0) { lds_u[8] = 0; lds_u[9] = 0; }
+    if (t == 0) { lds_u[8] = 0; lds_u[9] = 0; lds_u[10] = 0; }
     __syncthreads();
     unsigned base = 0;
     for (int w = 0; w < (t >> 6); ++w) base += lds_u[w];
@@ -266,7 +274,7 @@ __device__ __forceinline__ void select_resolve(const unsigned* hist, int nbins, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (j < per) {
-                if (rank >= cum && rank < cum + (long long)loc[j]) bin = t * per + j, lds_u[8] = (unsigned)(rank - cum), lds_u[9] = (unsigned)bin;
+                if (rank >= cum && rank < cum + (long long)loc[j]) bin = t * per + j, lds_u[8] = (unsigned)(rank - cum), lds_u[9] = (unsigned)bin, lds_u[10] = loc[j];
                 cum += loc[j];
             }
         }
@@ -274,7 +282,16 @@ __device__ __forceinline__ void select_resolve(const unsigned* hist, int nbins, 
     __syncthreads();
     rank_out = (long long)lds_u[8];
     prefix_out = (prefix << width) | (unsigned long long)lds_u[9];
+    if (count_out) *count_out = lds_u[10];
     __syncthreads();
+}
+
+__device__ __forceinline__ void select_resolve(const unsigned* hist, int nbins, int width, unsigned long long prefix,
+                                               long long rank, unsigned long long& prefix_out, long long& rank_out,
+                                               unsigned* lds_u /*[260]*/) {
+    unsigned loc[8];
+    select_load(hist, nbins, loc);
+    select_resolve_loaded(loc, nbins, width, prefix, rank, prefix_out, rank_out, lds_u);
 }
 
 }  // namespace vba

@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void k_dynamics_pair(DevView V) {
             double tp = 0.0, tq = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { tp += vw[0][threadIdx.x * 4 + k]; tq += vw[1][threadIdx.x * 4 + k]; }
-            V.part_pred[(size_t)w * V.nblk_pred + vb] = tp;
-            if (V.reg) V.part_prior[(size_t)w * V.nblk_pred + vb] = tq;
+            V.part_pred[((size_t)w * 2 + V.par) * V.nblk_pred + vb] = tp;
+            if (V.reg) V.part_prior[((size_t)w * 2 + V.par) * V.nblk_pred + vb] = tq;
         }
     }
 }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     // slot 0 = pose i0-1 (only Phi and rorb are used), slots 1..kAsmPoses = poses i0 ..
     asm_stage<REG>(V, w, n, dyn, i0 - 1, kAsmPoses + 1, in, threadIdx.x, 256);
     __syncthreads();
-    const double inv_wmax = 1.0 / bits_f64(V.sc[w].wmax_bits);
+    const double inv_wmax = 1.0 / bits_f64(V.sc[w].wmax_bits[V.par]);
     const int cnt = min(kAsmPoses, n - i0);
     // thread t forms entry t of every pose of the block: which band / row / column it is (and with that every index
     // into the staged inputs) is decoded once, and for a fixed pose the 252 threads write consecutive addresses

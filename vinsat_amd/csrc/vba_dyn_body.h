@@ -14,7 +14,9 @@
 namespace vba {
 
 // Besides the factor itself the block leaves the fixed-order sums of |r_pred| (and, BA_reg, of |r_prior|) over its poses
-// behind: the accept test adds up a handful of block partials instead of walking the pose arrays.
+// behind: the accept test adds up a handful of block partials instead of walking the pose arrays.  The partials are kept per
+// call parity: in a chained schedule the accept test of call c is evaluated in the prologue of the accumulation of call
+// c + 1, whose grid also carries the blocks that form the factor of call c + 1.
 __device__ __forceinline__ void dynamics_block(const DevView& V, int w, int block) {
     __shared__ double dred[4];
     const int n = V.n[w];
@@ -70,10 +72,10 @@ __device__ __forceinline__ void dynamics_block(const DevView& V, int w, int bloc
         s_prior = fabs(r6[0]) + fabs(r6[1]) + fabs(r6[2]) + fabs(r6[3]) + fabs(r6[4]) + fabs(r6[5]);
     }
     const double tp = block_sum<256>(s_pred, dred);
-    if (threadIdx.x == 0) V.part_pred[(size_t)w * V.nblk_pred + block] = tp;
+    if (threadIdx.x == 0) V.part_pred[((size_t)w * 2 + V.par) * V.nblk_pred + block] = tp;
     if (V.reg) {
         const double tq = block_sum<256>(s_prior, dred);
-        if (threadIdx.x == 0) V.part_prior[(size_t)w * V.nblk_pred + block] = tq;
+        if (threadIdx.x == 0) V.part_prior[((size_t)w * 2 + V.par) * V.nblk_pred + block] = tq;
     }
 }
 

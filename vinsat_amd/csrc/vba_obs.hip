@@ -29,11 +29,13 @@ namespace vba {
 //     (k_obs_residual, k_select_warm, or k_select_pass<1> of a repeated select), no other block of that kernel reads them;
 //   * the length of the compacted list: reset by the kernel in FRONT of the one that appends (k_obs_residual /
 //     k_select_pass<1>, or the previous call's k_trial for k_select_warm).
-__device__ __forceinline__ void begin_call_scalars(WinScalars& sc, int par) {
+// keep_wmax: the caller is a block of the accumulation itself (inline select): other blocks of the same kernel may
+// already have entered their maximum, the slot was cleared by the previous call's trial kernel instead
+__device__ __forceinline__ void begin_call_scalars(WinScalars& sc, int par, bool keep_wmax = false) {
     sc.done = 0;
     sc.n_trials = 0;
     sc.fl[par] = 0u;
-    sc.wmax_bits = 0ull;
+    if (!keep_wmax) sc.wmax_bits[par] = 0ull;
     sc.sum_abs_rpred = 0.0;
 }
 
@@ -195,37 +197,27 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
 // Then every block resolves the warm histogram the trial left behind (bin of the wanted rank), and the keys of that
 // bin are compacted for select_finish.  A rank outside the binned range, or a bin longer than the list may be, is a
 // miss: the window waits (sc.miss) until the host has repeated this call's select with the exact digits.
-template <int ITEMS>
-__global__ __launch_bounds__(256) void k_select_warm(DevView V) {
-    __shared__ unsigned lds_u[260];
-    __shared__ double red[5][4];
-    const int w = blockIdx.y;
+// The front of a call on carried keys, evaluated by EVERY block of the kernel that starts the call -- k_select_warm, or,
+// with the bin buckets (inline select), k_obs_accumulate itself.  fold_here: the accept test of the call in front; a
+// first trial that was not cleanly accepted leaves everything untouched (kWarmSkip).  Then the warm histogram the trial
+// left behind is resolved to the bin of the wanted rank; block 0 records the outcome.  A rank outside the binned range,
+// or a bin longer than `list_cap`, is a miss.
+enum { kWarmSkip = 0, kWarmHit = 1, kWarmMiss = 2 };
+
+__device__ __forceinline__ int warm_front(const DevView& V, int w, bool fold_here, bool inline_select, long long list_cap,
+                                          double (*red)[4], unsigned* lds_u, unsigned& bin_out, long long& rank_out,
+                                          unsigned& in_bin_out) {
     WinScalars& sc = V.sc[w];
     const int t = threadIdx.x;
     const int par = V.par;
-    const bool fold_here = V.call >= 0 && V.fold && sc.pending == V.call - 1 && sc.call_idx == V.call - 1;
-    if (!fold_here) VBA_SKIP_CALL(V, w);
-    const double* keys = V.absr + 2 * (size_t)w * V.m_max;
     const int64_t count = 2 * (int64_t)V.m[w];
-    if ((int64_t)blockIdx.x * 256 * ITEMS >= count) return;         // (never block 0)
-    // the keys of a short block are loaded before anything is decided (latency)
-    constexpr bool PRELOAD = ITEMS <= 8;
-    constexpr int PAIRS = ITEMS / 2;        // two keys (16 bytes) per load
-    const double2* keys2 = reinterpret_cast<const double2*>(keys);
-    const int64_t npair = count / 2;
-    double2 pk[PRELOAD ? PAIRS : 1];
-    if (PRELOAD) {
-#pragma unroll
-        for (int it = 0; it < PAIRS; ++it) {
-            const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + t;
-            pk[it] = idx < npair ? keys2[idx] : make_double2(0.0, 0.0);
-        }
-    }
     const unsigned* h0 = hist0_of(V, w, par);
     const unsigned long long lo = sc.warm_lo[par];
+    unsigned hloc[8];
+    select_load(h0, kSelBins, hloc);        // in flight while the accept test is evaluated
     if (fold_here) {
         const DecideOut d = decide_eval(V, w, par ^ 1, V.prev, 0, 0.0, nullptr, 0, red);
-        if (!d.accept || (d.flags & (2u | 8u | 32u))) return;       // not a clean first trial: the host finishes that call
+        if (!d.accept || (d.flags & (2u | 8u | 32u))) return kWarmSkip;     // not a clean first trial: the host finishes that call
         if (blockIdx.x == 0) {
             const double lam32 = sc.lam32;      // of the decided call's solve
             if (t < 81) sc.last_hessian[t] = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
@@ -247,16 +239,17 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
     }
     unsigned long long prefix;
     long long rank;
-    select_resolve(h0, kSelBins, 11, 0ull, (count - 1) / 2, prefix, rank, lds_u);
+    unsigned in_bin;
+    select_resolve_loaded(hloc, kSelBins, 11, 0ull, (count - 1) / 2, prefix, rank, lds_u, &in_bin);
     const unsigned bin = (unsigned)prefix;
-    const unsigned in_bin = h0[bin];
-    const bool hit = lo != ~0ull && bin >= 1u && bin <= 2046u && (int64_t)in_bin <= 2 * V.m_max && !V.warm_force_miss;
+    const bool hit = lo != ~0ull && bin >= 1u && bin <= 2046u && (int64_t)in_bin <= list_cap && !V.warm_force_miss;
     if (blockIdx.x == 0 && t == 0) {
-        begin_call_scalars(sc, par);
+        begin_call_scalars(sc, par, inline_select);
         if (hit) {
             sc.sel_mode = 1;
             sc.sel_rank[2] = rank;
             sc.warm_base = lo + ((unsigned long long)(bin - 1u) << V.warm_shift);
+            if (inline_select) sc.sel_cnt = in_bin;
         } else {
             sc.miss = 1;
             sc.fl[par] = 32u;
@@ -264,7 +257,41 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
             V.host_head[w].done = 0;
         }
     }
-    if (!hit) return;
+    bin_out = bin;
+    rank_out = rank;
+    in_bin_out = in_bin;
+    return hit ? kWarmHit : kWarmMiss;
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(256) void k_select_warm(DevView V) {
+    __shared__ unsigned lds_u[260];
+    __shared__ double red[5][4];
+    const int w = blockIdx.y;
+    WinScalars& sc = V.sc[w];
+    const int t = threadIdx.x;
+    const bool fold_here = V.call >= 0 && V.fold && sc.pending == V.call - 1 && sc.call_idx == V.call - 1;
+    if (!fold_here) VBA_SKIP_CALL(V, w);
+    const double* keys = V.absr + 2 * (size_t)w * V.m_max;
+    const int64_t count = 2 * (int64_t)V.m[w];
+    if ((int64_t)blockIdx.x * 256 * ITEMS >= count) return;         // (never block 0)
+    // the keys of a short block are loaded before anything is decided (latency)
+    constexpr bool PRELOAD = ITEMS <= 8;
+    constexpr int PAIRS = ITEMS / 2;        // two keys (16 bytes) per load
+    const double2* keys2 = reinterpret_cast<const double2*>(keys);
+    const int64_t npair = count / 2;
+    double2 pk[PRELOAD ? PAIRS : 1];
+    if (PRELOAD) {
+#pragma unroll
+        for (int it = 0; it < PAIRS; ++it) {
+            const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + t;
+            pk[it] = idx < npair ? keys2[idx] : make_double2(0.0, 0.0);
+        }
+    }
+    const unsigned long long lo = sc.warm_lo[V.par];
+    unsigned bin, in_bin;
+    long long rank;
+    if (warm_front(V, w, fold_here, false, 2 * V.m_max, red, lds_u, bin, rank, in_bin) != kWarmHit) return;
     auto take = [&](unsigned long long key, bool have) {
         const bool match = have && warm_bin(key, lo, V.warm_shift) == bin;
         const unsigned long long mask = __ballot(match);
@@ -293,23 +320,20 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
 // lists (massive ties) take digits 3, 4, 5 with a block-local histogram each, the full key array if the list
 // overflowed.  A list made by k_select_warm (one warm bin) is ranked by counting while short, by radix digits of the offset
 // inside the bin otherwise.
-__device__ __forceinline__ double select_finish(const DevView& V, int w, unsigned* lh /*[kSelBins]*/, unsigned* lds_u /*[260]*/,
-                                                unsigned long long* skeys /*[1024] + 1*/) {
+// ck: the list (capacity `cap` entries, cnt of them valid -- cnt > cap: it overflowed), want: the rank wanted among them,
+// mode 0: keys sharing the 32-bit prefix of an exact select, 1: the keys of one warm bin starting at warm_base.
+// speculate: load the first 1024 entries before cnt is known to the caller's satisfaction (one round trip instead of two).
+__device__ __forceinline__ double select_finish_list(const DevView& V, int w, const double* ck, int64_t cap, unsigned cnt, long long want,
+                                                     int mode, unsigned long long warm_base, bool speculate, unsigned* lh /*[kSelBins]*/,
+                                                     unsigned* lds_u /*[260]*/, unsigned long long* skeys /*[1024] + 1*/) {
     const WinScalars& sc = V.sc[w];
-    // the list length, the wanted rank and the first 1024 list entries are loaded together (the entries
-    // speculatively: the list is almost always that short)
-    unsigned cnt = sc.sel_cnt;
-    const long long want = sc.sel_rank[2];
-    const int mode = sc.sel_mode;
-    const unsigned long long warm_base = sc.warm_base;
-    const double* ck = V.ckeys + 2 * (size_t)w * V.m_max;
     // latency mode loads the first 1024 entries speculatively together with the length (one round trip instead of two);
     // with many windows per launch every block of every window would drag 8 KB through the caches for a handful of keys
     unsigned long long pre[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned q = threadIdx.x + 256u * j;
-        pre[j] = ((int64_t)q < 2 * V.m_max && (V.lat || q < cnt)) ? f64_bits(ck[q]) : 0ull;
+        pre[j] = ((int64_t)q < cap && (speculate || q < cnt)) ? f64_bits(ck[q]) : 0ull;
     }
     if (cnt <= (mode ? (unsigned)kWarmCount : 1024u)) {
         // the wanted key is the one of rank `want` among the list -- rank each key by counting (ties broken by position)
@@ -382,6 +406,15 @@ __device__ __forceinline__ double select_finish(const DevView& V, int w, unsigne
     return bits_f64(prefix);
 }
 
+// The list the select kernels of this call left (k_select_pass<2> / k_select_warm): its length, the wanted rank and the
+// first entries are loaded together.
+__device__ __forceinline__ double select_finish(const DevView& V, int w, unsigned* lh /*[kSelBins]*/, unsigned* lds_u /*[260]*/,
+                                                unsigned long long* skeys /*[1024] + 1*/) {
+    const WinScalars& sc = V.sc[w];
+    return select_finish_list(V, w, V.ckeys + 2 * (size_t)w * V.m_max, 2 * V.m_max, sc.sel_cnt, sc.sel_rank[2], sc.sel_mode, sc.warm_base,
+                              V.lat != 0, lh, lds_u, skeys);
+}
+
 // ---------------------------------------------------------------------------------------------- A2 + A3
 // G lanes per pose (power of two): every lane strides over its share of the pose's observation segment and
 // keeps the 21 + 6 unique entries of sum(w J^T J), sum(w J^T r) in registers; a log2(G)-step xor butterfly
@@ -400,17 +433,26 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     __shared__ unsigned sel_lh[kSelBins];
     __shared__ unsigned sel_u[260];
     __shared__ unsigned long long sel_keys[1025];
+    __shared__ double dec_red[5][4];
     constexpr int PPB = 256 / G;            // poses per block
     const int w = blockIdx.y;
-    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    // Inline select (V.sel_inline: latency mode, carried keys in bin buckets): this kernel STARTS the call -- no select
+    // kernel in front of it.  In a chained schedule its blocks evaluate the accept test of the call in front themselves
+    // (warm_front) and go on only if that first trial was cleanly accepted.
+    const bool fold_here = V.sel_inline && V.call >= 0 && V.fold && sc.pending == V.call - 1 && sc.call_idx == V.call - 1;
+    if (!fold_here) VBA_SKIP_CALL(V, w);
     const int nb_acc = (V.n_max * G + 255) / 256;
     if ((int)blockIdx.x >= nb_acc) {        // few windows: the dynamics factor rides in this grid (vba_dyn_body.h)
+        if (fold_here) {    // (a function of the input states only: a missed select does not concern it)
+            const DecideOut d = decide_eval(V, w, V.par ^ 1, V.prev, 0, 0.0, nullptr, 0, dec_red);
+            if (!d.accept || (d.flags & (2u | 8u | 32u))) return;
+        }
         dynamics_block(V, w, blockIdx.x - nb_acc);
         return;
     }
     const int n = V.n[w];
     if (blockIdx.x * PPB >= n) return;
-    WinScalars& sc = V.sc[w];
     const StepParams& prm = V.prm;
     const int sub = threadIdx.x % G;
     const int i = blockIdx.x * PPB + threadIdx.x / G;
@@ -460,13 +502,27 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 
     // Phase 2: the median (every block of the window finishes the select itself, see select_finish)
     RobustParams rp;
-    rp.c = select_finish(V, w, sel_lh, sel_u, sel_keys);
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) sc.c_obs = rp.c;      // the trial kernel centres the next call's warm bins on it
-        // the select of this call is over (its last reader of the digit-0 histogram was the kernel in front): clean for
-        // the call after next, which shares the parity
-        unsigned* h0 = hist0_of(V, w, V.par);
-        for (int b = threadIdx.x; b < kSelBins; b += 256) h0[b] = 0u;
+    if (V.sel_inline) {
+        // the trial kernel of the call in front dropped every key into the bucket of its warm bin: resolve the histogram,
+        // rank the wanted bin's bucket.  Every block does this redundantly (a few hundred keys), nothing is compacted.
+        unsigned bin, in_bin;
+        long long rank;
+        if (warm_front(V, w, fold_here, true, V.bucket_cap, dec_red, sel_u, bin, rank, in_bin) != kWarmHit) return;
+        const unsigned long long lo = sc.warm_lo[V.par];
+        const double* bucket = V.wbucket + (((size_t)w * 2 + V.par) * kSelBins + bin) * (size_t)V.bucket_cap;
+        rp.c = select_finish_list(V, w, bucket, V.bucket_cap, in_bin, rank, 1, lo + ((unsigned long long)(bin - 1u) << V.warm_shift), false,
+                                  sel_lh, sel_u, sel_keys);
+        // (the histogram is still being read by the other blocks: the trial kernel of this call clears it)
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc.c_obs = rp.c;
+    } else {
+        rp.c = select_finish(V, w, sel_lh, sel_u, sel_keys);
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) sc.c_obs = rp.c;      // the trial kernel centres the next call's warm bins on it
+            // the select of this call is over (its last reader of the digit-0 histogram was the kernel in front): clean for
+            // the call after next, which shares the parity
+            unsigned* h0 = hist0_of(V, w, V.par);
+            for (int b = threadIdx.x; b < kSelBins; b += 256) h0[b] = 0u;
+        }
     }
     rp.inv_c = 1.0 / rp.c;
     rp.inv_c2 = 1.0 / (rp.c * rp.c);
@@ -617,7 +673,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const double mx = fmax(fmax(wmx[0], wmx[1]), fmax(wmx[2], wmx[3]));
-        atomicMax(&sc.wmax_bits, f64_bits(mx));     // positive doubles order like their bit patterns
+        atomicMax(&sc.wmax_bits[V.par], f64_bits(mx));     // positive doubles order like their bit patterns
     }
 }
 
@@ -658,7 +714,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     const double lam32 = (double)(float)sc.lam[par];      // torch.eye() is float32 (BA_filtering.py:54)
     // a window that has fallen back to the pivoted kernels (landmark-only phase) reads the trial states they wrote
     const bool fz = FUSED == 2 || (FUSED == 1 && !(sc.fl[par] & 16u));
-    const double wmax = bits_f64(sc.wmax_bits);
+    const double wmax = bits_f64(sc.wmax_bits[par]);
     const double inv_wmax = 1.0 / wmax;
     const int l16 = tid & 15, grp = tid >> 4, gbase = (tid & 63) & ~15;
     unsigned long long wlo = 0ull;
@@ -672,6 +728,11 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
         // digits 1, 2 of an exact select are dead since the accumulation; the list of the next warm select starts empty
         unsigned* h12 = histd_of(V, w, 1);
         for (int b = tid; b < 2 * kSelBins; b += kObsBlock) h12[b] = 0u;
+        if (V.wbucket) {    // inline select: nobody clears these in front of the next accumulation
+            unsigned* h0 = hist0_of(V, w, par);     // this call's histogram: its last readers were the accumulation's prologues
+            for (int b = tid; b < kSelBins; b += kObsBlock) h0[b] = 0u;
+            if (tid == 0) sc.wmax_bits[par ^ 1] = 0ull;
+        }
         if (tid == 0) {
             sc.sel_cnt = 0u;
             sc.pending = V.call;
@@ -684,6 +745,9 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
         }
     }
     unsigned bad = 0u;
+    unsigned kbin[2] = {0u, 0u}, kslot[2] = {0u, 0u};      // EMIT 2: warm bin of this thread's two keys and their place in the block's share
+    double kkey[2] = {0.0, 0.0};
+    bool kvalid = false;
     if (obs_block) {
         const int k = blockIdx.x * kObsBlock + tid;
         const size_t ob = (size_t)w * V.obs_stride, mb = (size_t)w * V.m_max;
@@ -735,8 +799,13 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
                 reinterpret_cast<double2*>(V.absr + 2 * mb)[k] = make_double2(ru, rv);
                 s_raw = ru + rv;
                 if (EMIT == 2) {
-                    atomicAdd(&lh[warm_bin(f64_bits(ru), wlo, V.warm_shift)], 1u);
-                    atomicAdd(&lh[warm_bin(f64_bits(rv), wlo, V.warm_shift)], 1u);
+                    kbin[0] = warm_bin(f64_bits(ru), wlo, V.warm_shift);
+                    kbin[1] = warm_bin(f64_bits(rv), wlo, V.warm_shift);
+                    kslot[0] = atomicAdd(&lh[kbin[0]], 1u);
+                    kslot[1] = atomicAdd(&lh[kbin[1]], 1u);
+                    kkey[0] = ru;
+                    kkey[1] = rv;
+                    kvalid = true;
                 } else {
                     atomicAdd(&lh[(unsigned)(f64_bits(ru) >> 53) & 1023u], 1u);
                     atomicAdd(&lh[(unsigned)(f64_bits(rv) >> 53) & 1023u], 1u);
@@ -824,9 +893,31 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
         const double t_raw = block_sum<kObsBlock>(s_raw, red);
         if (tid == 0) V.part_next[(size_t)w * V.nblk_obs + blockIdx.x] = t_raw;
         unsigned* hist = hist0_of(V, w, par ^ 1);
-        for (int b = tid; b < kEmitBins; b += kObsBlock) {
-            const unsigned c = lh[b];
-            if (c) atomicAdd(&hist[b], c);
+        if (EMIT == 2 && V.wbucket) {
+            // bin buckets: the block reserves its share of every bin it touched and each key goes to its place -- the next
+            // call finds the keys of the wanted bin together, no pass over all keys (k_select_warm) is needed
+            static_assert(kSelBins % kObsBlock == 0, "bins per thread");
+            unsigned cb[kSelBins / kObsBlock], bb[kSelBins / kObsBlock];
+#pragma unroll
+            for (int q = 0; q < kSelBins / kObsBlock; ++q) cb[q] = lh[tid + q * kObsBlock];
+#pragma unroll
+            for (int q = 0; q < kSelBins / kObsBlock; ++q) bb[q] = cb[q] ? atomicAdd(&hist[tid + q * kObsBlock], cb[q]) : 0u;   // all in flight together
+#pragma unroll
+            for (int q = 0; q < kSelBins / kObsBlock; ++q) lh[tid + q * kObsBlock] = bb[q];
+            __syncthreads();
+            if (kvalid) {
+                double* pool = V.wbucket + ((size_t)w * 2 + (par ^ 1)) * kSelBins * (size_t)V.bucket_cap;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned slot = lh[kbin[q]] + kslot[q];
+                    if (kbin[q] >= 1u && kbin[q] <= 2046u && slot < (unsigned)V.bucket_cap) pool[(size_t)kbin[q] * V.bucket_cap + slot] = kkey[q];
+                }
+            }
+        } else {
+            for (int b = tid; b < kEmitBins; b += kObsBlock) {
+                const unsigned c = lh[b];
+                if (c) atomicAdd(&hist[b], c);
+            }
         }
     }
 }
@@ -846,7 +937,7 @@ __global__ __launch_bounds__(kObsBlock) void k_debug_project(DevView V, int w, d
     est[2 * k] = u;
     est[2 * k + 1] = v;
     project_jacobian(pc, cam, d, J + 12 * (size_t)k);
-    wt[k] = (V.wraw[mb + k] / bits_f64(V.sc[w].wmax_bits)) * V.oconf[ob + k];
+    wt[k] = (V.wraw[mb + k] / bits_f64(V.sc[w].wmax_bits[V.par])) * V.oconf[ob + k];
 }
 
 // window 0's states and damping copied to every other window (vba_set_states with window == -1)

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_shard_pack(DevView V, double* out) {
         for (int b = threadIdx.x; b < V.nblk_obs; b += 256) s += V.part_init[b];
         const double t = block_sum<256>(s, red);
         if (threadIdx.x == 0) {
-            out[cnt] = bits_f64(V.sc[0].wmax_bits);
+            out[cnt] = bits_f64(V.sc[0].wmax_bits[V.par]);
             out[cnt + 1] = t;
         }
     }
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_shard_reduce(DevView V, const double* a
             mx = fmax(mx, all[q * stride + cnt]);
             sa += all[q * stride + cnt + 1];
         }
-        V.sc[0].wmax_bits = f64_bits(mx);
+        V.sc[0].wmax_bits[V.par] = f64_bits(mx);
         V.sc[0].sum_in[V.par] = sa;
     }
 }

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
     }
     bool badp = false;
-    const RawSource<REG> src{V, sb, n, lane, V.prm.sigma, 1.0 / bits_f64(sc.wmax_bits), ring, {}};
+    const RawSource<REG> src{V, sb, n, lane, V.prm.sigma, 1.0 / bits_f64(sc.wmax_bits[V.par]), ring, {}};
     src.prefetch(0); src.commit(0);
     src.prefetch(1); src.commit(1);
     __syncthreads();
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_solve_chunks_fused(DevView V, int s) {
     double* in = blocks + (size_t)(s + 1) * 252;                             // [s + 2][kAsmIn]: poses j0 - 1 .. j1
     asm_stage<REG>(V, w, n, true, j0 - 1, nblk + 1, in, tid, 256);
     __syncthreads();
-    const double inv_wmax = 1.0 / bits_f64(sc.wmax_bits);
+    const double inv_wmax = 1.0 / bits_f64(sc.wmax_bits[V.par]);
     // thread t forms entry t of every block of the chunk: which band / row / column it is is decoded once (as in k_assemble)
     if (tid < 252) {
         const int e = tid;
