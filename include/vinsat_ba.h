@@ -133,7 +133,11 @@ int vba_set_key_carry(vba_handle h, int on);
  * "miss": counted by vba_warm_select_misses, same result either way).  In a chained schedule (vba_run_schedule) the
  * warm pass of call c + 1 also evaluates the LM accept test of call c in its prologue, which removes the decide launch
  * from the chain.  on == 0: every select takes the exact digit passes and every accept test its own launch (same bits).
- * on == 2 (test knob): every warm select reports a miss, i.e. every carried call takes the repeat path. */
+ * on == 2 (test knob): every warm select reports a miss, i.e. every carried call takes the repeat path.
+ * Latency mode (fewer than 16 windows) goes one step further: the trial kernel drops every key into the bucket of its warm
+ * bin (capacity ~6x the densest bin; a longer bin is a miss), so the bin of the wanted rank needs no pass over the keys --
+ * the accumulation kernel resolves the histogram, ranks that bucket and evaluates the folded accept test in its own
+ * prologue, and a chained landmark-only call is two kernels.  on == 3: keep the select as its own kernel (comparison). */
 int vba_set_warm_select(vba_handle h, int on);
 int vba_warm_select_misses(vba_handle h, int* count);
 

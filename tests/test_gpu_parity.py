@@ -1165,8 +1165,8 @@ def _schedule_states(eng, st0, iters, inits, chained):
 
 @pytest.mark.parametrize("confmode", ["golden", "rejections"])
 def test_warm_select_and_folded_accept_test_give_the_bits_of_the_exact_path(c2, confmode):
-    """Carried keys are selected in ONE warm pass whose prologue, in a chained schedule, is the accept test of the call
-    in front.  The median stays exact and the accept test is the same arithmetic, so: chained / stepped, warm / exact
+    """Carried keys are selected from the bucket of ONE warm bin in the prologue of the accumulation (or, setting 3, by one
+    warm pass of a select kernel), which in a chained schedule also evaluates the accept test of the call in front.  The median stays exact and the accept test is the same arithmetic, so: chained / stepped, warm / exact
     digits, and a warm select forced to miss on every call (the repeat path) all end in identical bits -- also when calls
     reject trials and exhaust lamda in the middle of the chain."""
     from vinsat_amd.engine import BAEngine
@@ -1176,7 +1176,8 @@ def test_warm_select_and_folded_accept_test_give_the_bits_of_the_exact_path(c2, 
     iters, inits = list(range(20)), [k < 10 for k in range(20)]
     outs = {}
     for name, warm, chained in (("exact-stepped", 0, False), ("exact-chained", 0, True), ("warm-stepped", 1, False),
-                                ("warm-chained", 1, True), ("miss-stepped", 2, False), ("miss-chained", 2, True)):
+                                ("warm-chained", 1, True), ("miss-stepped", 2, False), ("miss-chained", 2, True),
+                                ("kernel-stepped", 3, False), ("kernel-chained", 3, True)):      # 3: warm select as its own kernel
         e = BAEngine(n, m)
         e.set_warm_select(warm)
         e.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)

@@ -54,6 +54,9 @@ struct vba_context {
     DevView V{};
     // mutable device pointers (DevView holds const views of some)
     int *d_n = nullptr, *d_m = nullptr, *d_steps = nullptr;
+    // per-observation weights and per-pose normal equations exist per call parity (DevView points at the slot of the call):
+    // the accumulation of call c + 1 starts before the accept test of call c is known, whose later trials still read them
+    double *wraw2 = nullptr, *Hraw2 = nullptr, *braw2 = nullptr;
     double* d_obs = nullptr;                // observation blocks, [W][obs_stride] (layout: DevView::ox)
     int64_t m_pad = 0;                      // doubles per observation array inside a block
     double *d_intr = nullptr, *d_cumrot = nullptr;
@@ -193,7 +196,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     const int nblk_pred = (int)((N * kDynLanes + 255) / 256);
     need(W * 2 * nblk_pred * 8); need(W * 2 * nblk_pred * 8); need(W * 81 * 8);
     need(W * N * 36 * 8); need(W * N * 6 * 8);
-    need(W * 2 * M * 8); need(W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * trial_stride * 8); need(W * nblk_obs * 8);
+    need(W * 2 * M * 8); need(2 * W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * trial_stride * 8); need(W * nblk_obs * 8);
     need(W * kHistStride * 4);
     // bin buckets of the carried keys (latency mode only): capacity ~6x the count of the densest warm bin -- the bin of the
     // median holds ~0.13 % of the keys with 1/256-binade bins, half of that with 1/512 (see warm_shift below)
@@ -205,7 +208,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
         while (bucket_cap < expect && bucket_cap < 4096) bucket_cap *= 2;
         need(W * 2 * (size_t)kSelBins * bucket_cap * 8);
     }
-    const size_t per_pose = 21 + 6 + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
+    const size_t per_pose = 2 * (21 + 6) + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
     need(W * N * per_pose * 8 + 16 * 256);
     need(W * N * 171 * 8);
     need(W * N * (171 + 171 + 81 + 9 + 9) * 8 + 6 * 256);
@@ -243,7 +246,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.prior_H = h->d_prior_H = A.take<double>(W * N * 36);
     V.prior_x = h->d_prior_x = A.take<double>(W * N * 6);
     V.reg = 0;
-    V.absr = A.take<double>(W * 2 * M); V.wraw = A.take<double>(W * M); V.ckeys = A.take<double>(W * 2 * M);
+    V.absr = A.take<double>(W * 2 * M); V.wraw = h->wraw2 = A.take<double>(2 * W * M); V.ckeys = A.take<double>(W * 2 * M);
     V.acc_lanes = 8;    // set after construction by vba_set_accumulate_lanes(h, 0)
     V.part_init = A.take<double>(W * nblk_obs); V.part_trial = A.take<double>(W * trial_stride);
     V.trial_stride = trial_stride;
@@ -252,7 +255,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.wbucket = bucket_cap ? A.take<double>(W * 2 * (size_t)kSelBins * bucket_cap) : nullptr;
     V.bucket_cap = bucket_cap;
     V.sel_inline = 0;
-    V.Hraw = A.take<double>(W * N * 21); V.braw = A.take<double>(W * N * 6);
+    V.Hraw = h->Hraw2 = A.take<double>(2 * W * N * 21); V.braw = h->braw2 = A.take<double>(2 * W * N * 6);
     V.xhat = A.take<double>(W * N * 6); V.Phi = A.take<double>(W * N * 36); V.rorb = A.take<double>(W * N * 6);
     V.fatt = A.take<double>(W * N); V.qgrad = A.take<double>(W * N * 3);
     V.Hd = A.take<double>(W * N * 9); V.Hu = A.take<double>(W * N * 9); V.Hl = A.take<double>(W * N * 9);
@@ -691,6 +694,9 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     V.call = c.call;
     V.par = c.par;
     V.states = h->S[c.par];
+    V.wraw = h->wraw2 + (size_t)c.par * h->W * h->V.m_max;
+    V.Hraw = h->Hraw2 + (size_t)c.par * h->W * h->n_max * 21;
+    V.braw = h->braw2 + (size_t)c.par * h->W * h->n_max * 6;
     V.states_new = h->S[c.par ^ 1];
     V.states_prev = h->S[c.par];
     V.emit = c.emit;

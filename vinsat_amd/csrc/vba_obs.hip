@@ -204,62 +204,74 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
 // or a bin longer than `list_cap`, is a miss.
 enum { kWarmSkip = 0, kWarmHit = 1, kWarmMiss = 2 };
 
+// the accept test of the call in front (all threads); clean = its first trial was accepted with nothing to repair
+__device__ __forceinline__ bool fold_decide(const DevView& V, int w, double (*red)[4], DecideOut& d) {
+    d = decide_eval(V, w, V.par ^ 1, V.prev, 0, 0.0, nullptr, 0, red);
+    return d.accept && !(d.flags & (2u | 8u | 32u));
+}
+// ... and what a clean one leaves behind (block 0 only): the window moves on to this call
+__device__ __forceinline__ void fold_commit(const DevView& V, int w, const DecideOut& d) {
+    WinScalars& sc = V.sc[w];
+    const int t = threadIdx.x, par = V.par;
+    const double lam32 = sc.lam32;      // of the decided call's solve
+    if (t < 81) sc.last_hessian[t] = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
+    if (t == 0) {
+        sc.lam[par] = d.lam_out;
+        sc.sum_in[par] = d.sum_next;
+        sc.init_residual = d.init_residual;
+        sc.trial_residual = d.residual;
+        sc.call_idx = V.call;
+        WinHead& hh = V.host_head[w];
+        hh.lamda = d.lam_out;
+        hh.trial_residual = d.residual;
+        hh.n_trials = 1;
+        hh.flags = d.flags;
+        hh.done = 1;
+        hh.call_idx = V.call;
+    }
+}
+// the scalars of the call that begins (one thread): the selected bin, or the miss
+__device__ __forceinline__ void front_commit(const DevView& V, int w, bool hit, unsigned bin, long long rank, unsigned in_bin, bool inline_select) {
+    WinScalars& sc = V.sc[w];
+    const int par = V.par;
+    begin_call_scalars(sc, par, inline_select);
+    if (hit) {
+        sc.sel_mode = 1;
+        sc.sel_rank[2] = rank;
+        sc.warm_base = sc.warm_lo[par] + ((unsigned long long)(bin - 1u) << V.warm_shift);
+        if (inline_select) sc.sel_cnt = in_bin;
+    } else {
+        sc.miss = 1;
+        sc.fl[par] = 32u;
+        V.host_head[w].flags = 32u;
+        V.host_head[w].done = 0;
+    }
+}
+// the warm histogram resolved to the bin of the wanted rank (all threads; hloc: select_load of hist0[par])
+__device__ __forceinline__ bool front_resolve(const DevView& V, int w, const unsigned (&hloc)[8], long long list_cap, unsigned* lds_u,
+                                              unsigned& bin, long long& rank, unsigned& in_bin) {
+    const int64_t count = 2 * (int64_t)V.m[w];
+    const unsigned long long lo = V.sc[w].warm_lo[V.par];
+    unsigned long long prefix;
+    select_resolve_loaded(hloc, kSelBins, 11, 0ull, (count - 1) / 2, prefix, rank, lds_u, &in_bin);
+    bin = (unsigned)prefix;
+    return lo != ~0ull && bin >= 1u && bin <= 2046u && (int64_t)in_bin <= list_cap && !V.warm_force_miss;
+}
+
+// in order: accept test, then this call's select (k_select_warm; the accumulation when something of the call in front
+// could still read what it is about to overwrite)
 __device__ __forceinline__ int warm_front(const DevView& V, int w, bool fold_here, bool inline_select, long long list_cap,
                                           double (*red)[4], unsigned* lds_u, unsigned& bin_out, long long& rank_out,
                                           unsigned& in_bin_out) {
-    WinScalars& sc = V.sc[w];
-    const int t = threadIdx.x;
-    const int par = V.par;
-    const int64_t count = 2 * (int64_t)V.m[w];
-    const unsigned* h0 = hist0_of(V, w, par);
-    const unsigned long long lo = sc.warm_lo[par];
     unsigned hloc[8];
-    select_load(h0, kSelBins, hloc);        // in flight while the accept test is evaluated
+    select_load(hist0_of(V, w, V.par), kSelBins, hloc);        // in flight while the accept test is evaluated
     if (fold_here) {
-        const DecideOut d = decide_eval(V, w, par ^ 1, V.prev, 0, 0.0, nullptr, 0, red);
-        if (!d.accept || (d.flags & (2u | 8u | 32u))) return kWarmSkip;     // not a clean first trial: the host finishes that call
-        if (blockIdx.x == 0) {
-            const double lam32 = sc.lam32;      // of the decided call's solve
-            if (t < 81) sc.last_hessian[t] = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
-            if (t == 0) {
-                sc.lam[par] = d.lam_out;
-                sc.sum_in[par] = d.sum_next;
-                sc.init_residual = d.init_residual;
-                sc.trial_residual = d.residual;
-                sc.call_idx = V.call;
-                WinHead& hh = V.host_head[w];
-                hh.lamda = d.lam_out;
-                hh.trial_residual = d.residual;
-                hh.n_trials = 1;
-                hh.flags = d.flags;
-                hh.done = 1;
-                hh.call_idx = V.call;
-            }
-        }
+        DecideOut d;
+        if (!fold_decide(V, w, red, d)) return kWarmSkip;      // not a clean first trial: the host finishes that call
+        if (blockIdx.x == 0) fold_commit(V, w, d);
     }
-    unsigned long long prefix;
-    long long rank;
-    unsigned in_bin;
-    select_resolve_loaded(hloc, kSelBins, 11, 0ull, (count - 1) / 2, prefix, rank, lds_u, &in_bin);
-    const unsigned bin = (unsigned)prefix;
-    const bool hit = lo != ~0ull && bin >= 1u && bin <= 2046u && (int64_t)in_bin <= list_cap && !V.warm_force_miss;
-    if (blockIdx.x == 0 && t == 0) {
-        begin_call_scalars(sc, par, inline_select);
-        if (hit) {
-            sc.sel_mode = 1;
-            sc.sel_rank[2] = rank;
-            sc.warm_base = lo + ((unsigned long long)(bin - 1u) << V.warm_shift);
-            if (inline_select) sc.sel_cnt = in_bin;
-        } else {
-            sc.miss = 1;
-            sc.fl[par] = 32u;
-            V.host_head[w].flags = 32u;
-            V.host_head[w].done = 0;
-        }
-    }
-    bin_out = bin;
-    rank_out = rank;
-    in_bin_out = in_bin;
+    const bool hit = front_resolve(V, w, hloc, list_cap, lds_u, bin_out, rank_out, in_bin_out);
+    if (blockIdx.x == 0 && threadIdx.x == 0) front_commit(V, w, hit, bin_out, rank_out, in_bin_out, inline_select);
     return hit ? kWarmHit : kWarmMiss;
 }
 
@@ -442,11 +454,18 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     // (warm_front) and go on only if that first trial was cleanly accepted.
     const bool fold_here = V.sel_inline && V.call >= 0 && V.fold && sc.pending == V.call - 1 && sc.call_idx == V.call - 1;
     if (!fold_here) VBA_SKIP_CALL(V, w);
+    // The accept test only GATES: nothing this kernel computes depends on it.  So it is evaluated at the END, behind the
+    // accumulation, and a trial that turns out not to be clean just leaves no trace -- what this kernel writes on the way
+    // (weights, per-pose sums) lives per call parity, the later trials of the call in front still find theirs.  Only the
+    // chunk elimination that forms its blocks from this call's scratch (vba_set_fusion bit 1) needs the old order.
+    const bool ordered = V.fuse_blocks != 0;
     const int nb_acc = (V.n_max * G + 255) / 256;
     if ((int)blockIdx.x >= nb_acc) {        // few windows: the dynamics factor rides in this grid (vba_dyn_body.h)
-        if (fold_here) {    // (a function of the input states only: a missed select does not concern it)
-            const DecideOut d = decide_eval(V, w, V.par ^ 1, V.prev, 0, 0.0, nullptr, 0, dec_red);
-            if (!d.accept || (d.flags & (2u | 8u | 32u))) return;
+        // (a function of the input states only: neither a missed select nor, by default, the accept test concerns it --
+        // what it writes is read by this call's own assembly, which runs only if the window has moved on)
+        if (fold_here && ordered) {
+            DecideOut d;
+            if (!fold_decide(V, w, dec_red, d)) return;
         }
         dynamics_block(V, w, blockIdx.x - nb_acc);
         return;
@@ -502,18 +521,35 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 
     // Phase 2: the median (every block of the window finishes the select itself, see select_finish)
     RobustParams rp;
+    unsigned sel_bin = 0u, sel_in_bin = 0u;
+    long long sel_rank = 0;
     if (V.sel_inline) {
         // the trial kernel of the call in front dropped every key into the bucket of its warm bin: resolve the histogram,
         // rank the wanted bin's bucket.  Every block does this redundantly (a few hundred keys), nothing is compacted.
         unsigned bin, in_bin;
         long long rank;
-        if (warm_front(V, w, fold_here, true, V.bucket_cap, dec_red, sel_u, bin, rank, in_bin) != kWarmHit) return;
+        if (ordered) {
+            if (warm_front(V, w, fold_here, true, V.bucket_cap, dec_red, sel_u, bin, rank, in_bin) != kWarmHit) return;
+        } else {
+            unsigned hloc[8];
+            select_load(hist0_of(V, w, V.par), kSelBins, hloc);
+            if (!front_resolve(V, w, hloc, V.bucket_cap, sel_u, bin, rank, in_bin)) {      // a miss: nothing to hide the test behind
+                DecideOut d;
+                if (fold_here && !fold_decide(V, w, dec_red, d)) return;
+                if (blockIdx.x == 0) {
+                    if (fold_here) fold_commit(V, w, d);
+                    if (threadIdx.x == 0) front_commit(V, w, false, bin, rank, in_bin, true);
+                }
+                return;
+            }
+            sel_bin = bin; sel_rank = rank; sel_in_bin = in_bin;
+        }
         const unsigned long long lo = sc.warm_lo[V.par];
         const double* bucket = V.wbucket + (((size_t)w * 2 + V.par) * kSelBins + bin) * (size_t)V.bucket_cap;
         rp.c = select_finish_list(V, w, bucket, V.bucket_cap, in_bin, rank, 1, lo + ((unsigned long long)(bin - 1u) << V.warm_shift), false,
                                   sel_lh, sel_u, sel_keys);
         // (the histogram is still being read by the other blocks: the trial kernel of this call clears it)
-        if (blockIdx.x == 0 && threadIdx.x == 0) sc.c_obs = rp.c;
+        if (ordered && blockIdx.x == 0 && threadIdx.x == 0) sc.c_obs = rp.c;
     } else {
         rp.c = select_finish(V, w, sel_lh, sel_u, sel_keys);
         if (blockIdx.x == 0) {
@@ -666,6 +702,17 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             const int q = own + j;
             if (q < 21) H[q] = acc[j];
             else if (q < 27) B[q - 21] = acc[j];
+        }
+    }
+    if (V.sel_inline && !ordered) {     // the deferred accept test and what this call's start leaves in the scalars
+        DecideOut d;
+        if (fold_here && !fold_decide(V, w, dec_red, d)) return;        // not clean: no trace (the window stalls at the call in front)
+        if (blockIdx.x == 0) {
+            if (fold_here) fold_commit(V, w, d);
+            if (threadIdx.x == 0) {
+                front_commit(V, w, true, sel_bin, sel_rank, sel_in_bin, true);
+                sc.c_obs = rp.c;
+            }
         }
     }
     wmax_l = wave_max(wmax_l);

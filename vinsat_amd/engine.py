@@ -75,9 +75,11 @@ class BAEngine:
         _lib.check(self.lib.vba_set_chunk_waves(self.h, int(waves)), self.lib)
 
     def set_warm_select(self, on):
-        """True (default): carried keys are selected with one warm pass (and chained calls fold their accept test into it);
-        False: exact digit passes and a decide launch per call."""
-        _lib.check(self.lib.vba_set_warm_select(self.h, 2 if on == 2 else int(bool(on))), self.lib)
+        """True / 1 (default): carried keys are selected warm -- from the bucket of one warm bin inside the accumulation
+        (latency mode), by one warm pass otherwise -- and chained calls fold their accept test into that; False / 0: exact
+        digit passes and a decide launch per call; 2: every warm select is forced to miss (test knob); 3: the warm select
+        stays a kernel of its own."""
+        _lib.check(self.lib.vba_set_warm_select(self.h, int(on) if int(on) in (2, 3) else int(bool(on))), self.lib)
 
     def warm_select_misses(self):
         c = c_int()
