@@ -27,39 +27,57 @@ struct DecideOut {
     double sum_next;            // sum |r_obs| at the trial states (carried keys)
 };
 
-// pc: parity of the decided call; prm: ITS per-call constants; n_trials_in / init_prev: trials already counted and the
-// initial residual recorded by the first of them.  red: [5][4] doubles of LDS.  All 256 threads return the same values.
-__device__ __forceinline__ DecideOut decide_eval(const DevView& V, int w, int pc, const StepParams& prm, int n_trials_in,
-                                                 double init_prev, const double* trial_all, int ranks, double (*red)[4]) {
+// What a thread reads for the test: its share of the block partials and the scalars of the decided call.  Loaded apart from
+// the evaluation so that a caller can have the loads in flight while it does something else (k_obs_accumulate).
+struct DecideIn {
+    double s_pred, s_trial, s_next, s_prior, lam_in, so;
+    unsigned flags;
+};
+
+// pc: parity of the decided call; prm: ITS per-call constants
+__device__ __forceinline__ DecideIn decide_load(const DevView& V, int w, int pc, const StepParams& prm, int ranks) {
     const WinScalars& sc = V.sc[w];
     const int t = threadIdx.x;
-    const int n = V.n[w], m = V.m[w];
     const bool reg = V.reg && !prm.initialize;
-    double s_pred = 0.0, s_trial = 0.0, s_next = 0.0, s_prior = 0.0;
+    DecideIn in;
+    in.s_pred = in.s_trial = in.s_next = in.s_prior = 0.0;
     if (!prm.initialize) {
         const double* pp = V.part_pred + ((size_t)w * 2 + pc) * V.nblk_pred;
-        for (int b = t; b < V.nblk_pred; b += 256) s_pred += pp[b];
+        for (int b = t; b < V.nblk_pred; b += 256) in.s_pred += pp[b];
         if (reg) {
             const double* pq = V.part_prior + ((size_t)w * 2 + pc) * V.nblk_pred;
-            for (int b = t; b < V.nblk_pred; b += 256) s_prior += pq[b];
+            for (int b = t; b < V.nblk_pred; b += 256) in.s_prior += pq[b];
         }
     }
     if (ranks == 0) {
         const double* pt = V.part_trial + (size_t)w * V.trial_stride;
-        for (int b = t; b < V.nblk_obs + V.nblk_dyn; b += 256) s_trial += pt[b];
+        for (int b = t; b < V.nblk_obs + V.nblk_dyn; b += 256) in.s_trial += pt[b];
     }
     if (V.emit) {
         const double* pn = V.part_next + (size_t)w * V.nblk_obs;
-        for (int b = t; b < V.nblk_obs; b += 256) s_next += pn[b];
+        for (int b = t; b < V.nblk_obs; b += 256) in.s_next += pn[b];
     }
-    const double lam_in = sc.lam[pc], so = sc.sum_in[pc];
-    const unsigned flags = sc.fl[pc];
+    in.lam_in = sc.lam[pc];
+    in.so = sc.sum_in[pc];
+    in.flags = sc.fl[pc];
+    return in;
+}
+
+// n_trials_in / init_prev: trials already counted and the initial residual recorded by the first of them.
+// red: [5][4] doubles of LDS.  All 256 threads return the same values.
+__device__ __forceinline__ DecideOut decide_finish(const DevView& V, int w, const DecideIn& in, const StepParams& prm, int n_trials_in,
+                                                   double init_prev, const double* trial_all, int ranks, double (*red)[4]) {
+    const int t = threadIdx.x;
+    const int n = V.n[w], m = V.m[w];
+    const bool reg = V.reg && !prm.initialize;
+    const double lam_in = in.lam_in, so = in.so;
+    const unsigned flags = in.flags;
     double sh_trial = 0.0;
     if (ranks > 0) {        // sharded: rank-ordered sum of the gathered per-rank sums; every rank holds the same dynamics part
         sh_trial = trial_all[1];
         for (int q = 0; q < ranks; ++q) sh_trial += trial_all[2 * q];
     }
-    const double v4[4] = {wave_sum(s_pred), wave_sum(s_trial), wave_sum(s_next), wave_sum(s_prior)};
+    const double v4[4] = {wave_sum(in.s_pred), wave_sum(in.s_trial), wave_sum(in.s_next), wave_sum(in.s_prior)};
     __syncthreads();        // red may still be read from a previous use
     if ((t & 63) == 0) {
 #pragma unroll
@@ -89,6 +107,12 @@ __device__ __forceinline__ DecideOut decide_eval(const DevView& V, int w, int pc
     o.lam_out = fmax(fmin(1e-1, o.lam_next * 0.01), 1e-4);
     o.sum_next = tot[2];
     return o;
+}
+
+__device__ __forceinline__ DecideOut decide_eval(const DevView& V, int w, int pc, const StepParams& prm, int n_trials_in,
+                                                 double init_prev, const double* trial_all, int ranks, double (*red)[4]) {
+    const DecideIn in = decide_load(V, w, pc, prm, ranks);
+    return decide_finish(V, w, in, prm, n_trials_in, init_prev, trial_all, ranks, red);
 }
 
 }  // namespace vba

@@ -209,6 +209,12 @@ __device__ __forceinline__ bool fold_decide(const DevView& V, int w, double (*re
     d = decide_eval(V, w, V.par ^ 1, V.prev, 0, 0.0, nullptr, 0, red);
     return d.accept && !(d.flags & (2u | 8u | 32u));
 }
+// ... with its inputs loaded earlier (fold_load)
+__device__ __forceinline__ DecideIn fold_load(const DevView& V, int w) { return decide_load(V, w, V.par ^ 1, V.prev, 0); }
+__device__ __forceinline__ bool fold_decide_loaded(const DevView& V, int w, const DecideIn& in, double (*red)[4], DecideOut& d) {
+    d = decide_finish(V, w, in, V.prev, 0, 0.0, nullptr, 0, red);
+    return d.accept && !(d.flags & (2u | 8u | 32u));
+}
 // ... and what a clean one leaves behind (block 0 only): the window moves on to this call
 __device__ __forceinline__ void fold_commit(const DevView& V, int w, const DecideOut& d) {
     WinScalars& sc = V.sc[w];
@@ -523,6 +529,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     RobustParams rp;
     unsigned sel_bin = 0u, sel_in_bin = 0u;
     long long sel_rank = 0;
+    DecideIn fold_in = {};
     if (V.sel_inline) {
         // the trial kernel of the call in front dropped every key into the bucket of its warm bin: resolve the histogram,
         // rank the wanted bin's bucket.  Every block does this redundantly (a few hundred keys), nothing is compacted.
@@ -533,9 +540,10 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
         } else {
             unsigned hloc[8];
             select_load(hist0_of(V, w, V.par), kSelBins, hloc);
+            if (fold_here) fold_in = fold_load(V, w);       // in flight until the end of the kernel
             if (!front_resolve(V, w, hloc, V.bucket_cap, sel_u, bin, rank, in_bin)) {      // a miss: nothing to hide the test behind
                 DecideOut d;
-                if (fold_here && !fold_decide(V, w, dec_red, d)) return;
+                if (fold_here && !fold_decide_loaded(V, w, fold_in, dec_red, d)) return;
                 if (blockIdx.x == 0) {
                     if (fold_here) fold_commit(V, w, d);
                     if (threadIdx.x == 0) front_commit(V, w, false, bin, rank, in_bin, true);
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     }
     if (V.sel_inline && !ordered) {     // the deferred accept test and what this call's start leaves in the scalars
         DecideOut d;
-        if (fold_here && !fold_decide(V, w, dec_red, d)) return;        // not clean: no trace (the window stalls at the call in front)
+        if (fold_here && !fold_decide_loaded(V, w, fold_in, dec_red, d)) return;    // not clean: no trace (the window stalls at the call in front)
         if (blockIdx.x == 0) {
             if (fold_here) fold_commit(V, w, d);
             if (threadIdx.x == 0) {
