@@ -507,6 +507,14 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     // Software pipelined: the loads of the next observations are in flight while the current ones are processed (the
     // kernel sits at 2 waves per SIMD because of its accumulators either way; the registers between that and the next
     // occupancy step are spent on memory-level parallelism).
+    // (inline select: the histogram and the inputs of the deferred accept test are requested first of all -- they depend on
+    // nothing, the row range below is a dependent round trip)
+    unsigned hloc[8] = {};
+    DecideIn fold_in = {};
+    if (V.sel_inline && !ordered) {
+        select_load(hist0_of(V, w, V.par), kSelBins, hloc);
+        if (fold_here) fold_in = fold_load(V, w);       // in flight until the end of the kernel
+    }
     PoseCam pc{};
     int beg = 0, end = 0;
     Obs ring[kAccDepth]{};
@@ -529,7 +537,6 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     RobustParams rp;
     unsigned sel_bin = 0u, sel_in_bin = 0u;
     long long sel_rank = 0;
-    DecideIn fold_in = {};
     if (V.sel_inline) {
         // the trial kernel of the call in front dropped every key into the bucket of its warm bin: resolve the histogram,
         // rank the wanted bin's bucket.  Every block does this redundantly (a few hundred keys), nothing is compacted.
@@ -538,9 +545,6 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
         if (ordered) {
             if (warm_front(V, w, fold_here, true, V.bucket_cap, dec_red, sel_u, bin, rank, in_bin) != kWarmHit) return;
         } else {
-            unsigned hloc[8];
-            select_load(hist0_of(V, w, V.par), kSelBins, hloc);
-            if (fold_here) fold_in = fold_load(V, w);       // in flight until the end of the kernel
             if (!front_resolve(V, w, hloc, V.bucket_cap, sel_u, bin, rank, in_bin)) {      // a miss: nothing to hide the test behind
                 DecideOut d;
                 if (fold_here && !fold_decide_loaded(V, w, fold_in, dec_red, d)) return;
