@@ -655,9 +655,11 @@ namespace {
 // The kernels of a call, as the host enqueues them (all asynchronous on the handle's stream):
 //
 //   front   [k_obs_residual]                     only when the host replaced the states (no carried keys)
-//           select                               exact digits (2 passes; 3 when digit 0 is not there yet), or on carried
-//                                                keys ONE warm pass (k_select_warm) -- whose prologue, in a chained
-//                                                schedule, is the accept test of the call in front (fold)
+//           [select]                             exact digits (2 passes; 3 when digit 0 is not there yet); on carried keys
+//                                                ONE warm pass (k_select_warm) -- or, latency mode, nothing: the keys lie
+//                                                in per-bin buckets and the accumulation selects in its prologue.  In a
+//                                                chained schedule the kernel that starts the call also evaluates the
+//                                                accept test of the call in front (fold)
 //           k_obs_accumulate (+ dynamics blocks) median finish, weights, per-pose normal equations [+ orbit / attitude factor]
 //           [k_assemble]                         only when something reads the bands from memory: batched windows, sharded
 //                                                mode, the sequential / always-pivoting solvers
@@ -667,7 +669,7 @@ namespace {
 //           k_trial                              step + retraction (latency mode) + trial residuals + next call's keys
 //   decide  [k_decide]                           own launch unless the next call's first kernel folds it
 //
-// Latency mode, landmark-only call: 3 kernels (warm select, accumulate, trial); full call: 6 (+ chunks, two
+// Latency mode, landmark-only call: 2 kernels (accumulate, trial); full call: 6 (+ assembly, chunks, two
 // cyclic-reduction kernels).  Call parity p: input states S[p], trial states S[p ^ 1] (see WinScalars).
 struct CallSpec {
     int iter = 0, initialize = 0;
