@@ -1377,3 +1377,35 @@ def test_two_sided_chunk_elimination_vs_one_wave(c2, chunk, pivot):
         assert rel_err(outs[1][0], outs[0][0]) < 1e-7
         if conf is inp["conf"]:
             assert rel_err(steps[1], g["dpose_10"][0].reshape(n, 9)) < (DPOSE_TOL_PIVOTED if pivot else DPOSE_TOL)
+
+
+@pytest.mark.parametrize("reg", [False, True])
+@pytest.mark.parametrize("windows", [1, 16])
+def test_uniform_pass_assembly_gives_the_bits_of_the_per_entry_form(c2, reg, windows):
+    """Full-phase assembly: one wave per pose in seven uniform passes (vba_asm_fast.h, vba_set_fusion bit 3) against the
+    per-entry form (band_entry / rhs_entry per thread, default): every band entry, the right-hand side and the result of
+    the call, bit for bit -- latency and batched geometry, plain BA and BA_reg (prior terms)."""
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    gr = load_golden("reg_c2")
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    outs = []
+    for mask in (1, 9):
+        e = BAEngine(n, m, windows=windows)
+        e.set_fusion(mask)
+        for k in range(windows):
+            e.upload_observations(inp["xyz"], inp["uv"], inp["conf"] * (1.0 + 0.01 * k), inp["ii"], n, window=k)
+            e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"], window=k)
+            if reg:
+                e.upload_prior(gr["states_prior"][0], gr["hessian_state_t"][0] * (1.0 + 0.1 * k), window=k)
+            e.set_states(g["states_out_9"][0], float(g["lamda_in"][10]), window=k)
+        e.set_prior(reg)
+        e.step(10, False)
+        e.step(11, False)
+        wl = windows - 1
+        outs.append((e.debug("bands", window=wl), e.debug("rhs", window=wl), e.get_states(window=wl), e.debug("bands", window=0)))
+        e.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][2], b[2][2]) and a[2][1] == b[2][1]
+    assert np.abs(a[0]).max() > 0 and np.abs(a[0][:, 0]).max() > 0 and np.abs(a[0][:, 2]).max() > 0     # off-diagonal bands are populated

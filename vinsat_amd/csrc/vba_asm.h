@@ -48,6 +48,29 @@ __device__ __forceinline__ void asm_stage(const DevView& V, int w, int n, bool d
     }
 }
 
+// The same with the slot count known at compile time: all loads of a thread are issued before its first store (the loop
+// above waits for every load in turn -- one round trip per element and thread; the assembly kernels were bound by that).
+template <bool REG, int SLOTS, int NTHREADS>
+__device__ __forceinline__ void asm_stage_all(const DevView& V, int w, int n, bool dyn, int first, double* in, int tid) {
+    constexpr int kAsmIn = kAsmBase + (REG ? kAsmPrior : 0);
+    constexpr int kTotal = SLOTS * kAsmIn;
+    constexpr int kIter = (kTotal + NTHREADS - 1) / NTHREADS;
+    const size_t sb = (size_t)w * V.n_max;
+    double v[kIter];
+#pragma unroll
+    for (int k = 0; k < kIter; ++k) {
+        const int e = tid + k * NTHREADS;
+        const int slot = e / kAsmIn, q = e % kAsmIn;
+        const int i = first + slot;
+        v[k] = (e < kTotal && i >= 0 && i < n) ? asm_input<REG>(V, sb + i, q, dyn) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kIter; ++k) {
+        const int e = tid + k * NTHREADS;
+        if (e < kTotal) in[e] = v[k];
+    }
+}
+
 // row i of the system from the staged inputs of pose i (`me`) and pose i - 1 (`pv`)
 template <bool REG>
 __device__ __forceinline__ AsmRow asm_row(const double* me, const double* pv, int i, int n, bool dyn, double sigma, double inv_wmax) {

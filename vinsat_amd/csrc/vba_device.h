@@ -110,6 +110,7 @@ struct DevView {
     int bucket_cap;
     int sel_inline;                 // this call's accumulation starts the call: inline warm select on the buckets (+ folded accept test)
     int chunk_waves;                // partitioned solve: waves per chunk (2: eliminated from both ends, vba_set_chunk_waves)
+    int asm_rows;                   // full-phase assembly in uniform passes (vba_asm_fast.h; vba_set_fusion bit 3)
     int fuse_walk;                  // batched mode: the sequential walk forms the blocks itself (vba_set_fusion bit 2)
     int warm_shift;                 // log2 of the bit-pattern width of a warm bin
     int warm_force_miss;            // test knob: every warm select reports a miss (exercises the repeat with the exact digits)

@@ -6,6 +6,7 @@
 // (8 lanes per pose: lanes 0-5 one tangent each, lane 6 the attitude term), so only the 6x6 block that is
 // actually non-zero is ever produced.
 #include "vba_asm.h"
+#include "vba_asm_fast.h"
 #include "vba_device.h"
 #include "vba_dyn_body.h"
 #include "vba_launch.h"
@@ -209,6 +210,42 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     }
 }
 
+// Full-phase assembly, one wave per pose in seven uniform passes (vba_asm_fast.h): same staging, same entries to the bit,
+// about a third of the instructions of k_assemble's per-entry form -- which was VALU-bound, not bandwidth-bound.
+template <int kAsmPoses, bool REG>
+__global__ __launch_bounds__(256) void k_assemble_rows(DevView V) {
+    constexpr int kAsmIn = kAsmBase + (REG ? kAsmPrior : 0);
+    __shared__ double in[(kAsmPoses + 1) * kAsmIn];
+    const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
+    const int n = V.n[w];
+    const int i0 = blockIdx.x * kAsmPoses;
+    if (i0 >= n) return;
+    const size_t sb = (size_t)w * V.n_max;
+    asm_stage_all<REG, kAsmPoses + 1, 256>(V, w, n, true, i0 - 1, in, threadIdx.x);
+    __syncthreads();
+    const double inv_wmax = 1.0 / bits_f64(V.sc[w].wmax_bits[V.par]);
+    const double sigma = V.prm.sigma;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const AsmLanes g = asm_lanes(lane);
+    const int cnt = min(kAsmPoses, n - i0);
+    for (int p = wave; p < cnt; p += 4) {
+        const int i = i0 + p;
+        double* bands = V.bands + (sb + i) * 243;
+        double* rhs = V.rhs + (sb + i) * 9;
+        double* lastD = i == n - 1 ? V.lastD + (size_t)w * 81 : nullptr;      // BA_filtering.py:97
+        asm_form_row<REG>(g, in + (size_t)(p + 1) * kAsmIn, in + (size_t)p * kAsmIn, i < n - 1, i > 0, sigma, inv_wmax, lane,
+                          [&](int e, double v) {
+                              if (e < 243) {
+                                  bands[e] = v;
+                                  if (lastD && e >= 81 && e < 162) lastD[e - 81] = v;
+                              } else {
+                                  rhs[e - 243] = v;
+                              }
+                          });
+    }
+}
+
 void launch_dynamics(const DevView& V, hipStream_t s) {
     if (V.W >= 16) {
         hipLaunchKernelGGL(k_dynamics_pair, dim3((V.n_max + 127) / 128, V.W), dim3(256), 0, s, V);
@@ -223,15 +260,22 @@ void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s) {
 #define VBA_ASM_BATCHED 16
 #endif
     const bool reg = V.reg && !V.prm.initialize;
+    const bool rows = !V.prm.initialize && !fuse_init_solve && V.asm_rows;     // full phase: the uniform-pass form
     if (V.W >= 16) {
         constexpr int P = VBA_ASM_BATCHED;
         const dim3 g((V.n_max + P - 1) / P, V.W);
-        if (fuse_init_solve) hipLaunchKernelGGL((k_assemble<true, P, false>), g, dim3(256), 0, s, V);
+        if (rows) {
+            if (reg) hipLaunchKernelGGL((k_assemble_rows<P, true>), g, dim3(256), 0, s, V);
+            else hipLaunchKernelGGL((k_assemble_rows<P, false>), g, dim3(256), 0, s, V);
+        } else if (fuse_init_solve) hipLaunchKernelGGL((k_assemble<true, P, false>), g, dim3(256), 0, s, V);
         else if (reg) hipLaunchKernelGGL((k_assemble<false, P, true>), g, dim3(256), 0, s, V);
         else hipLaunchKernelGGL((k_assemble<false, P, false>), g, dim3(256), 0, s, V);
     } else {
         const dim3 g((V.n_max + 3) / 4, V.W);
-        if (fuse_init_solve) hipLaunchKernelGGL((k_assemble<true, 4, false>), g, dim3(256), 0, s, V);
+        if (rows) {
+            if (reg) hipLaunchKernelGGL((k_assemble_rows<4, true>), g, dim3(256), 0, s, V);
+            else hipLaunchKernelGGL((k_assemble_rows<4, false>), g, dim3(256), 0, s, V);
+        } else if (fuse_init_solve) hipLaunchKernelGGL((k_assemble<true, 4, false>), g, dim3(256), 0, s, V);
         else if (reg) hipLaunchKernelGGL((k_assemble<false, 4, true>), g, dim3(256), 0, s, V);
         else hipLaunchKernelGGL((k_assemble<false, 4, false>), g, dim3(256), 0, s, V);
     }

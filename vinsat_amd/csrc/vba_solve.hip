@@ -24,6 +24,7 @@
 //                      wave, and the interiors are recovered in parallel: ~ n/P + P sequential block steps
 //                      instead of n.
 #include "vba_asm.h"
+#include "vba_asm_fast.h"
 #include "vba_decide.h"
 #include "vba_device.h"
 #include "vba_launch.h"
@@ -269,15 +270,11 @@ __device__ __forceinline__ void chain_solve(const Src& src, int n, double lam32,
 #pragma unroll
             for (int r = 0; r < 9; ++r) z[r] = a[r];
         }
-        if (late) {
-            if (i + 1 < n) {    // one entry at a time, straight into the other buffer: keeps the register count of the plain walk
-#pragma unroll 1
-                for (int q = 0; q < 4; ++q) {
-                    const int e = lane + 64 * q;
-                    blk[buf ^ 1][e] = e < 252 ? src(i + 1, e) : 0.0;
-                }
-            }
-        } else if (i + 1 < n) stash(buf ^ 1);
+        if constexpr (late) {
+            if (i + 1 < n) src.form(i + 1, blk[buf ^ 1]);       // the whole block in uniform passes, straight into the other buffer
+        } else {
+            if (i + 1 < n) stash(buf ^ 1);
+        }
         src_commit(src, i + 2, 0);
         __syncthreads();
     }
@@ -368,6 +365,7 @@ struct RawSource {
     int n, lane;
     double sigma, inv_wmax;
     double* ring;               // [3][kIn]: pose i lives in slot i % 3
+    AsmLanes lanes;
     mutable double hold[kPer];
     __device__ void prefetch(int i) const {
         if (i >= n) return;
@@ -391,6 +389,11 @@ struct RawSource {
         if (e >= 243) return rhs_entry(R, e - 243);
         return band_entry(R, e / 81, (e % 81) / 9, e % 9);
     }
+    // all 252 entries of block i into out (LDS), seven uniform passes of the wave (vba_asm_fast.h)
+    __device__ void form(int i, double* out) const {
+        asm_form_row<REG>(lanes, ring + (i % 3) * kIn, ring + ((i + 2) % 3) * kIn, i < n - 1, i > 0, sigma, inv_wmax, lane,
+                          [&](int e, double v) { out[e] = v; });
+    }
 };
 
 template <bool PIVOT, bool REG>
@@ -410,9 +413,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
     }
     bool badp = false;
-    const RawSource<REG> src{V, sb, n, lane, V.prm.sigma, 1.0 / bits_f64(sc.wmax_bits[V.par]), ring, {}};
+    const RawSource<REG> src{V, sb, n, lane, V.prm.sigma, 1.0 / bits_f64(sc.wmax_bits[V.par]), ring, asm_lanes(lane), {}};
     src.prefetch(0); src.commit(0);
     src.prefetch(1); src.commit(1);
+    for (int e = lane; e < 512; e += 64) (&blk[0][0])[e] = 0.0;     // (entries 252 .. 255 of a buffer are never formed)
     __syncthreads();
     chain_solve<PIVOT, true>(src, n, lam32, V.Xs + sb * 81, V.zs + sb * 9, V.dpose + sb * 9, blk, lane, badp);
     // the ring still holds poses n-3 .. n-1: the last diagonal block leaves for last_hessian (BA_filtering.py:97)
