@@ -210,6 +210,51 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     }
 }
 
+// Landmark-only phase, first LM trial, unpivoted path, MANY windows: the step of every pose straight from its per-pose sums,
+// one THREAD per pose (step_blockdiag6, vba_step.h: the 6x6 Gauss-Jordan in registers, then the retraction).  With millions of
+// poses per launch what counts is instructions per pose: the 16-lanes-per-pose form of the latency mode (k_assemble<FUSE>)
+// spends a wave on 4 poses and runs the retraction in one lane of sixteen.  Same arithmetic per element, same bits.
+__global__ __launch_bounds__(256) void k_init_step(DevView V) {
+    const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
+    const int n = V.n[w];
+    if ((int)blockIdx.x * 256 >= n) return;
+    WinScalars& sc = V.sc[w];
+    const size_t sb = (size_t)w * V.n_max;
+    const double lam32 = (double)(float)sc.lam[V.par];      // torch.eye() is float32 (BA_filtering.py:54)
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc.lam32 = lam32;
+    const double inv_wmax = 1.0 / bits_f64(sc.wmax_bits[V.par]);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    bool badpiv = false, badnum = false;
+    if (live) {
+        double H[21], b[6], d9[9], o[10];
+        const double* Hg = V.Hraw + (sb + i) * 21;
+        const double* bg = V.braw + (sb + i) * 6;
+#pragma unroll
+        for (int q = 0; q < 21; ++q) H[q] = Hg[q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) b[q] = bg[q];
+        if (!step_blockdiag6(H, b, inv_wmax, lam32, d9)) badpiv = true;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            badnum |= !(fabs(d9[r]) <= 1.79e308);
+            V.dpose[(sb + i) * 9 + r] = d9[r];
+        }
+        retract(V.states + (sb + i) * 10, d9, o);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) V.states_new[(sb + i) * 10 + r] = o[r];
+        if (i == n - 1) {       // the last pose's diagonal block leaves for last_hessian (BA_filtering.py:97; band_entry, no dynamics)
+            for (int e = 0; e < 81; ++e) {
+                const int a = e / 9, c = e % 9;
+                V.lastD[(size_t)w * 81 + e] = (a < 6 && c < 6) ? Hg[sym6(a, c)] * inv_wmax : 0.0;
+            }
+        }
+    }
+    const unsigned long long bp = __ballot(badpiv), bn = __ballot(badnum);
+    if ((threadIdx.x & 63) == 0 && (bp || bn)) atomicOr(&sc.fl[V.par], (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
+}
+
 // Full-phase assembly, one wave per pose in seven uniform passes (vba_asm_fast.h): same staging, same entries to the bit,
 // about a third of the instructions of k_assemble's per-entry form -- which was VALU-bound, not bandwidth-bound.
 template <int kAsmPoses, bool REG>
@@ -260,6 +305,10 @@ void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s) {
 #define VBA_ASM_BATCHED 16
 #endif
     const bool reg = V.reg && !V.prm.initialize;
+    if (fuse_init_solve && V.W >= 16) {     // (few windows: the 16-lanes-per-pose form below, latency)
+        hipLaunchKernelGGL(k_init_step, dim3((V.n_max + 255) / 256, V.W), dim3(256), 0, s, V);
+        return;
+    }
     const bool rows = !V.prm.initialize && !fuse_init_solve && V.asm_rows;     // full phase: the uniform-pass form
     if (V.W >= 16) {
         constexpr int P = VBA_ASM_BATCHED;
