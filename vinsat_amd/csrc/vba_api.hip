@@ -57,6 +57,7 @@ struct vba_context {
     // per-observation weights and per-pose normal equations exist per call parity (DevView points at the slot of the call):
     // the accumulation of call c + 1 starts before the accept test of call c is known, whose later trials still read them
     double *wraw2 = nullptr, *Hraw2 = nullptr, *braw2 = nullptr;
+    double* dyn2[8] = {};           // xhat, Phi, rorb, fatt, qgrad, Hd, Hu, Hl
     double* d_obs = nullptr;                // observation blocks, [W][obs_stride] (layout: DevView::ox)
     int64_t m_pad = 0;                      // doubles per observation array inside a block
     double *d_intr = nullptr, *d_cumrot = nullptr;
@@ -208,7 +209,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
         while (bucket_cap < expect && bucket_cap < 4096) bucket_cap *= 2;
         need(W * 2 * (size_t)kSelBins * bucket_cap * 8);
     }
-    const size_t per_pose = 2 * (21 + 6) + 6 + 36 + 6 + 1 + 3 + 9 + 9 + 9 + 243 + 9 + 81 + 9 + 9;
+    const size_t per_pose = 2 * (21 + 6) + 2 * (6 + 36 + 6 + 1 + 3 + 9 + 9 + 9) + 243 + 9 + 81 + 9 + 9;
     need(W * N * per_pose * 8 + 16 * 256);
     need(W * N * 171 * 8);
     need(W * N * (171 + 171 + 81 + 9 + 9) * 8 + 6 * 256);
@@ -256,9 +257,10 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.bucket_cap = bucket_cap;
     V.sel_inline = 0;
     V.Hraw = h->Hraw2 = A.take<double>(2 * W * N * 21); V.braw = h->braw2 = A.take<double>(2 * W * N * 6);
-    V.xhat = A.take<double>(W * N * 6); V.Phi = A.take<double>(W * N * 36); V.rorb = A.take<double>(W * N * 6);
-    V.fatt = A.take<double>(W * N); V.qgrad = A.take<double>(W * N * 3);
-    V.Hd = A.take<double>(W * N * 9); V.Hu = A.take<double>(W * N * 9); V.Hl = A.take<double>(W * N * 9);
+    // (the pose-chain factor's outputs: per call parity as well, see wraw2)
+    V.xhat = h->dyn2[0] = A.take<double>(2 * W * N * 6); V.Phi = h->dyn2[1] = A.take<double>(2 * W * N * 36); V.rorb = h->dyn2[2] = A.take<double>(2 * W * N * 6);
+    V.fatt = h->dyn2[3] = A.take<double>(2 * W * N); V.qgrad = h->dyn2[4] = A.take<double>(2 * W * N * 3);
+    V.Hd = h->dyn2[5] = A.take<double>(2 * W * N * 9); V.Hu = h->dyn2[6] = A.take<double>(2 * W * N * 9); V.Hl = h->dyn2[7] = A.take<double>(2 * W * N * 9);
     V.bands = A.take<double>(W * N * 243); V.rhs = A.take<double>(W * N * 9);
     V.Xs = A.take<double>(W * N * 81); V.zs = A.take<double>(W * N * 9); V.dpose = A.take<double>(W * N * 9);
     V.p_max = n_max / 2 + 1;
@@ -699,6 +701,11 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     V.wraw = h->wraw2 + (size_t)c.par * h->W * h->V.m_max;
     V.Hraw = h->Hraw2 + (size_t)c.par * h->W * h->n_max * 21;
     V.braw = h->braw2 + (size_t)c.par * h->W * h->n_max * 6;
+    {
+        const size_t wn = (size_t)c.par * h->W * h->n_max;
+        V.xhat = h->dyn2[0] + wn * 6; V.Phi = h->dyn2[1] + wn * 36; V.rorb = h->dyn2[2] + wn * 6; V.fatt = h->dyn2[3] + wn;
+        V.qgrad = h->dyn2[4] + wn * 3; V.Hd = h->dyn2[5] + wn * 9; V.Hu = h->dyn2[6] + wn * 9; V.Hl = h->dyn2[7] + wn * 9;
+    }
     V.states_new = h->S[c.par ^ 1];
     V.states_prev = h->S[c.par];
     V.emit = c.emit;

@@ -462,9 +462,9 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     if (!fold_here) VBA_SKIP_CALL(V, w);
     // The accept test only GATES: nothing this kernel computes depends on it.  So it is evaluated at the END, behind the
     // accumulation, and a trial that turns out not to be clean just leaves no trace -- what this kernel writes on the way
-    // (weights, per-pose sums) lives per call parity, the later trials of the call in front still find theirs.  Only the
-    // chunk elimination that forms its blocks from this call's scratch (vba_set_fusion bit 1) needs the old order.
-    const bool ordered = V.fuse_blocks != 0;
+    // (weights, per-pose sums, the pose-chain factor of its rider blocks) lives per call parity, the later trials of the
+    // call in front still find theirs.
+    constexpr bool ordered = false;     // (kept: the in-order form, accept test first, is warm_front as k_select_warm uses it)
     const int nb_acc = (V.n_max * G + 255) / 256;
     if ((int)blockIdx.x >= nb_acc) {        // few windows: the dynamics factor rides in this grid (vba_dyn_body.h)
         // (a function of the input states only: neither a missed select nor, by default, the accept test concerns it --

@@ -1079,6 +1079,70 @@ __global__ __launch_bounds__(256) void k_solve_chunks_fused(DevView V, int s) {
     report_pivot<PIVOT>(bad, sc, tid, V.par);
 }
 
+// The same with the two-sided elimination and the uniform-pass row former (vba_asm_fast.h): the four waves of the block form
+// the chunk's (at most s + 1) blocks in LDS -- one wave per pose row, seven uniform passes -- then waves 0 and 1 eliminate
+// from both ends.  No assembly launch in the full phase of the latency mode.
+__host__ __device__ constexpr int twosided_fused_lds_doubles(int s, bool reg) {
+    return twosided_lds_doubles(s) + (s + 1) * 252 + (s + 2) * (kAsmBase + (reg ? kAsmPrior : 0));
+}
+
+template <bool PIVOT, bool REG>
+__global__ __launch_bounds__(256) void k_solve_chunks_ts_fused(DevView V, int s) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int kAsmIn = kAsmBase + (REG ? kAsmPrior : 0);
+    const int w = blockIdx.y, c = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n = V.n[w];
+    if (c * s >= n) return;
+    const int tid = threadIdx.x;
+    const size_t sb = (size_t)w * V.n_max;
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lam[V.par];
+    if (c == 0 && tid == 0) {
+        sc.lam32 = lam32;
+        if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
+    }
+    int a0, b0;
+    bool has_sep;
+    chunk_range(c, s, n, a0, b0, has_sep);
+    const int j0 = a0 > 0 ? a0 - 1 : 0, j1 = has_sep ? b0 + 1 : b0;         // blocks formed here
+    const int nblk = j1 - j0 + 1;
+    double* elim = smem;                                                     // scratch of the elimination
+    double* blocks = smem + twosided_lds_doubles(s);                         // [s + 1][252]
+    double* in = blocks + (size_t)(s + 1) * 252;                             // [s + 2][kAsmIn]: poses j0 - 1 .. j1
+    asm_stage<REG>(V, w, n, true, j0 - 1, nblk + 1, in, tid, 256);
+    __syncthreads();
+    const double inv_wmax = 1.0 / bits_f64(sc.wmax_bits[V.par]);
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const AsmLanes g = asm_lanes(lane);
+        for (int q = wave; q < nblk; q += 4) {
+            const int i = j0 + q;
+            double* blk = blocks + (size_t)q * 252;
+            const bool sep = has_sep && i == j1, last = i == n - 1;
+            asm_form_row<REG>(g, in + (size_t)(q + 1) * kAsmIn, in + (size_t)q * kAsmIn, i < n - 1, i > 0, V.prm.sigma, inv_wmax, lane,
+                              [&](int e, double v) {
+                                  blk[e] = v;
+                                  // what later kernels read from memory: the right separator's diagonal block and right-hand side
+                                  // (reduced system), the last pose's diagonal block (last_hessian)
+                                  if (e >= 243) { if (sep) V.rhs[(sb + i) * 9 + (e - 243)] = v; }
+                                  else if (e >= 81 && e < 162) {
+                                      if (sep) V.bands[(sb + i) * 243 + e] = v;
+                                      if (last) V.lastD[(size_t)w * 81 + (e - 81)] = v;
+                                  }
+                              });
+        }
+    }
+    __syncthreads();
+    if (tid >= 128) return;     // the elimination is two waves' work (its barriers count the surviving waves only)
+    bool bad = false;
+    const LdsBlockSource src{blocks, j0};
+    chunk_eliminate_twosided<PIVOT, true>(src, n, s, c, lam32, V.csol + sb * 171, V.cL + rb * 171, V.cR + rb * 171, elim, tid, bad);
+    report_pivot<PIVOT>(bad, sc, tid & 63, V.par);
+}
+
 // level 2: the reduced system over the level-1 separators is itself cut into chunks of s2
 template <bool PIVOT>
 __global__ __launch_bounds__(64) void k_solve_chunks2(DevView V, int s, int s2) {
@@ -1672,7 +1736,12 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
     const int cs = V.chunk, cs2 = V.chunk2;
     const int P = (V.n_max + cs - 1) / cs;
     const size_t lds = (512 + (size_t)cs * 252 + 162) * sizeof(double);
-    if (solve_forms_blocks(V)) {
+    if (solve_forms_blocks(V) && V.chunk_waves == 2 && cs >= 4) {
+        const bool reg = V.reg != 0;
+        const size_t ldsf = (size_t)twosided_fused_lds_doubles(cs, reg) * sizeof(double);
+        if (reg) hipLaunchKernelGGL((k_solve_chunks_ts_fused<PIVOT, true>), dim3(P, V.W), dim3(256), ldsf, s, V, cs);
+        else hipLaunchKernelGGL((k_solve_chunks_ts_fused<PIVOT, false>), dim3(P, V.W), dim3(256), ldsf, s, V, cs);
+    } else if (solve_forms_blocks(V)) {
         const bool reg = V.reg != 0;
         const size_t ldsf = lds + ((size_t)(cs + 1) * 252 + (size_t)(cs + 2) * (kAsmBase + (reg ? kAsmPrior : 0))) * sizeof(double);
         if (reg) hipLaunchKernelGGL((k_solve_chunks_fused<PIVOT, true>), dim3(P, V.W), dim3(256), ldsf, s, V, cs);
@@ -1711,6 +1780,10 @@ hipError_t configure_solver_device() {
     const struct { const void* fn; int bytes; } set[] = {
         {reinterpret_cast<const void*>(k_solve_chunks_fused<false, false>), cap_f}, {reinterpret_cast<const void*>(k_solve_chunks_fused<true, false>), cap_f},
         {reinterpret_cast<const void*>(k_solve_chunks_fused<false, true>), cap_f}, {reinterpret_cast<const void*>(k_solve_chunks_fused<true, true>), cap_f},
+        {reinterpret_cast<const void*>(k_solve_chunks_ts_fused<false, false>), twosided_fused_lds_doubles(kFusedChunkMax, true) * 8},
+        {reinterpret_cast<const void*>(k_solve_chunks_ts_fused<true, false>), twosided_fused_lds_doubles(kFusedChunkMax, true) * 8},
+        {reinterpret_cast<const void*>(k_solve_chunks_ts_fused<false, true>), twosided_fused_lds_doubles(kFusedChunkMax, true) * 8},
+        {reinterpret_cast<const void*>(k_solve_chunks_ts_fused<true, true>), twosided_fused_lds_doubles(kFusedChunkMax, true) * 8},
         {reinterpret_cast<const void*>(k_solve_chunks<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks<true>), cap},
         {reinterpret_cast<const void*>(k_solve_chunks_ts<false>), twosided_lds_doubles(60) * 8}, {reinterpret_cast<const void*>(k_solve_chunks_ts<true>), twosided_lds_doubles(60) * 8},
         {reinterpret_cast<const void*>(k_solve_chunks2<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks2<true>), cap},
