@@ -1205,7 +1205,8 @@ __global__ __launch_bounds__(64) void k_solve_reduced(DevView V, int s, int s2) 
 constexpr int kCrMax = 64;
 constexpr int kFusedChunkMax = 28;  // largest chunk whose blocks, staged inputs and elimination scratch fit 160 KiB of LDS
 constexpr int kCrThreads = 1024;
-constexpr int kCrSplitMin = 24;     // from this many separators on, the first level runs as its own multi-CU kernel
+constexpr int kCrSplitMin = 24;     // from this many separators on, the first level runs as its own multi-CU kernel (re-measured with
+                                    // the two-wave chunks: 56.2 us per call against 59.1 with all levels in the one workgroup)
 
 // Per-lane geometry of the two block operations (depends on the lane only, built once per kernel).
 struct CrLanes {
