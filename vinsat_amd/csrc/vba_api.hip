@@ -712,6 +712,7 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     V.carry = c.carry;
     V.fold = c.fold ? 1 : 0;
     V.sel_inline = 0;
+    V.median_ready = 0;
     V.redo = 0;
     V.pending_only = 0;
     V.warm_force_miss = h->warm_enabled == 2;
@@ -780,6 +781,8 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
         launch_select(V, true, s);
     }
     if (fork_late) { if (int rc = fork_dynamics()) return rc; }
+    V.median_ready = (!V.sel_inline && h->W >= 16) ? 1 : 0;
+    if (V.median_ready) launch_select_finish(V, s);
     mark(3);
     launch_obs_accumulate(V, s);
     mark(4);

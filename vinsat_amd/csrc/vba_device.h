@@ -108,6 +108,7 @@ struct DevView {
     int fuse_blocks;                // latency mode: the chunk elimination forms the blocks of its chunk itself (vba_set_fusion bit 1)
     double* wbucket;                // [W][2 (parity)][kSelBins][bucket_cap] carried keys by warm bin (latency mode; null: none)
     int bucket_cap;
+    int median_ready;               // many windows: k_select_finish has left the median in sc.c_obs
     int sel_inline;                 // this call's accumulation starts the call: inline warm select on the buckets (+ folded accept test)
     int chunk_waves;                // partitioned solve: waves per chunk (2: eliminated from both ends, vba_set_chunk_waves)
     int asm_rows;                   // full-phase assembly in uniform passes (vba_asm_fast.h; vba_set_fusion bit 3)

@@ -10,6 +10,7 @@ namespace vba {
 void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s);
 void launch_select(const DevView& V, bool with_digit0, hipStream_t s);
 void launch_select_warm(const DevView& V, hipStream_t s);
+void launch_select_finish(const DevView& V, hipStream_t s);
 void launch_obs_accumulate(const DevView& V, hipStream_t s);
 void launch_trial(const DevView& V, hipStream_t s);
 void launch_clear_hist(const DevView& V, int which, hipStream_t s);

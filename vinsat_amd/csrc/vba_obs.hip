@@ -433,6 +433,21 @@ __device__ __forceinline__ double select_finish(const DevView& V, int w, unsigne
                               V.lat != 0, lh, lds_u, skeys);
 }
 
+// Many windows per launch: the select is finished ONCE per window by a launch of its own (one block per window, ~20 us for
+// 4096 windows) instead of by every accumulation block in its prologue -- there the two dependent round trips and the
+// barriers of the finish were a third of a block's life at two blocks per CU, with nothing to overlap them.
+__global__ __launch_bounds__(256) void k_select_finish(DevView V) {
+    __shared__ unsigned sel_lh[kSelBins];
+    __shared__ unsigned sel_u[260];
+    __shared__ unsigned long long sel_keys[1025];
+    const int w = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    const double c = select_finish(V, w, sel_lh, sel_u, sel_keys);
+    if (threadIdx.x == 0) V.sc[w].c_obs = c;
+    unsigned* h0 = hist0_of(V, w, V.par);       // (see k_obs_accumulate: clean for the call after next)
+    for (int b = threadIdx.x; b < kSelBins; b += 256) h0[b] = 0u;
+}
+
 // ---------------------------------------------------------------------------------------------- A2 + A3
 // G lanes per pose (power of two): every lane strides over its share of the pose's observation segment and
 // keeps the 21 + 6 unique entries of sum(w J^T J), sum(w J^T r) in registers; a log2(G)-step xor butterfly
@@ -562,6 +577,8 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
                                   sel_lh, sel_u, sel_keys);
         // (the histogram is still being read by the other blocks: the trial kernel of this call clears it)
         if (ordered && blockIdx.x == 0 && threadIdx.x == 0) sc.c_obs = rp.c;
+    } else if (V.median_ready) {
+        rp.c = sc.c_obs;        // k_select_finish
     } else {
         rp.c = select_finish(V, w, sel_lh, sel_u, sel_keys);
         if (blockIdx.x == 0) {
@@ -1091,6 +1108,10 @@ void launch_select_warm(const DevView& V, hipStream_t s) {
         const int nb = (int)((count + 256 * kSelItems - 1) / (256 * kSelItems));
         hipLaunchKernelGGL((k_select_warm<kSelItems>), dim3(nb > 0 ? nb : 1, V.W), dim3(256), 0, s, V);
     }
+}
+
+void launch_select_finish(const DevView& V, hipStream_t s) {
+    hipLaunchKernelGGL(k_select_finish, dim3(V.W), dim3(256), 0, s, V);
 }
 
 void launch_obs_accumulate(const DevView& V, hipStream_t s) {
