@@ -959,6 +959,21 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             s += fabs(r6[0]) + fabs(r6[1]) + fabs(r6[2]) + fabs(r6[3]) + fabs(r6[4]) + fabs(r6[5]);
         }
     }
+    // bin buckets: the block reserves its share of every bin it touched with one returning atomic per bin -- requested
+    // here, in flight while the block sums below are formed
+    constexpr int kBinsPerThread = kSelBins / kObsBlock;
+    static_assert(kSelBins % kObsBlock == 0, "bins per thread");
+    unsigned bb[kBinsPerThread] = {};
+    const bool bucketing = EMIT == 2 && obs_block && V.wbucket;
+    if (bucketing) {
+        __syncthreads();        // the block's counts are complete
+        unsigned* hist = hist0_of(V, w, par ^ 1);
+#pragma unroll
+        for (int q = 0; q < kBinsPerThread; ++q) {
+            const unsigned c = lh[tid + q * kObsBlock];
+            bb[q] = c ? atomicAdd(&hist[tid + q * kObsBlock], c) : 0u;
+        }
+    }
     const double t = block_sum<kObsBlock>(s, red);
     if (tid == 0) V.part_trial[(size_t)w * V.trial_stride + blockIdx.x] = t;
     if (FORM && !obs_block) {
@@ -969,17 +984,11 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
         const double t_raw = block_sum<kObsBlock>(s_raw, red);
         if (tid == 0) V.part_next[(size_t)w * V.nblk_obs + blockIdx.x] = t_raw;
         unsigned* hist = hist0_of(V, w, par ^ 1);
-        if (EMIT == 2 && V.wbucket) {
-            // bin buckets: the block reserves its share of every bin it touched and each key goes to its place -- the next
-            // call finds the keys of the wanted bin together, no pass over all keys (k_select_warm) is needed
-            static_assert(kSelBins % kObsBlock == 0, "bins per thread");
-            unsigned cb[kSelBins / kObsBlock], bb[kSelBins / kObsBlock];
+        if (bucketing) {
+            // ... and each key goes to its place: the next call finds the keys of the wanted bin together, no pass over all keys
+            // (k_select_warm) is needed
 #pragma unroll
-            for (int q = 0; q < kSelBins / kObsBlock; ++q) cb[q] = lh[tid + q * kObsBlock];
-#pragma unroll
-            for (int q = 0; q < kSelBins / kObsBlock; ++q) bb[q] = cb[q] ? atomicAdd(&hist[tid + q * kObsBlock], cb[q]) : 0u;   // all in flight together
-#pragma unroll
-            for (int q = 0; q < kSelBins / kObsBlock; ++q) lh[tid + q * kObsBlock] = bb[q];
+            for (int q = 0; q < kBinsPerThread; ++q) lh[tid + q * kObsBlock] = bb[q];
             __syncthreads();
             if (kvalid) {
                 double* pool = V.wbucket + ((size_t)w * 2 + (par ^ 1)) * kSelBins * (size_t)V.bucket_cap;
