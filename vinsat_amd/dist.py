@@ -131,8 +131,10 @@ class ShardedBA:
             d.all_gather_into_tensor(self.trial_all, self.trial_local, group=self.group)
             trials += 1
             first = False
-            if e.stage4(self.trial_all, self.world) or trials >= 12:
+            if e.stage4(self.trial_all, self.world):
                 break
+            if trials >= 24:        # lamda runs out after 9 trials (+ one repeat for a pivoted fallback): the device never reported an outcome
+                raise RuntimeError(f"sharded BA call (iter {it}): LM loop did not terminate within {trials} trials")
         self.n_trials = trials
         return trials
 
