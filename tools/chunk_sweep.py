@@ -15,6 +15,8 @@ e = BAEngine(n, m)
 e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
 e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
 iters, inits = list(range(20)), [k < 10 for k in range(20)]
+if os.environ.get("VBA_LANES"):
+    e.set_accumulate_lanes(int(os.environ["VBA_LANES"]))
 if os.environ.get("VBA_FUSION"):
     e.set_fusion(int(os.environ["VBA_FUSION"]))
 for chunk in [int(x) for x in sys.argv[2:]] or [-1, 4, 5, 6, 7, 8, 10, 12]:
