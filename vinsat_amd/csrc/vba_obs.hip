@@ -353,6 +353,61 @@ __device__ __forceinline__ double select_finish_list(const DevView& V, int w, co
         const unsigned q = threadIdx.x + 256u * j;
         pre[j] = ((int64_t)q < cap && (speculate || q < cnt)) ? f64_bits(ck[q]) : 0ull;
     }
+    if (mode == 1 && cnt <= 1024u && V.warm_shift >= 8) {
+        // One warm bin: every key is warm_base + rel, rel < 2^warm_shift.  Ranking ~130 keys by counting is a serial loop of
+        // ~130 LDS reads per thread on the critical path of every call; instead the top 8 bits of rel split the list over 256
+        // sub-bins (one LDS atomic per key, one sub-bin per thread for the scan), and only the handful of keys in the sub-bin
+        // of the wanted rank is ranked by counting.  Exact either way: the same key comes out.
+        const int t = threadIdx.x;
+        const int sh = V.warm_shift - 8;
+        lh[t] = 0u;
+        if (t == 0) { lds_u[16] = 0u; lds_u[17] = 0u; lds_u[18] = 0u; }
+        __syncthreads();
+        unsigned sb4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned q = t + 256u * j;
+            sb4[j] = (unsigned)((pre[j] - warm_base) >> sh) & 255u;
+            if (q < cnt) atomicAdd(&lh[sb4[j]], 1u);
+        }
+        __syncthreads();
+        const unsigned c = lh[t];
+        unsigned inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(inc, o, kWave);
+            if ((t & 63) >= o) inc += v;
+        }
+        if ((t & 63) == 63) lds_u[t >> 6] = inc;
+        __syncthreads();
+        unsigned base = 0;
+        for (int q = 0; q < (t >> 6); ++q) base += lds_u[q];
+        const long long excl = (long long)base + inc - c;
+        if (want >= excl && want < excl + (long long)c) { lds_u[16] = (unsigned)t; lds_u[17] = (unsigned)(want - excl); }
+        __syncthreads();
+        const unsigned tb = lds_u[16], r = lds_u[17];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned q = t + 256u * j;
+            if (q < cnt && sb4[j] == tb) {
+                const unsigned slot = atomicAdd(&lds_u[18], 1u);
+                skeys[slot] = pre[j];       // (the order inside the list does not matter: equal keys are the same value)
+            }
+        }
+        __syncthreads();
+        const unsigned k = lds_u[18];
+        for (unsigned q = t; q < k; q += 256) {
+            const unsigned long long key = skeys[q];
+            unsigned below = 0;
+            for (unsigned j = 0; j < k; ++j) {
+                const unsigned long long o = skeys[j];
+                below += (o < key) || (o == key && j < q);
+            }
+            if (below == r) skeys[1024] = key;
+        }
+        __syncthreads();
+        return bits_f64(skeys[1024]);
+    }
     if (cnt <= (mode ? (unsigned)kWarmCount : 1024u)) {
         // the wanted key is the one of rank `want` among the list -- rank each key by counting (ties broken by position)
 #pragma unroll
