@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     const bool dyn = !prm.initialize;
     // REG: the host launches it only for full-phase BA_reg calls (BA_utils.py:609-612)
     // slot 0 = pose i0-1 (only Phi and rorb are used), slots 1..kAsmPoses = poses i0 ..
-    asm_stage<REG>(V, w, n, dyn, i0 - 1, kAsmPoses + 1, in, threadIdx.x, 256);
+    asm_stage_all<REG, kAsmPoses + 1, 256>(V, w, n, dyn, i0 - 1, in, threadIdx.x);
     __syncthreads();
     const double inv_wmax = 1.0 / bits_f64(V.sc[w].wmax_bits[V.par]);
     const int cnt = min(kAsmPoses, n - i0);

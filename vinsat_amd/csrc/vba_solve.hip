@@ -612,11 +612,21 @@ __device__ __forceinline__ void chunk_eliminate(const Src& src, int n, int s, in
     double* Xb = smem + 512;                                                 // [s][81]
     double* Zb = Xb + (size_t)s * 81;                                        // [s][19][9]
     double* Cm = Zb + (size_t)s * 171;                                       // [2][81]: L of the right separator, U of the left one
-    for (int e = lane; e < 162; e += 64) {
-        double v = 0.0;
-        if (e < 81) { if (has_sep) v = src(b0 + 1, e); }
-        else if (c > 0) v = src(a0 - 1, 162 + (e - 81));
-        Cm[e] = v;
+    {   // (the loads of a lane before its first store)
+        double cm[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = lane + 64 * q;
+            double v = 0.0;
+            if (e < 81) { if (has_sep) v = src(b0 + 1, e); }
+            else if (e < 162 && c > 0) v = src(a0 - 1, 162 + (e - 81));
+            cm[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = lane + 64 * q;
+            if (e < 162) Cm[e] = cm[q];
+        }
     }
     double a[9];
 #pragma unroll
@@ -790,9 +800,18 @@ __device__ __forceinline__ void chunk_eliminate_twosided(const Src& src, int n, 
         return src(i, ee);
     };
     auto block_of = [&](int t) { return side ? b0 - t : a0 + t; };
-    for (int e = lane; e < 81; e += 64) {
-        if (side) Cm[e] = has_sep ? src(b0 + 1, e) : 0.0;
-        else Cm[81 + e] = c > 0 ? src(a0 - 1, 162 + e) : 0.0;
+    {   // (both loads of a lane before its first store)
+        double cm[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = lane + 64 * q;
+            cm[q] = e >= 81 ? 0.0 : (side ? (has_sep ? src(b0 + 1, e) : 0.0) : (c > 0 ? src(a0 - 1, 162 + e) : 0.0));
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = lane + 64 * q;
+            if (e < 81) Cm[side ? e : 81 + e] = cm[q];
+        }
     }
     double mid[4] = {0.0, 0.0, 0.0, 0.0};
     if (side == 0) {
@@ -1412,8 +1431,21 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
     const size_t rb = (size_t)w * V.p_max;
     const double lam32 = (double)(float)sc.lam[V.par];
     if (PRE) {
+        // all loads of a thread before its first store: a copy loop waits for every element in turn (up to 16 dependent
+        // round trips here -- a third of this kernel's time when it was written that way)
         const double* R = V.cL2 + rb * 171;
-        for (int idx = tid; idx < n1 * 252; idx += kCrThreads) smem[idx] = R[idx];
+        constexpr int kFill = (kCrMax * 252 + kCrThreads - 1) / kCrThreads;
+        double v[kFill];
+#pragma unroll
+        for (int k = 0; k < kFill; ++k) {
+            const int idx = tid + k * kCrThreads;
+            v[k] = idx < n1 * 252 ? R[idx] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < kFill; ++k) {
+            const int idx = tid + k * kCrThreads;
+            if (idx < n1 * 252) smem[idx] = v[k];
+        }
     } else {
         cr_fill<kCrMax / NW>(V, w, s, n1, lam32, wave, NW, smem + (size_t)wave * 252, NW, lane);   // blocks wave, wave + NW, ...
     }
