@@ -8,9 +8,10 @@
 // column) is data -- offsets and masks decoded once per kernel (AsmLanes) -- and the arithmetic per entry is the SAME
 // expression, operation for operation, as in band_entry / rhs_entry, so the system is the same to the bit (tests: uniform
 // vs per-entry assembly, every band entry).
-// Measured (MI355X, 4096 windows): k_assemble_rows 1.77 ms against k_assemble's 1.85 ms -- the assembly is not bound by its
-// instruction count after all -- and the block-forming walk built on it (vba_set_fusion bit 2) stays slower than assembly +
-// walk.  Both are opt-in (vba_set_fusion bits 3 and 2), bit-exact and under test; the default path is the per-entry kernel.
+// Measured (MI355X): one window, 0.8 us off the average call (the per-entry form has every thread form its entry of four
+// poses in turn, ~600 serial instructions); 4096 windows, k_assemble_rows 1.77 ms against k_assemble's 1.85 ms -- there the
+// assembly is not bound by its instruction count.  Default (vba_set_fusion bit 3); the block-forming walk built on the
+// same rows (bit 2) stays slower than assembly + walk and is opt-in.  Both bit-exact and under test.
 //
 // Slot layout of the staged inputs of a pose (vba_asm.h): Hraw 0, braw 21, Phi 27, rorb 63, qgrad 69, Hd 72, Hu 81, Hl 90,
 // prior H 99, prior r 135.
