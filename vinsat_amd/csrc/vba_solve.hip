@@ -1330,8 +1330,10 @@ __device__ __forceinline__ void cr_fold(double* Bj, const double* Pm, const doub
 // whole blocks and a lane the same (row, column) of L, D and U, so the index arithmetic is done once per three
 // entries and nothing diverges (walking the 252 entries of a block through the generic source costs more in integer
 // divisions and branches than in loads); all loads are issued before the first store.
-template <int NB>
-__device__ __forceinline__ void cr_fill(const DevView& V, int w, int s, int n1, double lam32, int q0, int stride, double* dst, int dst_stride, int lane) {
+// between(): called when the loads have been issued and before the first store waits for them (lane geometry and the like)
+template <int NB, class Between>
+__device__ __forceinline__ void cr_fill(const DevView& V, int w, int s, int n1, double lam32, int q0, int stride, double* dst, int dst_stride, int lane,
+                                        Between&& between) {
     const size_t sb = (size_t)w * V.n_max, rb = (size_t)w * V.p_max;
     const double* bands = V.bands + sb * 243;
     const double* rhs = V.rhs + sb * 9;
@@ -1358,6 +1360,7 @@ __device__ __forceinline__ void cr_fill(const DevView& V, int w, int s, int n1, 
         }
         gv[u] = (in && lane < 9) ? rhs[j * 9 + lane] - l[lane * 19] - r_[lane * 19] : 0.0;
     }
+    between();
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int q = q0 + u * stride;
@@ -1396,9 +1399,9 @@ __global__ __launch_bounds__(64) void k_cr_level0(DevView V, int s) {
     const int lane = threadIdx.x;
     const size_t rb = (size_t)w * V.p_max;
     const double lam32 = (double)(float)sc.lam[V.par];
-    cr_fill<3>(V, w, s, n1, lam32, 2 * t, 1, blk, 1, lane);
+    CrLanes g;
+    cr_fill<3>(V, w, s, n1, lam32, 2 * t, 1, blk, 1, lane, [&]() { g = cr_lanes(lane); });
     __syncthreads();
-    const CrLanes g = cr_lanes(lane);
     bool bad = false;
     const bool has_j = 2 * t + 1 < n1, has_p = 2 * t + 2 < n1;
     cr_eliminate<PIVOT>(blk, g, lane, bad);
@@ -1430,6 +1433,7 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
     constexpr int NW = kCrThreads / 64;
     const size_t rb = (size_t)w * V.p_max;
     const double lam32 = (double)(float)sc.lam[V.par];
+    CrLanes g;
     if (PRE) {
         // all loads of a thread before its first store: a copy loop waits for every element in turn (up to 16 dependent
         // round trips here -- a third of this kernel's time when it was written that way)
@@ -1441,17 +1445,17 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
             const int idx = tid + k * kCrThreads;
             v[k] = idx < n1 * 252 ? R[idx] : 0.0;
         }
+        g = cr_lanes(lane);     // (while the loads are in flight)
 #pragma unroll
         for (int k = 0; k < kFill; ++k) {
             const int idx = tid + k * kCrThreads;
             if (idx < n1 * 252) smem[idx] = v[k];
         }
     } else {
-        cr_fill<kCrMax / NW>(V, w, s, n1, lam32, wave, NW, smem + (size_t)wave * 252, NW, lane);   // blocks wave, wave + NW, ...
+        cr_fill<kCrMax / NW>(V, w, s, n1, lam32, wave, NW, smem + (size_t)wave * 252, NW, lane, [&]() { g = cr_lanes(lane); });   // blocks wave, wave + NW, ...
     }
     __syncthreads();
     bool bad = false;
-    const CrLanes g = cr_lanes(lane);
     int h = 1;
     for (;; h <<= 1) {
         const int cnt = n1 / h;                 // active blocks of this level
