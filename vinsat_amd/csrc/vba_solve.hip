@@ -1387,8 +1387,9 @@ __device__ __forceinline__ void cr_fill(const DevView& V, int w, int s, int n1, 
 //   red[t] = the folded block 2t+1 (252 doubles) and  P[2t] = [PL | PU | Pg] of block 2t (for the back substitution)
 // in global memory.  The 31 eliminations + folds of a 62-separator system then run on 31 CUs instead of sharing the
 // four SIMDs of one.
+// Two waves: the two eliminations are independent, so wave 1 builds and eliminates block 2t+2 beside wave 0's 2t.
 template <bool PIVOT>
-__global__ __launch_bounds__(64) void k_cr_level0(DevView V, int s) {
+__global__ __launch_bounds__(128) void k_cr_level0(DevView V, int s) {
     __shared__ __attribute__((aligned(16))) double blk[3 * 252];
     const int w = blockIdx.y, t = blockIdx.x;
     VBA_SKIP_CALL(V, w);
@@ -1396,22 +1397,26 @@ __global__ __launch_bounds__(64) void k_cr_level0(DevView V, int s) {
     if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
     const int n1 = n_separators(V.n[w], s);
     if (n1 < kCrSplitMin || n1 > 2 * kCrMax || 2 * t >= n1) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const size_t rb = (size_t)w * V.p_max;
     const double lam32 = (double)(float)sc.lam[V.par];
     CrLanes g;
-    cr_fill<3>(V, w, s, n1, lam32, 2 * t, 1, blk, 1, lane, [&]() { g = cr_lanes(lane); });
+    if (wv == 0) cr_fill<2>(V, w, s, n1, lam32, 2 * t, 1, blk, 1, lane, [&]() { g = cr_lanes(lane); });
+    else cr_fill<1>(V, w, s, n1, lam32, 2 * t + 2, 1, blk + 504, 1, lane, [&]() { g = cr_lanes(lane); });
     __syncthreads();
     bool bad = false;
     const bool has_j = 2 * t + 1 < n1, has_p = 2 * t + 2 < n1;
-    cr_eliminate<PIVOT>(blk, g, lane, bad);
-    if (has_p) cr_eliminate<PIVOT>(blk + 504, g, lane, bad);
-    double* P = V.csol2 + (rb + 2 * t) * 171;           // scratch of the two-level driver, unused in this mode
-    for (int e = lane; e < 171; e += 64) P[e] = e < 81 ? blk[e] : blk[81 + e];       // PL | PU | Pg
-    if (has_j) {
-        cr_fold(blk + 252, blk, blk + 504, has_p, g);
-        double* R = V.cL2 + rb * 171 + (size_t)t * 252;
-        for (int e = lane; e < 252; e += 64) R[e] = blk[252 + e];
+    if (wv == 0) cr_eliminate<PIVOT>(blk, g, lane, bad);
+    else if (has_p) cr_eliminate<PIVOT>(blk + 504, g, lane, bad);
+    __syncthreads();
+    if (wv == 0) {
+        double* P = V.csol2 + (rb + 2 * t) * 171;           // scratch of the two-level driver, unused in this mode
+        for (int e = lane; e < 171; e += 64) P[e] = e < 81 ? blk[e] : blk[81 + e];       // PL | PU | Pg
+        if (has_j) {
+            cr_fold(blk + 252, blk, blk + 504, has_p, g);
+            double* R = V.cL2 + rb * 171 + (size_t)t * 252;
+            for (int e = lane; e < 252; e += 64) R[e] = blk[252 + e];
+        }
     }
     report_pivot<PIVOT>(bad, sc, lane, V.par);
 }
@@ -1796,7 +1801,7 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
     if (cs2 < 0) {      // one level, the reduced system by cyclic reduction (every window picks its variant by its own size)
         const int n0_max = P - 1, n0_min = (V.n_min + cs - 1) / cs - 1;
         if (n0_max >= kCrSplitMin) {    // first level on its own CUs, the rest in one workgroup
-            hipLaunchKernelGGL(k_cr_level0<PIVOT>, dim3((n0_max + 1) / 2, V.W), dim3(64), 0, s, V, cs);
+            hipLaunchKernelGGL(k_cr_level0<PIVOT>, dim3((n0_max + 1) / 2, V.W), dim3(128), 0, s, V, cs);
             hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, true>), dim3(V.W), dim3(kCrThreads), (size_t)(n0_max / 2) * 252 * sizeof(double), s, V, cs);
         }
         if (n0_min < kCrSplitMin && n0_max > 0) {
