@@ -1409,3 +1409,34 @@ def test_uniform_pass_assembly_gives_the_bits_of_the_per_entry_form(c2, reg, win
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
     assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][2], b[2][2]) and a[2][1] == b[2][1]
     assert np.abs(a[0]).max() > 0 and np.abs(a[0][:, 0]).max() > 0 and np.abs(a[0][:, 2]).max() > 0     # off-diagonal bands are populated
+
+
+@pytest.mark.parametrize("chunk", [4, 5, 6, 7, 8, 13])
+def test_two_cyclic_reduction_levels_in_front_give_the_bits_of_one(chunk):
+    """The reduced system's first TWO cyclic-reduction levels on their own CUs (k_cr_level01, default) against one level in
+    front (k_cr_level0; vba_set_fusion bit 4): the same eliminations and folds in another place, so the same bits -- for
+    separator counts of every residue mod 4 (a 300-pose window cut into chunks of 4 .. 13: 74, 59, 49, 42, 37, 23 separators,
+    the last one below the size from which the levels are split off at all), unpivoted and pivoted."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    cfg = synth.WindowConfig("cr2", 300, 20, 5)
+    win = od_pipe.prepare_window(*synth.make_sequence(cfg, seed=11))
+    n, m = win.time_idx.size, win.ii.size
+    st0 = od_pipe.initial_guess(win, seed=11)
+    iters, inits = [9, 10, 11, 12, 13], [True, False, False, False, False]
+    for pivot in (False, True):
+        outs = []
+        for mask in (9, 25):
+            e = BAEngine(n, m)
+            e.set_solver(chunk, -1)
+            e.set_pivoting(pivot)
+            e.set_fusion(mask)
+            e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+            e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+            e.set_states(st0, 1e-4)
+            e.run_schedule(iters, inits)
+            outs.append((e.get_states(), e.debug("dpose")))
+            e.close()
+        a, b = outs
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0][0], b[0][0]) and a[0][1] == b[0][1] and a[0][3] == b[0][3], (chunk, pivot)
+        assert np.isfinite(a[1]).all() and np.abs(a[1]).max() > 0

@@ -429,7 +429,7 @@ int vba_set_key_carry(vba_handle h, int on) {
 
 int vba_set_fusion(vba_handle h, int mask) {
     if (!h) return fail(VBA_EINVAL, "null handle");
-    if (mask < 0 || mask > 15) return fail(VBA_EINVAL, "mask must be in [0, 15]");
+    if (mask < 0 || mask > 31) return fail(VBA_EINVAL, "mask must be in [0, 31]");
     h->fusion = mask;
     return VBA_OK;
 }
@@ -734,6 +734,7 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     V.fuse_blocks = (h->fusion & 2) ? 1 : 0;
     V.chunk_waves = h->chunk_waves;
     V.asm_rows = (h->fusion & 8) ? 1 : 0;
+    V.cr_levels = (h->fusion & 16) ? 1 : 2;
     V.fuse_walk = ((h->fusion & 4) && h->W >= 16) ? 1 : 0;
 }
 

@@ -110,6 +110,7 @@ struct DevView {
     int bucket_cap;
     int median_ready;               // many windows: k_select_finish has left the median in sc.c_obs
     int sel_inline;                 // this call's accumulation starts the call: inline warm select on the buckets (+ folded accept test)
+    int cr_levels;                  // cyclic-reduction levels that run as their own multi-CU kernel in front of the one-workgroup kernel (1 or 2)
     int chunk_waves;                // partitioned solve: waves per chunk (2: eliminated from both ends, vba_set_chunk_waves)
     int asm_rows;                   // full-phase assembly in uniform passes (vba_asm_fast.h; vba_set_fusion bit 3)
     int fuse_walk;                  // batched mode: the sequential walk forms the blocks itself (vba_set_fusion bit 2)

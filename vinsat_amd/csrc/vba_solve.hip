@@ -1421,9 +1421,69 @@ __global__ __launch_bounds__(128) void k_cr_level0(DevView V, int s) {
     report_pivot<PIVOT>(bad, sc, lane, V.par);
 }
 
+// The first TWO levels on their own CUs: four waves per group of four separators.  Group t builds the seven blocks
+// 4t .. 4t+6, eliminates the even ones (four waves side by side), folds them into 4t+1, 4t+3, 4t+5, eliminates 4t+1 and
+// 4t+5 (level 1: every other odd block) and folds those into 4t+3.  It leaves
+//   red2[t] = the twice-folded block 4t+3 (252 doubles),  P[4t], P[4t+2] (level 0) and P[4t+1] (level 1) = [PL | PU | Pg]
+// in global memory; what it shares with its neighbour groups (blocks 4t+4 .. 4t+6) is computed by both: redundant work
+// instead of communication.  In the one-workgroup kernel the first level ran 16 eliminations on the four SIMDs of one CU
+// (5.8 us, issue-bound at four waves per SIMD) -- here they are spread over 16 CUs and that kernel starts from 15 blocks.
+template <bool PIVOT>
+__global__ __launch_bounds__(256) void k_cr_level01(DevView V, int s) {
+    __shared__ __attribute__((aligned(16))) double blk[7 * 252];
+    const int w = blockIdx.y, t = blockIdx.x;
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n1 = n_separators(V.n[w], s);
+    if (n1 < kCrSplitMin || n1 > 4 * kCrMax || 4 * t >= n1) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lam[V.par];
+    const int q0 = 4 * t;
+    CrLanes g;
+    cr_fill<2>(V, w, s, n1, lam32, q0 + wv, 4, blk + (size_t)wv * 252, 4, lane, [&]() { g = cr_lanes(lane); });     // blocks wv, wv + 4
+    __syncthreads();
+    bool bad = false;
+    auto store_P = [&](int u) {         // [PL | PU | Pg] of block q0 + u
+        double* P = V.csol2 + (rb + q0 + u) * 171;
+        const double* B = blk + (size_t)u * 252;
+        for (int e = lane; e < 171; e += 64) P[e] = e < 81 ? B[e] : B[81 + e];
+    };
+    // level 0: the even blocks
+    if (q0 + 2 * wv < n1) cr_eliminate<PIVOT>(blk + (size_t)(2 * wv) * 252, g, lane, bad);
+    __syncthreads();
+    if (wv < 3) {
+        const int u = 2 * wv + 1;
+        if (q0 + u < n1) cr_fold(blk + (size_t)u * 252, blk + (size_t)(u - 1) * 252, blk + (size_t)(u + 1) * 252, q0 + u + 1 < n1, g);
+    } else {
+        store_P(0);
+        if (q0 + 2 < n1) store_P(2);
+    }
+    __syncthreads();
+    // level 1: blocks 4t+1 and 4t+5
+    if (wv < 2) {
+        const int u = 4 * wv + 1;
+        if (q0 + u < n1) cr_eliminate<PIVOT>(blk + (size_t)u * 252, g, lane, bad);
+    }
+    __syncthreads();
+    if (wv == 0) {
+        if (q0 + 3 < n1) {
+            cr_fold(blk + 3 * 252, blk + 1 * 252, blk + 5 * 252, q0 + 5 < n1, g);
+            wave_sync_lds();
+            double* R = V.cL2 + rb * 171 + (size_t)t * 252;
+            for (int e = lane; e < 252; e += 64) R[e] = blk[3 * 252 + e];
+        }
+    } else if (wv == 1) {
+        if (q0 + 1 < n1) store_P(1);
+    }
+    report_pivot<PIVOT>(bad, sc, lane, V.par);
+}
+
 // PRE: the first level has been done by k_cr_level0; this kernel continues with the n1 / 2 folded blocks and finishes
 // with the back substitution of the level-0 blocks.
-template <bool PIVOT, bool PRE>
+// PRE 2: the first two levels have been done by k_cr_level01; the system solved here is over the separators 4b + 3.
+template <bool PIVOT, int PRE>
 __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int s) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int w = blockIdx.x;
@@ -1432,8 +1492,8 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
     if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
     const int n0 = n_separators(V.n[w], s);             // separators of the window
     if (n0 <= 0) return;
-    if (PRE ? (n0 < kCrSplitMin || n0 > 2 * kCrMax) : (n0 >= kCrSplitMin || n0 > kCrMax)) return;   // the other variant's window
-    const int n1 = PRE ? n0 / 2 : n0;                   // blocks of the system solved here
+    if (PRE ? (n0 < kCrSplitMin || n0 > (PRE == 2 ? 4 : 2) * kCrMax) : (n0 >= kCrSplitMin || n0 > kCrMax)) return;   // the other variant's window
+    const int n1 = PRE == 2 ? n0 / 4 : (PRE ? n0 / 2 : n0);             // blocks of the system solved here
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = kCrThreads / 64;
     const size_t rb = (size_t)w * V.p_max;
@@ -1502,7 +1562,54 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
         }
         __syncthreads();
     }
-    if (!PRE) {
+    if (PRE == 2) {
+        // separators 4b+3 are the blocks solved here.  4b+1 come from the level-1 eliminations, x = Pg - PL x_{q-2} - PU x_{q+2},
+        // then the even ones from level 0, x = Pg - PL x_{q-1} - PU x_{q+1}
+        double* x1 = smem + (size_t)n1 * 252;       // [ceil(n0 / 4)][9]: the level-1 solutions (behind the blocks)
+        auto x_odd = [&](int q) -> const double* {  // solution of an odd separator
+            return (q & 3) == 3 ? smem + (size_t)(q >> 2) * 252 + 243 : x1 + (size_t)(q >> 2) * 9;
+        };
+        for (int idx = tid; idx < ((n0 + 3) / 4) * 9; idx += kCrThreads) {
+            const int q = 4 * (idx / 9) + 1, r = idx % 9;
+            if (q < n0) {
+                const double* P = V.csol2 + (rb + q) * 171;
+                double x = P[162 + r];
+                if (q >= 3) {
+                    const double* xm = smem + (size_t)((q - 2) >> 2) * 252 + 243;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) x -= P[r * 9 + k] * xm[k];
+                }
+                if (q + 2 < n0) {
+                    const double* xp = smem + (size_t)((q + 2) >> 2) * 252 + 243;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) x -= P[81 + r * 9 + k] * xp[k];
+                }
+                x1[(size_t)(q >> 2) * 9 + r] = x;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n0 * 9; idx += kCrThreads) {
+            const int q = idx / 9, r = idx % 9;
+            double x;
+            if (q & 1) {
+                x = x_odd(q)[r];
+            } else {
+                const double* P = V.csol2 + (rb + q) * 171;
+                x = P[162 + r];
+                if (q >= 1) {
+                    const double* xm = x_odd(q - 1);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) x -= P[r * 9 + k] * xm[k];
+                }
+                if (q + 1 < n0) {
+                    const double* xp = x_odd(q + 1);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) x -= P[81 + r * 9 + k] * xp[k];
+                }
+            }
+            V.rx[rb * 9 + idx] = x;
+        }
+    } else if (!PRE) {
         for (int idx = tid; idx < n1 * 9; idx += kCrThreads) V.rx[rb * 9 + idx] = smem[(size_t)(idx / 9) * 252 + 243 + idx % 9];
     } else {
         // separators 2t+1 are the blocks solved here; 2t come from the level-0 eliminations:
@@ -1800,13 +1907,19 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
     }
     if (cs2 < 0) {      // one level, the reduced system by cyclic reduction (every window picks its variant by its own size)
         const int n0_max = P - 1, n0_min = (V.n_min + cs - 1) / cs - 1;
-        if (n0_max >= kCrSplitMin) {    // first level on its own CUs, the rest in one workgroup
-            hipLaunchKernelGGL(k_cr_level0<PIVOT>, dim3((n0_max + 1) / 2, V.W), dim3(128), 0, s, V, cs);
-            hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, true>), dim3(V.W), dim3(kCrThreads), (size_t)(n0_max / 2) * 252 * sizeof(double), s, V, cs);
+        if (n0_max >= kCrSplitMin) {    // first level(s) on their own CUs, the rest in one workgroup
+            if (V.cr_levels == 2) {
+                hipLaunchKernelGGL(k_cr_level01<PIVOT>, dim3((n0_max + 3) / 4, V.W), dim3(256), 0, s, V, cs);
+                hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, 2>), dim3(V.W), dim3(kCrThreads),
+                                   ((size_t)(n0_max / 4) * 252 + (size_t)((n0_max + 3) / 4) * 9) * sizeof(double), s, V, cs);
+            } else {
+                hipLaunchKernelGGL(k_cr_level0<PIVOT>, dim3((n0_max + 1) / 2, V.W), dim3(128), 0, s, V, cs);
+                hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, 1>), dim3(V.W), dim3(kCrThreads), (size_t)(n0_max / 2) * 252 * sizeof(double), s, V, cs);
+            }
         }
         if (n0_min < kCrSplitMin && n0_max > 0) {
             const int nb = n0_max < kCrSplitMin ? n0_max : kCrSplitMin - 1;
-            hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, false>), dim3(V.W), dim3(kCrThreads), (size_t)nb * 252 * sizeof(double), s, V, cs);
+            hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, 0>), dim3(V.W), dim3(kCrThreads), (size_t)nb * 252 * sizeof(double), s, V, cs);
         }
         return;
     }
@@ -1829,8 +1942,9 @@ hipError_t configure_solver_device() {
         {reinterpret_cast<const void*>(k_solve_chunks<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks<true>), cap},
         {reinterpret_cast<const void*>(k_solve_chunks_ts<false>), twosided_lds_doubles(60) * 8}, {reinterpret_cast<const void*>(k_solve_chunks_ts<true>), twosided_lds_doubles(60) * 8},
         {reinterpret_cast<const void*>(k_solve_chunks2<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks2<true>), cap},
-        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, false>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, false>), cap_cr},
-        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, true>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, true>), cap_cr}};
+        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 0>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 0>), cap_cr},
+        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 1>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 1>), cap_cr},
+        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 2>), cap_cr + 65 * 9 * 8}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 2>), cap_cr + 65 * 9 * 8}};
     for (const auto& e : set) {
         const hipError_t rc = hipFuncSetAttribute(e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, e.bytes);
         if (rc != hipSuccess) return rc;
