@@ -152,6 +152,8 @@ int vba_warm_select_misses(vba_handle h, int* count);
  *   bit 3: the full-phase assembly forms each pose row with one wave in seven uniform passes (vba_asm_fast.h) instead of one
  *          entry per thread.  Bit-exact; 0.8 us off the average call of a single window (the per-entry form is a serial
  *          ~600 instructions per thread there), on par at 4096 windows (1.77 vs 1.85 ms).
+ *   bit 4: only ONE cyclic-reduction level of the reduced system runs on its own CUs in front of the one-workgroup kernel
+ *          (k_cr_level0) instead of two (k_cr_level01, default).  Same bits; 0.9 us per call slower.  Comparison / tests.
  * Default 9 (bits 0 and 3).  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
  * formed by 16 lanes together (formed redundantly by every thread it was 6 us SLOWER: instruction issue of a single wave
  * is the time in this mode); bit 1 gains nothing (the assembly costs the elimination's block what its own launch cost)
