@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
     const bool dyn = !prm.initialize;
     // REG: the host launches it only for full-phase BA_reg calls (BA_utils.py:609-612)
     // slot 0 = pose i0-1 (only Phi and rorb are used), slots 1..kAsmPoses = poses i0 ..
-    asm_stage_all<REG, kAsmPoses + 1, 256>(V, w, n, dyn, i0 - 1, in, threadIdx.x);
+    // (few windows: every load in flight at once; many: the plain loop -- other blocks hide the round trips and it is
+    // the faster one there, 1.77 against 1.87 ms at 4096 windows)
+    if constexpr (kAsmPoses <= 4) asm_stage_all<REG, kAsmPoses + 1, 256>(V, w, n, dyn, i0 - 1, in, threadIdx.x);
+    else asm_stage<REG>(V, w, n, dyn, i0 - 1, kAsmPoses + 1, in, threadIdx.x, 256);
     __syncthreads();
     const double inv_wmax = 1.0 / bits_f64(V.sc[w].wmax_bits[V.par]);
     const int cnt = min(kAsmPoses, n - i0);
@@ -267,7 +270,8 @@ __global__ __launch_bounds__(256) void k_assemble_rows(DevView V) {
     const int i0 = blockIdx.x * kAsmPoses;
     if (i0 >= n) return;
     const size_t sb = (size_t)w * V.n_max;
-    asm_stage_all<REG, kAsmPoses + 1, 256>(V, w, n, true, i0 - 1, in, threadIdx.x);
+    if constexpr (kAsmPoses <= 4) asm_stage_all<REG, kAsmPoses + 1, 256>(V, w, n, true, i0 - 1, in, threadIdx.x);
+    else asm_stage<REG>(V, w, n, true, i0 - 1, kAsmPoses + 1, in, threadIdx.x, 256);
     __syncthreads();
     const double inv_wmax = 1.0 / bits_f64(V.sc[w].wmax_bits[V.par]);
     const double sigma = V.prm.sigma;
