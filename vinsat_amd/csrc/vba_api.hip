@@ -153,7 +153,7 @@ extern "C" {
 int vba_set_accumulate_lanes(vba_handle h, int lanes);
 int vba_set_solver(vba_handle h, int chunk);
 
-int vba_version(void) { return 200; }
+int vba_version(void) { return 210; }     // 2.1: vba_set_chunk_waves, fusion bits 2..4, warm select mode 3
 
 const char* vba_last_error(void) { return g_err.c_str(); }
 
