@@ -518,6 +518,22 @@ def run_rank(args):
                    "whole_step_GBps_serialised": step_bytes / (1e-3 * sum(bms[k] * len(bk[k]) / 20.0 for k in bms)) / 1e9,
                    "whole_step_bytes_per_window": step_bytes / W,
                    "kernels": per_kernel}
+        # measured HBM traffic of the same chained schedule from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE
+        # per kernel, tools/profile_pmc.sh / summarize_pmc.py), if that profile was taken at this many windows
+        tpath4 = os.path.join(ROOT, "profiles", f"{args.profile_tag}_w{W}_traffic.json")
+        if os.path.exists(tpath4):
+            try:
+                tj4 = json.load(open(tpath4))
+                tot = sum(v["hbm_bytes_per_launch"] * v["calls"] for k, v in tj4.items()
+                          if k.startswith("k_") and k not in ("k_broadcast_states", "k_set_counts", "k_reset_calls", "k_clear_hist")
+                          and "hbm_bytes_per_launch" in v)
+                calls = max(v["calls"] for k, v in tj4.items() if k.startswith("k_trial"))
+                per_step = tot / max(calls, 1)
+                batched["hbm_traffic"] = {"bytes_per_step": per_step, "GBps": per_step / (1e-3 * bms_step) / 1e9,
+                                          "frac": per_step / (1e-3 * bms_step) / 1e9 / HBM_PEAK_GBS,
+                                          "source": os.path.relpath(tpath4, ROOT) + " (PMC counters of one chained schedule; rate over this run's timed ms_per_step)"}
+            except Exception:
+                pass
         be.close()
 
     # ---- accuracy: the 20-call schedule once more from the initial guess, against the reference's final states
