@@ -13,6 +13,8 @@ for seed in range(a, b):
     except Exception as ex:
         bad.append(seed)
         print(f"seed {seed}: {type(ex).__name__}: {str(ex)[:200]}", flush=True)
+        if os.environ.get("STRESS_TRACE"):
+            traceback.print_exc()
     if seed % 20 == 0:
         print(f"... seed {seed}, failures so far {bad}", flush=True)
 print("failures:", bad)
