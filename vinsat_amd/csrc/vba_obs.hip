@@ -8,8 +8,14 @@
 //   k_select_warm      A3a on carried keys: the trial that produced the keys binned them around the median of its own
 //                      call (warm_bin, vba_device.h), so ONE pass compacts the bin of the wanted rank; in a chained
 //                      schedule its prologue is the accept test of the call in front (vba_decide.h)
-//   k_obs_accumulate<G> A2 + A3a + A3b: Jacobian, robust weight, per-pose 6x6 / 6 accumulation (G lanes per pose)
-//   k_trial            A8: weighted trial residuals (observations) and dynamics residuals at the trial states
+//                      (batched handles; latency mode keeps the keys in per-bin buckets instead and selects inside the
+//                      accumulation: warm_front / front_resolve / select_finish_list below)
+//   k_select_finish    many windows: the select finished once per window (one block each) instead of in every
+//                      accumulation block
+//   k_obs_accumulate<G> A2 + A3a + A3b: Jacobian, robust weight, per-pose 6x6 / 6 accumulation (G lanes per pose); latency
+//                      mode: starts the call -- inline select on the bin buckets, accept test of the call in front at its end
+//   k_trial            A8: step + retraction (latency mode), weighted trial residuals and dynamics residuals at the trial
+//                      states, next call's keys: histogram + bin buckets
 //   k_debug_project    recompute est / Jacobian at the step's input states for vba_debug_fetch
 //
 // All of these stream the observation arrays once, coalesced (SoA, 8 B per lane per array); the pose state
@@ -23,10 +29,12 @@
 namespace vba {
 
 // Per-call state that must be clean before the first kernel touches it:
-//   * digit-0 histogram of the call's parity: zeroed by k_obs_accumulate of the call that consumed it last (and by
-//     the allocation); digits 1, 2: zeroed by k_trial;
+//   * digit-0 histogram of the call's parity: zeroed by k_obs_accumulate / k_select_finish of the call that consumed it last
+//     -- with the inline select by that call's k_trial, the accumulation's blocks are still reading it -- (and by the
+//     allocation); digits 1, 2: zeroed by k_trial;
 //   * scalars (done, n_trials, flags, max weight): reset by thread 0 of block 0 of the call's first kernel
-//     (k_obs_residual, k_select_warm, or k_select_pass<1> of a repeated select), no other block of that kernel reads them;
+//     (k_obs_residual, k_select_warm, k_select_pass<1> of a repeated select, or -- inline select -- k_obs_accumulate at its
+//     end, except the max weight: per parity, cleared by the previous call's k_trial); no other block of that kernel reads them;
 //   * the length of the compacted list: reset by the kernel in FRONT of the one that appends (k_obs_residual /
 //     k_select_pass<1>, or the previous call's k_trial for k_select_warm).
 // keep_wmax: the caller is a block of the accumulation itself (inline select): other blocks of the same kernel may
