@@ -22,7 +22,10 @@
 //                      eliminated by its own wave with 19 right-hand sides (g and the couplings to its two
 //                      separators), a reduced block-tridiagonal system over the P-1 separators is solved by one
 //                      wave, and the interiors are recovered in parallel: ~ n/P + P sequential block steps
-//                      instead of n.
+//                      instead of n.  Default of the latency mode: k_solve_chunks_ts (two waves per chunk, meeting in the
+//                      middle), the reduced system by block cyclic reduction -- k_cr_level01 (first two levels, one
+//                      workgroup per four separators) and k_solve_reduced_cr (the rest in one workgroup) -- and the
+//                      recovery inside the trial kernel (vba_step.h).
 #include "vba_asm.h"
 #include "vba_asm_fast.h"
 #include "vba_decide.h"
