@@ -538,12 +538,37 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     // (warm_front) and go on only if that first trial was cleanly accepted.
     const bool fold_here = V.sel_inline && V.call >= 0 && V.fold && sc.pending == V.call - 1 && sc.call_idx == V.call - 1;
     if (!fold_here) VBA_SKIP_CALL(V, w);
-    // The accept test only GATES: nothing this kernel computes depends on it.  So it is evaluated at the END, behind the
-    // accumulation, and a trial that turns out not to be clean just leaves no trace -- what this kernel writes on the way
-    // (weights, per-pose sums, the pose-chain factor of its rider blocks) lives per call parity, the later trials of the
-    // call in front still find theirs.
+    // The accept test only GATES: nothing this kernel computes depends on it, and a trial that turns out not to be clean just
+    // leaves no trace -- what this kernel writes on the way (weights, per-pose sums, the pose-chain factor of its rider
+    // blocks) lives per call parity, the later trials of the call in front still find theirs.
     constexpr bool ordered = false;     // (kept: the in-order form, accept test first, is warm_front as k_select_warm uses it)
     const int nb_acc = (V.n_max * G + 255) / 256;
+    // ... and it is evaluated by ONE extra block of the grid (the last one), which also leaves what the start of this call
+    // leaves in the scalars: off the critical path of the blocks that accumulate.  Those need no gate at all: their
+    // maximum goes into a slot that the trial kernel of the call in front clears whenever it runs again.
+    if (V.sel_inline && !ordered && blockIdx.x == gridDim.x - 1) {
+        unsigned hl[8];
+        select_load(hist0_of(V, w, V.par), kSelBins, hl);
+        DecideIn fin = {};
+        if (fold_here) fin = fold_load(V, w);
+        unsigned bin, in_bin;
+        long long rank;
+        const bool hit = front_resolve(V, w, hl, V.bucket_cap, sel_u, bin, rank, in_bin);
+        double c = 0.0;
+        if (hit) {
+            const double* bucket = V.wbucket + (((size_t)w * 2 + V.par) * kSelBins + bin) * (size_t)V.bucket_cap;
+            c = select_finish_list(V, w, bucket, V.bucket_cap, in_bin, rank, 1, sc.warm_lo[V.par] + ((unsigned long long)(bin - 1u) << V.warm_shift),
+                                   false, sel_lh, sel_u, sel_keys);
+        }
+        DecideOut d;
+        if (fold_here && !fold_decide_loaded(V, w, fin, dec_red, d)) return;    // not clean: no trace (the window stalls at the call in front)
+        if (fold_here) fold_commit(V, w, d);
+        if (threadIdx.x == 0) {
+            front_commit(V, w, hit, bin, rank, in_bin, true);
+            if (hit) sc.c_obs = c;
+        }
+        return;
+    }
     if ((int)blockIdx.x >= nb_acc) {        // few windows: the dynamics factor rides in this grid (vba_dyn_body.h)
         // (a function of the input states only: neither a missed select nor, by default, the accept test concerns it --
         // what it writes is read by this call's own assembly, which runs only if the window has moved on)
@@ -585,14 +610,10 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     // Software pipelined: the loads of the next observations are in flight while the current ones are processed (the
     // kernel sits at 2 waves per SIMD because of its accumulators either way; the registers between that and the next
     // occupancy step are spent on memory-level parallelism).
-    // (inline select: the histogram and the inputs of the deferred accept test are requested first of all -- they depend on
-    // nothing, the row range below is a dependent round trip)
+    // (inline select: the histogram is requested first of all -- it depends on nothing, the row range below is a dependent
+    // round trip)
     unsigned hloc[8] = {};
-    DecideIn fold_in = {};
-    if (V.sel_inline && !ordered) {
-        select_load(hist0_of(V, w, V.par), kSelBins, hloc);
-        if (fold_here) fold_in = fold_load(V, w);       // in flight until the end of the kernel
-    }
+    if (V.sel_inline && !ordered) select_load(hist0_of(V, w, V.par), kSelBins, hloc);
     PoseCam pc{};
     int beg = 0, end = 0;
     Obs ring[kAccDepth]{};
@@ -613,8 +634,6 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 
     // Phase 2: the median (every block of the window finishes the select itself, see select_finish)
     RobustParams rp;
-    unsigned sel_bin = 0u, sel_in_bin = 0u;
-    long long sel_rank = 0;
     if (V.sel_inline) {
         // the trial kernel of the call in front dropped every key into the bucket of its warm bin: resolve the histogram,
         // rank the wanted bin's bucket.  Every block does this redundantly (a few hundred keys), nothing is compacted.
@@ -623,16 +642,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
         if (ordered) {
             if (warm_front(V, w, fold_here, true, V.bucket_cap, dec_red, sel_u, bin, rank, in_bin) != kWarmHit) return;
         } else {
-            if (!front_resolve(V, w, hloc, V.bucket_cap, sel_u, bin, rank, in_bin)) {      // a miss: nothing to hide the test behind
-                DecideOut d;
-                if (fold_here && !fold_decide_loaded(V, w, fold_in, dec_red, d)) return;
-                if (blockIdx.x == 0) {
-                    if (fold_here) fold_commit(V, w, d);
-                    if (threadIdx.x == 0) front_commit(V, w, false, bin, rank, in_bin, true);
-                }
-                return;
-            }
-            sel_bin = bin; sel_rank = rank; sel_in_bin = in_bin;
+            if (!front_resolve(V, w, hloc, V.bucket_cap, sel_u, bin, rank, in_bin)) return;    // a miss (the last block records it)
         }
         const unsigned long long lo = sc.warm_lo[V.par];
         const double* bucket = V.wbucket + (((size_t)w * 2 + V.par) * kSelBins + bin) * (size_t)V.bucket_cap;
@@ -794,17 +804,6 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             const int q = own + j;
             if (q < 21) H[q] = acc[j];
             else if (q < 27) B[q - 21] = acc[j];
-        }
-    }
-    if (V.sel_inline && !ordered) {     // the deferred accept test and what this call's start leaves in the scalars
-        DecideOut d;
-        if (fold_here && !fold_decide_loaded(V, w, fold_in, dec_red, d)) return;    // not clean: no trace (the window stalls at the call in front)
-        if (blockIdx.x == 0) {
-            if (fold_here) fold_commit(V, w, d);
-            if (threadIdx.x == 0) {
-                front_commit(V, w, true, sel_bin, sel_rank, sel_in_bin, true);
-                sc.c_obs = rp.c;
-            }
         }
     }
     wmax_l = wave_max(wmax_l);
@@ -1190,7 +1189,8 @@ void launch_obs_accumulate(const DevView& V, hipStream_t s) {
     const int G = V.acc_lanes;
     const int nb = (V.n_max * G + 255) / 256;
     // V.dyn_in_acc: the blocks of the dynamics factor are appended to the grid
-    const dim3 g(nb + (V.dyn_in_acc ? (V.n_max * kDynLanes + 255) / 256 : 0), V.W), b(256);
+    // V.sel_inline: one more block, which evaluates the folded accept test and records the start of the call
+    const dim3 g(nb + (V.dyn_in_acc ? (V.n_max * kDynLanes + 255) / 256 : 0) + (V.sel_inline ? 1 : 0), V.W), b(256);
 #ifndef VBA_ACC_PAIR
 #define VBA_ACC_PAIR 1
 #endif
