@@ -140,6 +140,9 @@ int vba_set_key_carry(vba_handle h, int on);
  * prologue, and a chained landmark-only call is two kernels.  on == 3: keep the select as its own kernel (comparison). */
 int vba_set_warm_select(vba_handle h, int on);
 int vba_warm_select_misses(vba_handle h, int* count);
+/* Test knob: capacity of a bin bucket (latency mode), 8 .. the allocated one; 0 restores the default.  A bin that holds more
+ * keys than that overflows -- its bucket is incomplete -- and a call whose median falls into it takes the miss path. */
+int vba_set_bucket_cap(vba_handle h, int cap);
 
 /* Kernel fusion, a bit mask (bits 0 and 1: latency mode, fewer than 16 windows per handle); same results to rounding.
  *   bit 0: the trial kernel forms the step of each pose itself (landmark-only phase: the 6x6 solve; full phase: the

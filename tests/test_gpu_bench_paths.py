@@ -1,0 +1,219 @@
+"""The two code paths bench.py times, pinned at bench size (C3 500/50k, C4 500/200k, C5S 500/125k).
+
+* headline: ``vba_run_schedule`` on a default one-window handle (latency mode: bin buckets, accept test folded into the
+  next call's accumulation, ungated accumulation) -- against the reference's states (tests/golden/c3|c4|c5s.npz, made by
+  the reference's driver, BA_filtering.py:4-98 called as od_pipe.py:1036-1040) and bit for bit against the call-by-call
+  ``vba_iterate`` chain;
+* batched: a 16-window handle (bandwidth-mode kernels: two digit passes + k_select_finish, k_obs_accumulate<8,true>,
+  k_dynamics_pair on the second stream, k_assemble / k_init_step, k_solve, k_trial<1,0>, k_decide) stepped call by call
+  against the same fixtures, with a window that rejects trials inside it;
+* the miss paths of the warm select (forced misses, overflowing bin buckets) at 100 000 and 400 000 keys;
+* the two degenerate random windows the free-running 1e-5 bar does not hold for: conditioning, shown against the oracle's
+  own dense / banded solves.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, rel_err
+from oracle import ba_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CHECKPOINTS = (0, 9, 10, 14, 19)
+
+
+def _window(name):
+    from vinsat_amd import od_pipe, synth
+    if name == "c5s":
+        det, orb = synth.make_subwindow("C5", 500)
+    else:
+        det, orb = synth.make_sequence(name.upper())
+    return od_pipe.prepare_window(det, orb)
+
+
+def _engine(win, windows=1, conf=None):
+    from vinsat_amd.engine import BAEngine
+    n, m = win.time_idx.size, win.ii.size
+    e = BAEngine(n, m, windows=windows)
+    for w in range(windows):
+        e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences if conf is None else conf, win.ii, n, window=w)
+        e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx, window=w)
+    return e
+
+
+def _close_to_reference(st, ref, k):
+    assert np.abs(st[:, :3] - ref[:, :3]).max() / np.abs(ref[:, :3]).max() < 1e-6, k
+    q, qr = st[:, 3:7], ref[:, 3:7]
+    assert (2 * np.arccos(np.clip(np.abs((q * qr).sum(-1)), 0, 1))).max() < 1e-6, k
+    assert rel_err(st, ref) < 1e-6, k
+
+
+@pytest.fixture(scope="module", params=["c3", "c4", "c5s"])
+def sized(request):
+    name = request.param
+    if not os.path.exists(os.path.join(GOLDEN, f"{name}.npz")):
+        pytest.skip(f"{name} fixture not generated")
+    g = load_golden(name)
+    win = _window(name)
+    assert np.array_equal(win.time_idx, g["in_time_idx"])
+    assert np.array_equal(np.array([win.ii.size, win.ii.sum(), win.ii[0], win.ii[-1]]), g["in_ii_digest"])
+    return name, g, win
+
+
+def test_headline_path_run_schedule_vs_reference_states(sized):
+    """What bench.py's `value` is timed on: set_states + ONE vba_run_schedule of the 20 calls on a default handle."""
+    name, g, win = sized
+    iters, inits = [int(x) for x in g["iters"]], [bool(x) for x in g["initialize"]]
+    eng = _engine(win)
+    # (1) the 20 calls as one chained schedule
+    eng.set_states(g["states0"][0], 1e-4)
+    trials = eng.run_schedule(iters, inits)
+    st20, lam20, hess20, ntr20, flags20 = eng.get_states()
+    assert trials >= int(g["n_trials"].sum())
+    assert lam20 == g["lamda_out"][19] and ntr20 == g["n_trials"][19] and flags20 == 0
+    _close_to_reference(st20, g["states_out_19"][0], 19)
+    assert eng.warm_select_misses() == 0 and eng.solver_fallbacks() == 0
+    # (2) the same schedule cut at the calls the fixture holds: chained segments, every checkpoint against the reference
+    eng.set_states(g["states0"][0], 1e-4)
+    prev = 0
+    for k in CHECKPOINTS:
+        eng.run_schedule(iters[prev:k + 1], inits[prev:k + 1])
+        st, lam, _, ntr, flags = eng.get_states()
+        assert lam == g["lamda_out"][k] and ntr == g["n_trials"][k] and flags == 0, k
+        _close_to_reference(st, g[f"states_out_{k}"][0], k)
+        prev = k + 1
+    assert np.array_equal(st, st20)
+    # (3) call by call with the states crossing the host every time (vba_iterate: no carried keys, own decide launch)
+    st, lam = g["states0"][0], 1e-4
+    for k in range(20):
+        st, lam, hess, ntr, flags = eng.iterate(iters[k], inits[k], lam, st)
+        assert ntr == g["n_trials"][k] and lam == g["lamda_out"][k] and flags == 0, k
+    assert np.array_equal(st, st20) and np.array_equal(hess, hess20)
+    eng.close()
+
+
+def test_batched_path_sixteen_c3_windows_stepped_vs_reference_states():
+    """What bench.py's `batched` series is timed on, at C3 size: 16 windows per launch.  Windows 0..13 are the reference's
+    C3 run; window 14 starts from another initial guess (against a one-window handle); window 15 has confidences of 3, so
+    that its LM loop rejects trials (against the oracle, which tests/test_oracle_golden.py pins to the reference's
+    rejections): the other windows must not notice."""
+    from vinsat_amd import od_pipe
+    g, win = load_golden("c3"), _window("c3")
+    iters, inits = [int(x) for x in g["iters"]], [bool(x) for x in g["initialize"]]
+    W = 16
+    conf3 = np.full_like(win.confidences, 3.0)
+    eng = _engine(win, windows=W)
+    n = win.time_idx.size
+    eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, conf3, win.ii, n, window=15)
+    st_other = od_pipe.initial_guess(win, seed=7)
+    for w in range(W):
+        eng.set_states(st_other if w == 14 else g["states0"][0], 1e-4, window=w)
+    single = _engine(win)
+    ref14, lam14 = st_other, 1e-4
+    ref15, lam15 = g["states0"][0].copy(), 1e-4
+    seen15 = []
+    for k in range(20):
+        eng.step(iters[k], inits[k])
+        ref14, lam14, _, ntr14, _ = single.iterate(iters[k], inits[k], lam14, ref14)
+        lam15_in = lam15
+        ref15, lam15, _, ntr15 = O.ba_iteration(iters[k], ref15, win.cumrot_last, win.landmarks_uv, win.landmarks_xyz, win.ii,
+                                                win.time_idx, win.intrinsics, conf3, lam15, initialize=inits[k])
+        seen15.append(ntr15)
+        for w in (0, 5, 13):
+            st, lam, _, ntr, flags = eng.get_states(window=w)
+            assert ntr == g["n_trials"][k] and lam == g["lamda_out"][k] and flags == 0, (k, w)
+            if k in CHECKPOINTS:
+                _close_to_reference(st, g[f"states_out_{k}"][0], k)
+            if w == 0:
+                st0w = st
+            else:
+                assert np.array_equal(st, st0w), (k, w)         # equal windows: equal bits
+        st, lam, _, ntr, flags = eng.get_states(window=14)
+        assert ntr == ntr14 and lam == lam14 and flags == 0, k
+        assert rel_err(st, ref14) < 1e-6, k          # another reduction tree (8 lanes per pose, one wave per chain)
+        st, lam, _, ntr, flags = eng.get_states(window=15)
+        assert ntr == ntr15 and lam == lam15, (k, ntr, ntr15)
+        # "lamda too large" (BA_filtering.py:75-77) only when the damping really ran out
+        assert flags in (0, 1) and (flags == 0 or lam15_in * 10.0 ** ntr15 > 1e4), (k, flags)
+        assert rel_err(st, ref15) < 1e-6, k
+    assert max(seen15) >= 3, seen15                 # the window did reject trials
+    stepped = [eng.get_states(window=w) for w in range(W)]
+    # the same 20 calls chained on the device (what bench.py issues): bit for bit
+    for w in range(W):
+        eng.set_states(st_other if w == 14 else g["states0"][0], 1e-4, window=w)
+    eng.run_schedule(iters, inits)
+    for w in range(W):
+        got = eng.get_states(window=w)
+        assert np.array_equal(got[0], stepped[w][0]) and got[1] == stepped[w][1] and got[3] == stepped[w][3], w
+    single.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["c3", "c4"])
+def test_warm_select_miss_paths_at_bench_size(name):
+    """100 000 (C3) and 400 000 (C4: 1/512-binade bins) carried keys: a warm select forced to miss on every call, and bin
+    buckets too short for the bin of the median (a real overflow: the key is dropped on the writing side and the reader
+    reports a miss), both end in the bits of the default path and of the exact digit passes."""
+    g, win = load_golden(name), _window(name)
+    iters, inits = [int(x) for x in g["iters"]], [bool(x) for x in g["initialize"]]
+    outs = {}
+    for mode in ("default", "exact", "forced-miss", "overflow-16", "overflow-64"):
+        eng = _engine(win)
+        if mode == "exact":
+            eng.set_warm_select(0)
+        elif mode == "forced-miss":
+            eng.set_warm_select(2)
+        elif mode.startswith("overflow"):
+            eng.set_bucket_cap(int(mode.split("-")[1]))
+        eng.set_states(g["states0"][0], 1e-4)
+        eng.run_schedule(iters, inits)
+        outs[mode] = eng.get_states()
+        misses = eng.warm_select_misses()
+        if mode in ("default", "exact"):
+            assert misses == 0, (mode, misses)
+        elif mode == "forced-miss":
+            assert misses >= 19, misses
+        else:       # the bin of the median holds ~130 (C3) / ~260 (C4) keys
+            assert misses >= 15, (mode, misses)
+        eng.close()
+    ref = outs["default"]
+    _close_to_reference(ref[0], g["states_out_19"][0], 19)
+    for mode, o in outs.items():
+        assert np.array_equal(o[0], ref[0]) and o[1] == ref[1] and o[3] == ref[3] and o[4] == ref[4], mode
+
+
+@pytest.mark.parametrize("seed", [276, 294])
+def test_degenerate_random_windows_differ_by_conditioning_not_by_code_path(seed):
+    """Seeds 276 (37 poses / 116 rows) and 294 (13 poses / 16 rows) of the randomised test exceed its FREE-RUNNING 1e-5 bar.
+    Each call started from the oracle's state agrees as everywhere else; and the oracle's own two solvers (LAPACK banded LU
+    against dense LU on the same matrices) drift apart by as much over the six free-running calls
+    (tests/test_oracle_golden.py::test_conditioning_of_the_degenerate_random_windows) -- the GPU chain stays within a small
+    multiple of that."""
+    import random_windows
+    from vinsat_amd.engine import BAEngine
+    win, xyz, uv, ii, conf, t, st0 = random_windows.make(seed)
+    n = win.time_idx.size
+    args = (win.cumrot_last, uv, xyz, ii, t, win.intrinsics, conf)
+    eng = BAEngine(n, ii.size)
+    eng.upload_observations(xyz, uv, conf, ii, n)
+    eng.upload_window(win.intrinsics, win.cumrot_last, t)
+    chains = {}
+    for solver in ("banded", "dense"):
+        st, lam = st0.copy(), 1e-4
+        for it, init in random_windows.SCHEDULE:
+            if solver == "banded":      # like for like: this call from the oracle's state
+                out, lam_g, hess, ntr, flags = eng.iterate(it, init, lam, st)
+            st, lam, hess_ref, ntr_ref = O.ba_iteration(it, st, *args, lam, initialize=init, solver=solver)
+            if solver == "banded":
+                assert ntr == ntr_ref and lam_g == lam
+                assert rel_err(out, st) < 1e-6, it
+        chains[solver] = st
+    drift = rel_err(chains["banded"], chains["dense"])
+    assert drift > 1e-6                         # the oracle disagrees with itself at this level
+    eng.set_states(st0, 1e-4)
+    eng.run_schedule([c[0] for c in random_windows.SCHEDULE], [c[1] for c in random_windows.SCHEDULE])
+    free = eng.get_states()[0]
+    assert min(rel_err(free, chains["banded"]), rel_err(free, chains["dense"])) < 10 * drift
+    eng.close()

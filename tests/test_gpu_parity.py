@@ -797,21 +797,10 @@ def test_randomised_windows_vs_oracle(seed):
     """Random window shapes (2..70 poses, 0..60 rows per pose, gaps 1..60 s, confidences 0.3..1.2, shuffled rows),
     random solver settings and a random call schedule, against the oracle."""
     from vinsat_amd.engine import BAEngine
-    from vinsat_amd import od_pipe, synth
-    rng = np.random.default_rng(1000 + seed)
-    n_target = int(rng.integers(2, 71))
-    det, orb = synth.make_sequence(synth.WindowConfig("rnd", n_target, int(rng.integers(3, 61)), 5), seed=seed)
-    win = od_pipe.prepare_window(det, orb)
+    from vinsat_amd import od_pipe
+    import random_windows
+    win, xyz, uv, ii, conf, t, _ = random_windows.make(seed)
     n = win.time_idx.size
-    keep = rng.random(win.ii.size) < rng.uniform(0.3, 1.0)
-    if n > 3:
-        keep[win.ii == int(rng.integers(0, n))] = False            # one pose without rows
-    if keep.sum() < 2:
-        keep[:2] = True
-    order = rng.permutation(np.nonzero(keep)[0])
-    xyz, uv, ii = win.landmarks_xyz[order], win.landmarks_uv[order], win.ii[order]
-    conf = rng.uniform(0.3, 1.2, size=ii.size)
-    t = np.cumsum(np.concatenate([[10], rng.integers(1, 61, size=n - 1)])).astype(np.int64)
     eng = BAEngine(n, ii.size)
     mode = seed % 4
     if mode == 1:
@@ -825,7 +814,7 @@ def test_randomised_windows_vs_oracle(seed):
     args = (win.cumrot_last, uv, xyz, ii, t, win.intrinsics, conf)
     st = od_pipe.initial_guess(win, seed=seed)
     lam = 1e-4
-    sched = [(0, True), (1, True), (3, True), (10, False), (12, False), (19, False)]
+    sched = random_windows.SCHEDULE
     ref, lam_ref = st.copy(), lam
     for it, init in sched:
         # every call starts from the oracle's state, so each comparison is like for like (ill-conditioned random

@@ -150,3 +150,22 @@ def test_c5_subwindow_pins_the_oracle_on_the_c5_orbit():
         assert ntr == g["n_trials"][k] and lam == g["lamda_out"][k], k
         if f"states_out_{k}" in g:
             assert rel_err(st, g[f"states_out_{k}"][0]) < 1e-8, k
+
+
+@pytest.mark.parametrize("seed,degenerate", [(0, False), (1, False), (2, False), (3, False), (276, True), (294, True)])
+def test_conditioning_of_the_degenerate_random_windows(seed, degenerate):
+    """Evidence for DESIGN.md section 5: the two random windows whose FREE-RUNNING six-call chain misses the 1e-5 bar on the
+    GPU (seeds 276: 37 poses / 116 rows, 294: 13 poses / 16 rows) are ill-conditioned, not mis-computed -- the oracle's own
+    two solvers (LAPACK banded LU and dense LU, the reference's torch.linalg.solve, on identical matrices) drift apart by
+    4e-6 / 1e-5 over the same six calls there, and by ~1e-11 on ordinary windows."""
+    import random_windows
+    win, xyz, uv, ii, conf, t, st0 = random_windows.make(seed)
+    ends = {}
+    for solver in ("banded", "dense"):
+        st, lam = st0.copy(), 1e-4
+        for it, init in random_windows.SCHEDULE:
+            st, lam, _, _ = O.ba_iteration(it, st, win.cumrot_last, uv, xyz, ii, t, win.intrinsics, conf, lam, initialize=init,
+                                           solver=solver)
+        ends[solver] = st
+    drift = np.abs(ends["banded"] - ends["dense"]).max() / np.abs(ends["dense"]).max()
+    assert (drift > 1e-6) if degenerate else (drift < 1e-9), drift

@@ -97,6 +97,7 @@ struct vba_context {
     int inline_select = 1;                  // latency mode: warm select inside the accumulation (bin buckets); vba_set_warm_select(h, 3) turns it off
     int chunk_waves = 2;                    // vba_set_chunk_waves
     int fusion = 9;                         // vba_set_fusion (default: the trial kernel forms the step)
+    int bucket_cap_alloc = 0;               // allocated capacity of a bin bucket (vba_set_bucket_cap lowers the one in use)
     int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
     size_t dbg_cap = 0;
@@ -255,6 +256,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.hist = A.take<unsigned>(W * kHistStride);
     V.wbucket = bucket_cap ? A.take<double>(W * 2 * (size_t)kSelBins * bucket_cap) : nullptr;
     V.bucket_cap = bucket_cap;
+    h->bucket_cap_alloc = bucket_cap;
     V.sel_inline = 0;
     V.Hraw = h->Hraw2 = A.take<double>(2 * W * N * 21); V.braw = h->braw2 = A.take<double>(2 * W * N * 6);
     // (the pose-chain factor's outputs: per call parity as well, see wraw2)
@@ -445,6 +447,15 @@ int vba_set_warm_select(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     h->warm_enabled = on == 2 ? 2 : (on != 0);
     h->inline_select = on != 3;     // 3: warm select as its own kernel (k_select_warm), the round-2 mid-point; comparison / tests
+    return VBA_OK;
+}
+
+int vba_set_bucket_cap(vba_handle h, int cap) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (!h->bucket_cap_alloc) return fail(VBA_ESTATE, "this handle has no bin buckets (16 windows or more)");
+    if (cap != 0 && (cap < 8 || cap > h->bucket_cap_alloc)) return fail(VBA_EINVAL, "cap must be 0 (default) or in [8, allocated capacity]");
+    h->V.bucket_cap = cap ? cap : h->bucket_cap_alloc;
+    h->carry_ok = 0;            // buckets filled with another stride are not addressable any more
     return VBA_OK;
 }
 
@@ -1088,6 +1099,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
         if (next >= ncalls) { complete = true; break; }
     }
     if (!complete) {
+        complete = true;
         for (int w = 0; w < h->W; ++w) complete = complete && head(h, w)->call_idx >= ncalls;
         if (!complete) return fail(VBA_ESTATE, "chained schedule did not complete (a window never reached its last call)");
     }
