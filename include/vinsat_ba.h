@@ -125,7 +125,7 @@ int vba_set_prior(vba_handle h, int on);
  * on == 0: every call recomputes them (same bits; for comparison). */
 int vba_set_key_carry(vba_handle h, int on);
 
-/* Warm select (default: on for handles of fewer than 16 windows, off beyond).  The exact lower median of the 2m keys |r| (torch.median, BA_filtering.py:23) is found by
+/* Warm select (default: on).  The exact lower median of the 2m keys |r| (torch.median, BA_filtering.py:23) is found by
  * radix select.  On carried keys the trial that produced them has already binned them into 2046 narrow bins around the
  * median of its own call (consecutive calls move the median by a factor 0.3 .. 2.5), so ONE pass over the keys -- the
  * compaction of the bin that holds the wanted rank -- replaces the two digit passes; the short list is ranked exactly as
@@ -139,6 +139,11 @@ int vba_set_key_carry(vba_handle h, int on);
  * the accumulation kernel resolves the histogram, ranks that bucket and evaluates the folded accept test in its own
  * prologue, and a chained landmark-only call is two kernels.  on == 3: keep the select as its own kernel (comparison). */
 int vba_set_warm_select(vba_handle h, int on);
+/* Tuning / test knob: log2 of the width of a warm bin in bit patterns (52 = one binade).  Defaults: 44 (1/256 binade; 43 for
+ * more than 300 000 keys) in latency mode, where the bin of the median must be a short bucket; 49 (1/8 binade) for handles
+ * of 16 windows and more, where a block's histogram flush costs one global atomic per bin it touched and the few per cent of
+ * the keys in the median's bin are compacted by one pass.  The median is exact for every width. */
+int vba_set_warm_shift(vba_handle h, int shift);
 int vba_warm_select_misses(vba_handle h, int* count);
 /* Test knob: capacity of a bin bucket (latency mode), 8 .. the allocated one; 0 restores the default.  A bin that holds more
  * keys than that overflows -- its bucket is incomplete -- and a call whose median falls into it takes the miss path. */

@@ -16,7 +16,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_golden, rel_err
+from conftest import GOLDEN, load_golden, rel_err  # noqa: F401  (c2 fixture comes from conftest)
 from oracle import ba_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -217,3 +217,40 @@ def test_degenerate_random_windows_differ_by_conditioning_not_by_code_path(seed)
     free = eng.get_states()[0]
     assert min(rel_err(free, chains["banded"]), rel_err(free, chains["dense"])) < 10 * drift
     eng.close()
+
+
+def test_batched_warm_select_gives_the_bits_of_the_exact_digit_passes(c2):
+    """Handles of 16 windows and more select warm as well since round 3: the trial kernel bins its keys in 1/64-binade bins
+    around its own median, ONE pass (k_select_warm, a block reserves its share of the list with one atomic) compacts the bin
+    of the wanted rank and k_select_finish ranks that list (also the long-list path: 1/8-binade bins hold a few hundred
+    keys here).  The median must be the exact lower median of the device's own residuals -- the carried keys have the bits
+    the next call's reprojection produces, whichever kernel made them (vba_math.h: vba_mul / vba_add) -- and the states
+    after 20 calls the bits of the exact two-pass select."""
+    from conftest import golden_inputs
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    W = 16
+    res = {}
+    for mode in ("exact", "warm-default", "warm-49", "warm-44"):
+        e = BAEngine(n, m, windows=W)
+        if mode == "exact":
+            e.set_warm_select(0)
+        elif mode != "warm-default":
+            e.set_warm_shift(int(mode.split("-")[1]))
+        for w in range(W):
+            e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n, window=w)
+            e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"], window=w)
+            e.set_states(g["states0"][0], 1e-4, window=w)
+        for k in range(20):
+            e.step(k, k < 10)
+            sc = e.debug("scalars", window=3)
+            a = np.abs(inp["uv"] - e.debug("est", window=3)).reshape(-1)
+            assert sc[0] == np.sort(a)[(a.size - 1) // 2], (mode, k)
+            assert sc[7] == g["n_trials"][k]
+        assert e.warm_select_misses() == 0
+        res[mode] = e.get_states(window=3)
+        e.close()
+    for mode, o in res.items():
+        assert np.array_equal(o[0], res["exact"][0]) and o[1] == res["exact"][1], mode
+    assert rel_err(res["exact"][0], g["states_out_19"][0]) < 1e-7

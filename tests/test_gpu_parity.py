@@ -120,7 +120,9 @@ def test_c2_weights_and_blocks_vs_oracle(eng_c2, c2):
         # gives the same bits (the oracle's value differs in the last ulp because its residuals do)
         a = np.abs(inp["uv"] - eng_c2.debug("est")).reshape(-1)
         assert sc[0] == np.sort(a)[(a.size - 1) // 2]
-        assert rel_err(sc[0], dbg["c_obs"]) < 1e-13
+        # vs the oracle: the reference rotates with quaternion products (BA_utils.py:1052-1069), the kernels with the matrix of
+        # the normalised quaternion; one ulp of a matrix entry is ~2e-12 px here (f ~ 17 500 px, range ~ 600 km)
+        assert rel_err(sc[0], dbg["c_obs"]) < 1e-11
         assert rel_err(sc[1], dbg["wmax"]) < 1e-14
         assert rel_err(eng_c2.debug("weight"), dbg["w"]) < 1e-11     # pow() differs in the last bits
         assert rel_err(eng_c2.debug("H"), dbg["H"]) < 1e-12

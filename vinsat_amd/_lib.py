@@ -32,6 +32,7 @@ SIGNATURES = {
     "vba_set_fusion": (c_int, [c_void_p, c_int]),
     "vba_set_chunk_waves": (c_int, [c_void_p, c_int]),
     "vba_set_warm_select": (c_int, [c_void_p, c_int]),
+    "vba_set_warm_shift": (c_int, [c_void_p, c_int]),
     "vba_set_bucket_cap": (c_int, [c_void_p, c_int]),
     "vba_warm_select_misses": (c_int, [c_void_p, POINTER(c_int)]),
     "vba_set_pivoting": (c_int, [c_void_p, c_int]),

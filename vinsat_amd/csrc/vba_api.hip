@@ -85,6 +85,7 @@ struct vba_context {
                                     // exponent histogram, 2 with the warm histogram (the kind the last trial emitted)
     bool carry_enabled = true;
     bool hist_dirty = false;        // a k_trial<true> has left a warm histogram (digit-0 slot of parity `par`) behind that nobody consumed
+    bool fold_enabled = true;       // chained schedule: the first kernel of call c + 1 evaluates the accept test of call c (latency mode)
     int warm_enabled = 1;           // carried keys are selected with the one-pass warm select (vba_set_warm_select; 2: forced misses, test knob)
     int last_iter = 0, last_init = 0;
     int sh_pivot = 0;                       // sharded mode: solver variant of the current call (0 unpivoted, 2 mixed after a failed check)
@@ -202,7 +203,11 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     need(W * kHistStride * 4);
     // bin buckets of the carried keys (latency mode only): capacity ~6x the count of the densest warm bin -- the bin of the
     // median holds ~0.13 % of the keys with 1/256-binade bins, half of that with 1/512 (see warm_shift below)
-    const int warm_shift = 2 * m_max <= 300000 ? 44 : 43;
+    // ... and 2^46 (1/64 of a binade, range [c / 2^16, c * 2^16)) for handles of many windows: the flush of a block's
+    // histogram costs a global atomic per bin it touched, coarser bins contend in LDS and lengthen the list the single pass
+    // (k_select_warm) compacts and k_select_finish ranks -- about half a per cent of the keys here.  Swept 44 .. 51 at
+    // 4096 x C3: 10.53 / 9.94 / 9.85 / 9.87 / 9.90 / 9.94 / 10.03 ms per step for 44 .. 50 (exact two-pass select: 10.12)
+    const int warm_shift = windows >= 16 ? 46 : (2 * m_max <= 300000 ? 44 : 43);
     int bucket_cap = 0;
     if (windows < 16) {
         const double expect = 2.0 * (double)m_max * (warm_shift == 44 ? 0.0013 : 0.00065) * 6.0;
@@ -320,10 +325,10 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     h->perm.resize(W);
     vba_set_accumulate_lanes(h, 0);
     vba_set_solver(h, -1);
-    // warm select: a latency-mode feature (one pass and no decide launch per chained call); with many windows per launch
-    // the ~1 global atomic per key of its 2048-bin histogram costs more than the second pass over the keys it saves
-    // (measured at 4096 windows: trial + select 5.2 ms against 4.8 ms)
-    h->warm_enabled = windows < 16 ? 1 : 0;
+    // warm select everywhere; the accept test is folded into the next call's first kernel only in latency mode (with many
+    // windows the decide launch is 20 us of a 10 ms step, and every block of the select would repeat the test)
+    h->warm_enabled = 1;
+    h->fold_enabled = windows < 16;
     *out = h;
     return VBA_OK;
 }
@@ -447,6 +452,14 @@ int vba_set_warm_select(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     h->warm_enabled = on == 2 ? 2 : (on != 0);
     h->inline_select = on != 3;     // 3: warm select as its own kernel (k_select_warm), the round-2 mid-point; comparison / tests
+    return VBA_OK;
+}
+
+int vba_set_warm_shift(vba_handle h, int shift) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (shift < 42 || shift > 51) return fail(VBA_EINVAL, "shift must be in [42, 51]");
+    h->V.warm_shift = shift;
+    h->carry_ok = 0;            // a histogram binned with another width cannot be resolved
     return VBA_OK;
 }
 
@@ -1008,14 +1021,14 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     for (int guard = 0; guard <= ncalls; ++guard) {
         // speculative part: calls next .. ncalls-1, one trial each
         for (int c = next; c < ncalls; ++c) {
-            const bool fold = c > next && emit_kind == 2;       // call c-1 of this pass left its decision to this call's warm select
+            const bool fold = c > next && emit_kind == 2 && h->fold_enabled;       // call c-1 of this pass left its decision to this call's warm select
             const CallSpec q = spec(c, fold);
             CallCtx C;
             view_for_call(h, C.V, q);
             if (fold) fill_params(C.V.prev, iters[c - 1], inits[c - 1]);
             if (int rc = enqueue_front(h, C, q, false, nullptr)) return rc;
             enqueue_trial(h, C, q, true);
-            const bool next_folds = c + 1 < ncalls && emit_kind == 2;
+            const bool next_folds = c + 1 < ncalls && emit_kind == 2 && h->fold_enabled;
             if (!next_folds) launch_decide(C.V, nullptr, 0, s);
         }
         HIPCHK(hipGetLastError());

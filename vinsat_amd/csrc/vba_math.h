@@ -24,6 +24,21 @@ constexpr double kZMin = 0.1;          // BA_utils.py:13
 constexpr double kQuatCoeff = 100.0;   // BA_filtering.py:11
 constexpr double kVelCoeff = 100.0;    // BA_filtering.py:12
 
+// A product / a sum rounded on its own, never contracted into an fma: the build uses -ffp-contract=fast-honor-pragmas
+// (HIP's default mode), under which the pragma below is obeyed also after inlining into a kernel.
+VBA_HD double vba_mul(double a, double b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    return a * b;
+}
+VBA_HD double vba_add(double a, double b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    return a + b;
+}
+
 // index of (a,b), a<=b, in the packed upper triangle of a symmetric 6x6
 VBA_HD int sym6(int a, int b) {
     if (a > b) { int t = a; a = b; b = t; }
@@ -43,11 +58,17 @@ VBA_HD void pose_camera(const double* s /*[10]*/, const double* K /*[4]*/, PoseC
     double x = s[3], y = s[4], z = s[5], w = s[6];
     // one division, four products (the reference divides each component, BA_utils.py:1058: same value to an ulp; the
     // four fp64 divisions were a quarter of the instructions of the per-observation kernels)
-    const double inv = 1.0 / sqrt(x * x + y * y + z * z + w * w);
-    x *= inv; y *= inv; z *= inv; w *= inv;
-    pc.R[0] = 1 - 2 * (y * y + z * z); pc.R[1] = 2 * (x * y - z * w);     pc.R[2] = 2 * (x * z + y * w);
-    pc.R[3] = 2 * (x * y + z * w);     pc.R[4] = 1 - 2 * (x * x + z * z); pc.R[5] = 2 * (y * z - x * w);
-    pc.R[6] = 2 * (x * z - y * w);     pc.R[7] = 2 * (y * z + x * w);     pc.R[8] = 1 - 2 * (x * x + y * y);
+    // Every product and sum below is rounded on its own (vba_mul / vba_add: never contracted into an fma).  With
+    // -ffp-contract=fast the compiler would otherwise be free to contract `a*b + c*d` one way in one kernel and another way
+    // in the next, and the |r| keys a trial kernel leaves behind must carry the bits the next call's own reprojection
+    // produces.  Operation by operation this is also what the oracle's NumPy expressions do (oracle/ba_oracle.py).
+    const double inv = 1.0 / sqrt(vba_add(vba_add(vba_add(vba_mul(x, x), vba_mul(y, y)), vba_mul(z, z)), vba_mul(w, w)));
+    x = vba_mul(x, inv); y = vba_mul(y, inv); z = vba_mul(z, inv); w = vba_mul(w, inv);
+    const double xx = vba_mul(x, x), yy = vba_mul(y, y), zz = vba_mul(z, z);
+    const double xy = vba_mul(x, y), xz = vba_mul(x, z), yz = vba_mul(y, z), xw = vba_mul(x, w), yw = vba_mul(y, w), zw = vba_mul(z, w);
+    pc.R[0] = vba_add(1.0, -vba_mul(2.0, vba_add(yy, zz))); pc.R[1] = vba_mul(2.0, vba_add(xy, -zw)); pc.R[2] = vba_mul(2.0, vba_add(xz, yw));
+    pc.R[3] = vba_mul(2.0, vba_add(xy, zw)); pc.R[4] = vba_add(1.0, -vba_mul(2.0, vba_add(xx, zz))); pc.R[5] = vba_mul(2.0, vba_add(yz, -xw));
+    pc.R[6] = vba_mul(2.0, vba_add(xz, -yw)); pc.R[7] = vba_mul(2.0, vba_add(yz, xw)); pc.R[8] = vba_add(1.0, -vba_mul(2.0, vba_add(xx, yy)));
     pc.fx = K[0]; pc.fy = K[1]; pc.cx = K[2]; pc.cy = K[3];
 }
 
@@ -55,9 +76,9 @@ VBA_HD void pose_camera(const double* s /*[10]*/, const double* K /*[4]*/, PoseC
 VBA_HD void project(const PoseCam& pc, double X, double Y, double Z, double& u, double& v, double* cam /*[3]*/,
                     double& d) {
     const double dx = X - pc.t[0], dy = Y - pc.t[1], dz = Z - pc.t[2];
-    cam[0] = pc.R[0] * dx + pc.R[3] * dy + pc.R[6] * dz;
-    cam[1] = pc.R[1] * dx + pc.R[4] * dy + pc.R[7] * dz;
-    cam[2] = pc.R[2] * dx + pc.R[5] * dy + pc.R[8] * dz;
+    cam[0] = vba_add(vba_add(vba_mul(pc.R[0], dx), vba_mul(pc.R[3], dy)), vba_mul(pc.R[6], dz));     // (see pose_camera)
+    cam[1] = vba_add(vba_add(vba_mul(pc.R[1], dx), vba_mul(pc.R[4], dy)), vba_mul(pc.R[7], dz));
+    cam[2] = vba_add(vba_add(vba_mul(pc.R[2], dx), vba_mul(pc.R[5], dy)), vba_mul(pc.R[8], dz));
     const double zc = cam[2] > kZMin ? cam[2] : kZMin;
 #if defined(__HIP_DEVICE_COMPILE__)
     // 1 / zc from v_rcp_f64 refined to ~1 ulp (r (1 + e + e^2), e = 1 - zc r): the IEEE division sequence is ~30
@@ -68,8 +89,8 @@ VBA_HD void project(const PoseCam& pc, double X, double Y, double Z, double& u, 
 #else
     d = 1.0 / zc;
 #endif
-    u = pc.fx * (d * cam[0]) + pc.cx;
-    v = pc.fy * (d * cam[1]) + pc.cy;
+    u = vba_add(vba_mul(pc.fx, vba_mul(d, cam[0])), pc.cx);
+    v = vba_add(vba_mul(pc.fy, vba_mul(d, cam[1])), pc.cy);
 }
 
 // 2x6 Jacobian of (u,v) w.r.t. [dp, dtheta] (BA_utils.py:44-48): [-Jpi R^T | 2 Jpi hat(p_c)], with the

@@ -318,6 +318,45 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
     unsigned bin, in_bin;
     long long rank;
     if (warm_front(V, w, fold_here, false, 2 * V.m_max, red, lds_u, bin, rank, in_bin) != kWarmHit) return;
+    if constexpr (!PRELOAD) {
+        // Many windows per launch, coarse warm bins (1/8 binade: a few per cent of the keys match).  A returning atomic per
+        // wave instruction would be a chain of ITEMS dependent round trips; instead the block counts its matches first,
+        // reserves its share of the list with ONE atomic and then writes.  The keys stay in registers in between.
+        double2 kk[PAIRS];
+        unsigned long long mbits = 0ull;        // bit 2 it: kk[it].x matches, bit 2 it + 1: kk[it].y
+#pragma unroll
+        for (int it = 0; it < PAIRS; ++it) {
+            const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + t;
+            const bool have = idx < npair;
+            kk[it] = have ? keys2[idx] : make_double2(0.0, 0.0);
+            if (have && warm_bin(f64_bits(kk[it].x), lo, V.warm_shift) == bin) mbits |= 1ull << (2 * it);
+            if (have && warm_bin(f64_bits(kk[it].y), lo, V.warm_shift) == bin) mbits |= 2ull << (2 * it);
+        }
+        const unsigned mine = (unsigned)__popcll(mbits);
+        unsigned inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned v = __shfl_up(inc, o, kWave);
+            if ((t & 63) >= o) inc += v;
+        }
+        __syncthreads();            // lds_u was read by the resolve above
+        if ((t & 63) == 63) lds_u[t >> 6] = inc;
+        __syncthreads();
+        if (t == 0) {
+            const unsigned total = lds_u[0] + lds_u[1] + lds_u[2] + lds_u[3];
+            lds_u[4] = total ? atomicAdd(&sc.sel_cnt, total) : 0u;
+        }
+        __syncthreads();
+        unsigned at = lds_u[4] + inc - mine;
+        for (int q = 0; q < (t >> 6); ++q) at += lds_u[q];
+        double* list = V.ckeys + 2 * (size_t)w * V.m_max;
+#pragma unroll
+        for (int it = 0; it < PAIRS; ++it) {
+            if (mbits & (1ull << (2 * it))) list[at++] = kk[it].x;
+            if (mbits & (2ull << (2 * it))) list[at++] = kk[it].y;
+        }
+        return;
+    }
     auto take = [&](unsigned long long key, bool have) {
         const bool match = have && warm_bin(key, lo, V.warm_shift) == bin;
         const unsigned long long mask = __ballot(match);
@@ -330,13 +369,14 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
             if (match) V.ckeys[2 * (size_t)w * V.m_max + base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = bits_f64(key);
         }
     };
+    if constexpr (PRELOAD) {
 #pragma unroll 8
-    for (int it = 0; it < PAIRS; ++it) {
-        const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + t;
-        const bool have = idx < npair;
-        const double2 kk = PRELOAD ? pk[it] : (have ? keys2[idx] : make_double2(0.0, 0.0));
-        take(f64_bits(kk.x), have);
-        take(f64_bits(kk.y), have);
+        for (int it = 0; it < PAIRS; ++it) {
+            const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + t;
+            const bool have = idx < npair;
+            take(f64_bits(pk[it].x), have);
+            take(f64_bits(pk[it].y), have);
+        }
     }
 }
 
@@ -442,6 +482,43 @@ __device__ __forceinline__ double select_finish_list(const DevView& V, int w, co
         unsigned long long prefix = 0ull;
         long long rank = want;
         int remaining = V.warm_shift;
+        if (remaining > 11) {
+            // first digit, then -- the usual case: thousands of keys spread over 2048 sub-bins -- the handful of keys of the
+            // wanted sub-bin is gathered in LDS and ranked by counting: two passes over the list instead of one per digit
+            remaining -= 11;
+            for (int b = threadIdx.x; b < kSelBins; b += 256) lh[b] = 0u;
+            if (threadIdx.x == 0) lds_u[18] = 0u;
+            __syncthreads();
+            for (unsigned q = threadIdx.x; q < cnt; q += 256) {
+                const unsigned long long rel = f64_bits(ck[q]) - warm_base;
+                atomicAdd(&lh[(unsigned)(rel >> remaining) & 2047u], 1u);
+            }
+            __syncthreads();
+            unsigned sub_cnt;
+            {
+                unsigned loc[8];
+                select_load(lh, kSelBins, loc);
+                select_resolve_loaded(loc, kSelBins, 11, 0ull, rank, prefix, rank, lds_u, &sub_cnt);
+            }
+            if (sub_cnt <= 1024u) {
+                for (unsigned q = threadIdx.x; q < cnt; q += 256) {
+                    const unsigned long long key = f64_bits(ck[q]);
+                    if (((key - warm_base) >> remaining) == prefix) skeys[atomicAdd(&lds_u[18], 1u)] = key;
+                }
+                __syncthreads();
+                for (unsigned q = threadIdx.x; q < sub_cnt; q += 256) {
+                    const unsigned long long key = skeys[q];
+                    long long below = 0;
+                    for (unsigned j = 0; j < sub_cnt; ++j) {
+                        const unsigned long long o = skeys[j];
+                        below += (o < key) || (o == key && j < q);
+                    }
+                    if (below == rank) skeys[1024] = key;
+                }
+                __syncthreads();
+                return bits_f64(skeys[1024]);
+            }
+        }
         while (remaining > 0) {
             const int width = remaining < 11 ? remaining : 11;
             remaining -= width;
@@ -523,16 +600,19 @@ constexpr int kAccDepth = VBA_ACC_DEPTH;
 
 // PAIR: a lane takes two consecutive observations per step with 16-byte loads, so that the G lanes of a pose read
 // whole 128-byte lines (G = 8) instead of half lines whose other half is fetched again by the next step.
-template <int G, bool PAIR>
+// BATCH: the variant of handles with many windows -- the median is in sc.c_obs already (k_select_finish), nothing rides in
+// the grid and nothing is selected inline, so none of that code (nor its registers: the rider alone needs ~195) is compiled in.
+template <int G, bool PAIR, bool BATCH>
 __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     __shared__ double wmx[4];
-    __shared__ unsigned sel_lh[kSelBins];
-    __shared__ unsigned sel_u[260];
-    __shared__ unsigned long long sel_keys[1025];
-    __shared__ double dec_red[5][4];
+    __shared__ unsigned sel_lh[BATCH ? 1 : kSelBins];
+    __shared__ unsigned sel_u[BATCH ? 1 : 260];
+    __shared__ unsigned long long sel_keys[BATCH ? 1 : 1025];
+    __shared__ double dec_red[BATCH ? 1 : 5][4];
     constexpr int PPB = 256 / G;            // poses per block
     const int w = blockIdx.y;
     WinScalars& sc = V.sc[w];
+    if (BATCH) { V.sel_inline = 0; V.dyn_in_acc = 0; V.median_ready = 1; }
     // Inline select (V.sel_inline: latency mode, carried keys in bin buckets): this kernel STARTS the call -- no select
     // kernel in front of it.  In a chained schedule its blocks evaluate the accept test of the call in front themselves
     // (warm_front) and go on only if that first trial was cleanly accepted.
@@ -569,7 +649,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
         }
         return;
     }
-    if ((int)blockIdx.x >= nb_acc) {        // few windows: the dynamics factor rides in this grid (vba_dyn_body.h)
+    if (!BATCH && (int)blockIdx.x >= nb_acc) {        // few windows: the dynamics factor rides in this grid (vba_dyn_body.h)
         // (a function of the input states only: neither a missed select nor, by default, the accept test concerns it --
         // what it writes is read by this call's own assembly, which runs only if the window has moved on)
         if (fold_here && ordered) {
@@ -634,7 +714,9 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 
     // Phase 2: the median (every block of the window finishes the select itself, see select_finish)
     RobustParams rp;
-    if (V.sel_inline) {
+    if (BATCH) {
+        rp.c = sc.c_obs;        // k_select_finish
+    } else if (V.sel_inline) {
         // the trial kernel of the call in front dropped every key into the bucket of its warm bin: resolve the histogram,
         // rank the wanted bin's bucket.  Every block does this redundantly (a few hundred keys), nothing is compacted.
         unsigned bin, in_bin;
@@ -830,8 +912,12 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 // of 1 / 2 with the trial states read from memory (a call of such a handle that cannot fuse: pivoted landmark-only solve).
 constexpr int kEdgesPerBlock16 = 15;
 
-template <int EMIT, int FUSED>
+// PART (many windows per launch, FUSED 0): 0 = one grid does both kinds of block; 1 = the observation blocks only, 2 = the
+// pose-chain blocks only, as two launches -- the orbit propagation of the chain blocks costs the streaming blocks half
+// their occupancy when both are one kernel (96 registers against 40).
+template <int EMIT, int FUSED, int PART = 0>
 __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
+    static_assert(PART == 0 || FUSED == 0, "split launches exist for the plain geometry only");
     constexpr bool FORM = FUSED == 1 || FUSED == 2;
     __shared__ double red[kObsBlock / 64];
     __shared__ unsigned lh[EMIT == 2 ? kSelBins : (EMIT == 1 ? 1024 : 1)];
@@ -848,7 +934,8 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     const int tid = threadIdx.x;
     double s = 0.0, s_raw = 0.0;
     const size_t sb = (size_t)w * V.n_max;
-    const bool obs_block = (int)blockIdx.x < V.nblk_obs;
+    const bool obs_block = PART == 1 || (PART == 0 && (int)blockIdx.x < V.nblk_obs);
+    const int part_slot = PART == 2 ? V.nblk_obs + (int)blockIdx.x : (int)blockIdx.x;        // this block's place in part_trial
     const double lam32 = (double)(float)sc.lam[par];      // torch.eye() is float32 (BA_filtering.py:54)
     // a window that has fallen back to the pivoted kernels (landmark-only phase) reads the trial states they wrote
     const bool fz = FUSED == 2 || (FUSED == 1 && !(sc.fl[par] & 16u));
@@ -858,11 +945,11 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     unsigned long long wlo = 0ull;
     constexpr int kEmitBins = EMIT == 2 ? kSelBins : 1024;     // warm bins, or the 10 exponent bits (digit 0 of the exact select)
     if (EMIT == 2) wlo = warm_range_start(f64_bits(sc.c_obs), V.warm_shift);
-    if (EMIT && obs_block) {
+    if (EMIT && PART != 2 && obs_block) {
         for (int b = tid; b < kEmitBins; b += kObsBlock) lh[b] = 0u;
         __syncthreads();
     }
-    if (blockIdx.x == 0) {
+    if (PART != 2 && blockIdx.x == 0) {
         // digits 1, 2 of an exact select are dead since the accumulation; the list of the next warm select starts empty
         unsigned* h12 = histd_of(V, w, 1);
         for (int b = tid; b < 2 * kSelBins; b += kObsBlock) h12[b] = 0u;
@@ -886,7 +973,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     unsigned kbin[2] = {0u, 0u}, kslot[2] = {0u, 0u};      // EMIT 2: warm bin of this thread's two keys and their place in the block's share
     double kkey[2] = {0.0, 0.0};
     bool kvalid = false;
-    if (obs_block) {
+    if (PART != 2 && obs_block) {
         const int k = blockIdx.x * kObsBlock + tid;
         const size_t ob = (size_t)w * V.obs_stride, mb = (size_t)w * V.m_max;
         const bool have = k < m;
@@ -939,19 +1026,24 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
                 if (EMIT == 2) {
                     kbin[0] = warm_bin(f64_bits(ru), wlo, V.warm_shift);
                     kbin[1] = warm_bin(f64_bits(rv), wlo, V.warm_shift);
-                    kslot[0] = atomicAdd(&lh[kbin[0]], 1u);
-                    kslot[1] = atomicAdd(&lh[kbin[1]], 1u);
-                    kkey[0] = ru;
-                    kkey[1] = rv;
-                    kvalid = true;
+                    if (V.wbucket) {        // the place inside the block's share of the bin: a returning atomic
+                        kslot[0] = atomicAdd(&lh[kbin[0]], 1u);
+                        kslot[1] = atomicAdd(&lh[kbin[1]], 1u);
+                        kkey[0] = ru;
+                        kkey[1] = rv;
+                        kvalid = true;
+                    } else {
+                        atomicAdd(&lh[kbin[0]], 1u);
+                        atomicAdd(&lh[kbin[1]], 1u);
+                    }
                 } else {
                     atomicAdd(&lh[(unsigned)(f64_bits(ru) >> 53) & 1023u], 1u);
                     atomicAdd(&lh[(unsigned)(f64_bits(rv) >> 53) & 1023u], 1u);
                 }
             }
         }
-    } else {
-        const int db = blockIdx.x - V.nblk_obs;
+    } else if (PART != 1) {
+        const int db = part_slot - V.nblk_obs;
         const bool reg = V.reg && !prm.initialize;
         // which pose / edge this thread evaluates, and where its two states are
         int i;                      // pose; edge i -> i + 1
@@ -1026,7 +1118,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     constexpr int kBinsPerThread = kSelBins / kObsBlock;
     static_assert(kSelBins % kObsBlock == 0, "bins per thread");
     unsigned bb[kBinsPerThread] = {};
-    const bool bucketing = EMIT == 2 && obs_block && V.wbucket;
+    const bool bucketing = EMIT == 2 && PART == 0 && obs_block && V.wbucket;
     if (bucketing) {
         __syncthreads();        // the block's counts are complete
         unsigned* hist = hist0_of(V, w, par ^ 1);
@@ -1037,12 +1129,12 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
         }
     }
     const double t = block_sum<kObsBlock>(s, red);
-    if (tid == 0) V.part_trial[(size_t)w * V.trial_stride + blockIdx.x] = t;
+    if (tid == 0) V.part_trial[(size_t)w * V.trial_stride + part_slot] = t;
     if (FORM && !obs_block) {
         const unsigned long long bp = __ballot(bad & 1u), bn = __ballot(bad & 2u);
         if ((tid & 63) == 0 && (bp || bn)) atomicOr(&sc.fl[par], (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
     }
-    if (EMIT && obs_block) {
+    if (EMIT && PART != 2 && obs_block) {
         const double t_raw = block_sum<kObsBlock>(s_raw, red);
         if (tid == 0) V.part_next[(size_t)w * V.nblk_obs + blockIdx.x] = t_raw;
         unsigned* hist = hist0_of(V, w, par ^ 1);
@@ -1195,12 +1287,17 @@ void launch_obs_accumulate(const DevView& V, hipStream_t s) {
 #define VBA_ACC_PAIR 1
 #endif
     constexpr bool kPair = VBA_ACC_PAIR != 0;
+    if (V.median_ready && !V.dyn_in_acc && !V.sel_inline && (G == 8 || G == 16)) {      // many windows per launch
+        if (G == 8) hipLaunchKernelGGL((k_obs_accumulate<8, kPair, true>), g, b, 0, s, V);
+        else hipLaunchKernelGGL((k_obs_accumulate<16, false, true>), g, b, 0, s, V);
+        return;
+    }
     switch (G) {
-        case 4: hipLaunchKernelGGL((k_obs_accumulate<4, kPair>), g, b, 0, s, V); break;
-        case 8: hipLaunchKernelGGL((k_obs_accumulate<8, kPair>), g, b, 0, s, V); break;
-        case 16: hipLaunchKernelGGL((k_obs_accumulate<16, false>), g, b, 0, s, V); break;
-        case 32: hipLaunchKernelGGL((k_obs_accumulate<32, false>), g, b, 0, s, V); break;
-        default: hipLaunchKernelGGL((k_obs_accumulate<64, false>), g, b, 0, s, V); break;
+        case 4: hipLaunchKernelGGL((k_obs_accumulate<4, kPair, false>), g, b, 0, s, V); break;
+        case 8: hipLaunchKernelGGL((k_obs_accumulate<8, kPair, false>), g, b, 0, s, V); break;
+        case 16: hipLaunchKernelGGL((k_obs_accumulate<16, false, false>), g, b, 0, s, V); break;
+        case 32: hipLaunchKernelGGL((k_obs_accumulate<32, false, false>), g, b, 0, s, V); break;
+        default: hipLaunchKernelGGL((k_obs_accumulate<64, false, false>), g, b, 0, s, V); break;
     }
 }
 
@@ -1208,6 +1305,11 @@ template <int EMIT>
 static void launch_trial_emit(const DevView& V, hipStream_t s) {
     const dim3 g(V.nblk_obs + V.nblk_dyn, V.W), b(kObsBlock);
     const int f = V.fused_trial;        // 0..3, see k_trial; V.nblk_dyn is the pose-chain block count of that geometry
+    if (f == 0 && V.W >= 16 && !V.wbucket) {        // many windows: the two kinds of block as two launches
+        hipLaunchKernelGGL((k_trial<EMIT, 0, 2>), dim3(V.nblk_dyn, V.W), b, 0, s, V);
+        hipLaunchKernelGGL((k_trial<EMIT, 0, 1>), dim3(V.nblk_obs, V.W), b, 0, s, V);
+        return;
+    }
     if (f == 1) hipLaunchKernelGGL((k_trial<EMIT, 1>), g, b, 0, s, V);
     else if (f == 2) hipLaunchKernelGGL((k_trial<EMIT, 2>), g, b, 0, s, V);
     else if (f == 3) hipLaunchKernelGGL((k_trial<EMIT, 3>), g, b, 0, s, V);

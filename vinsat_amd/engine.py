@@ -81,6 +81,10 @@ class BAEngine:
         stays a kernel of its own."""
         _lib.check(self.lib.vba_set_warm_select(self.h, int(on) if int(on) in (2, 3) else int(bool(on))), self.lib)
 
+    def set_warm_shift(self, shift):
+        """Tuning / test knob: log2 of the warm-bin width in bit patterns (52 = a binade)."""
+        _lib.check(self.lib.vba_set_warm_shift(self.h, int(shift)), self.lib)
+
     def set_bucket_cap(self, cap):
         """Test knob: keys a bin bucket can hold (0 = default); a fuller bin makes the call that needs it miss."""
         _lib.check(self.lib.vba_set_bucket_cap(self.h, int(cap)), self.lib)
