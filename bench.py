@@ -65,6 +65,9 @@ ALG_BYTES = {
     # writes the step and the trial states; the diagonal blocks are not written (a later trial forms them)
     "assemble_init": lambda n, m: (216 + 80 + 72 + 80) * n,
     "solve": lambda n, m: (1944 + 72 + 2 * 1440 + 144 + 160) * n,
+    # batched mode since round 3: the walk forms its blocks from the per-pose inputs itself (792 B per pose) -- no assembly
+    # launch, the bands never go through memory; X / z of the forward sweep still make their round trip
+    "solve_forming": lambda n, m: (792 + 2 * 1440 + 144 + 160) * n,
     "trial": lambda n, m: 80 * m + (80 + 32 + 8) * n,
     # the accept test reads a few hundred block partials and writes the window's scalars; "begin" has no kernel at all (two
     # back-to-back event records: the state ping-pong removed the commit copy) -- neither moves per-pose data any more
@@ -508,10 +511,13 @@ def run_rank(args):
             it, init = schedule(k)
             if it == 0:
                 be.set_states(st0, 1e-4, window=-1)
-            for name, v in be.step_profiled(it, init).items():
+            ms_k = be.step_profiled(it, init)
+            for name, v in ms_k.items():
                 if v > 0:
                     bk[name].append(v)
                     key = "assemble_init" if (name == "assemble" and init) else name
+                    if name == "solve" and not init and ms_k.get("assemble", 0.0) == 0.0:
+                        key = "solve_forming"
                     bbytes[name].append(float(ALG_BYTES[key](n, m)))
         bms = {k: (float(np.mean(v)) if v else 0.0) for k, v in bk.items()}
         per_kernel = {k: {"ms": bms[k], "GBps": (float(np.mean(bbytes[k])) * W / (bms[k] * 1e-3) / 1e9) if bms[k] > 0 else 0.0}
@@ -529,6 +535,9 @@ def run_rank(args):
                    "whole_step_frac": step_bytes / (1e-3 * bms_step) / 1e9 / HBM_PEAK_GBS,
                    "whole_step_GBps_serialised": step_bytes / (1e-3 * sum(bms[k] * len(bk[k]) / 20.0 for k in bms)) / 1e9,
                    "whole_step_bytes_per_window": step_bytes / W,
+                   # the same time against SURVEY 8(d)'s per-unit figure B_alg = 208 m + 5000 n (which charges a re-read of the
+                   # observations for the residual pass and the bands' round trip through memory: both are gone here)
+                   "whole_step_frac_survey_bytes": survey_bytes_per_call(n, m) * W / (1e-3 * bms_step) / 1e9 / HBM_PEAK_GBS,
                    "kernels": per_kernel}
         # measured HBM traffic of the same chained schedule from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE
         # per kernel, tools/profile_pmc.sh / summarize_pmc.py), if that profile was taken at this many windows

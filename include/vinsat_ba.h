@@ -154,15 +154,16 @@ int vba_set_bucket_cap(vba_handle h, int cap);
  *          recovery of the partitioned solve) -- no recovery launch and, in the landmark-only phase, no assembly + solve launch;
  *   bit 1: the chunk elimination forms the blocks of its chunk in LDS itself -- no assembly launch in the full phase, the
  *          bands never go through memory.
- *   bit 2: (16 windows and more) the sequential solve of the full phase forms each block from the per-pose inputs itself --
- *          no assembly launch, the bands never go through memory.  Bit-exact; measured slower (the generic per-entry
- *          evaluation costs more instructions than the launch it removes), off by default.
+ *   bit 2: (16 windows and more, sequential driver) the solve of the full phase forms each block from the per-pose inputs
+ *          itself -- no assembly launch, the bands never go through memory.  Bit-exact.  With one window per wavefront
+ *          (k_solve_forming) it measured slower than assembly + walk (the walk was bound by instruction issue); since the
+ *          walk packs four windows into a wavefront (k_solve_quad) it is the faster form and the default.
  *   bit 3: the full-phase assembly forms each pose row with one wave in seven uniform passes (vba_asm_fast.h) instead of one
  *          entry per thread.  Bit-exact; 0.8 us off the average call of a single window (the per-entry form is a serial
  *          ~600 instructions per thread there), on par at 4096 windows (1.77 vs 1.85 ms).
  *   bit 4: only ONE cyclic-reduction level of the reduced system runs on its own CUs in front of the one-workgroup kernel
  *          (k_cr_level0) instead of two (k_cr_level01, default).  Same bits; 0.9 us per call slower.  Comparison / tests.
- * Default 9 (bits 0 and 3).  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
+ * Default 13 (bits 0, 2 and 3).  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
  * formed by 16 lanes together (formed redundantly by every thread it was 6 us SLOWER: instruction issue of a single wave
  * is the time in this mode); bit 1 gains nothing (the assembly costs the elimination's block what its own launch cost)
  * and stays off -- also in its two-wave form, where the four waves of the block form the rows in uniform passes

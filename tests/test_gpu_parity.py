@@ -1297,9 +1297,11 @@ def test_torch_cuda_initialises_after_the_library_has_used_the_gpu():
     assert out.stdout.strip().splitlines()[-1] == "0"
 
 
+@pytest.mark.parametrize("solver", [0, -2], ids=["four-per-wave", "one-per-wave"])
 @pytest.mark.parametrize("reg", [False, True])
-def test_batched_walk_forming_its_own_blocks_gives_the_bits_of_the_assembled_path(c2, reg):
-    """vba_set_fusion bit 2 (default for 16 windows and more): in the full phase the sequential solve forms each block
+def test_batched_walk_forming_its_own_blocks_gives_the_bits_of_the_assembled_path(c2, reg, solver):
+    """vba_set_fusion bit 2 (default for 16 windows and more, sequential driver -- itself the default from 128 windows on):
+    in the full phase the sequential solve (k_solve_quad, four windows per wavefront; k_solve_forming with one) forms each block
     from the per-pose inputs itself and the assembly launch is gone.  Same entries, same elimination: 16 windows -- the
     golden one, one that rejects trials and exhausts lamda, one whose blocks send the unpivoted path to the pivoted
     kernels, perturbed copies -- through the chained schedule, bit for bit against the assembled path; plain BA and
@@ -1317,6 +1319,7 @@ def test_batched_walk_forming_its_own_blocks_gives_the_bits_of_the_assembled_pat
     for mask in (1, 5):
         e = BAEngine(n, m, windows=W)
         e.set_fusion(mask)
+        e.set_solver(solver)
         for k in range(W):
             e.upload_observations(inp["xyz"], inp["uv"], confs[k], inp["ii"], n, window=k)
             e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"], window=k)

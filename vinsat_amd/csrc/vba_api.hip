@@ -97,7 +97,7 @@ struct vba_context {
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
     int inline_select = 1;                  // latency mode: warm select inside the accumulation (bin buckets); vba_set_warm_select(h, 3) turns it off
     int chunk_waves = 2;                    // vba_set_chunk_waves
-    int fusion = 9;                         // vba_set_fusion (default: the trial kernel forms the step)
+    int fusion = 13;                        // vba_set_fusion (default: the trial kernel forms the step, uniform-pass assembly, block-forming walk)
     int bucket_cap_alloc = 0;               // allocated capacity of a bin bucket (vba_set_bucket_cap lowers the one in use)
     int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
@@ -741,10 +741,15 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     V.pending_only = 0;
     V.warm_force_miss = h->warm_enabled == 2;
     V.pivot = h->pivot_mode;
+    // sequential driver with several windows: four chains per wavefront (k_solve_quad); vba_set_solver(h, -3) asks for the
+    // older three-chain packing (equal pose counts only), -2 for one window per wavefront
     V.pack = 0;
-    if (V.chunk <= 0 && h->W >= h->pack_min && !h->no_pack) {
-        V.pack = 1;
-        for (int w = 1; w < h->W; ++w) V.pack = V.pack && h->n[w] == h->n[0];
+    if (V.chunk <= 0 && !h->no_pack && h->W >= 2) {
+        V.pack = 2;
+        if (h->W >= h->pack_min) {
+            V.pack = 1;
+            for (int w = 1; w < h->W; ++w) if (h->n[w] != h->n[0]) V.pack = 2;
+        }
     }
     fill_params(V.prm, c.iter, c.initialize);
     // who forms the step: latency mode lets the trial kernel do it (landmark-only: 6x6 solve per pose on the unpivoted
@@ -1266,7 +1271,8 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
         }
         case VBA_DBG_BANDS: {
             // latency mode never writes the bands to memory (the chunk kernel forms its blocks in LDS): form them now
-            launch_assemble(V, 0, h->stream);
+            // (VBA_DBG_RAW_BANDS: diagnostic -- fetch what is in memory instead)
+            if (!std::getenv("VBA_DBG_RAW_BANDS")) launch_assemble(V, 0, h->stream);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(h->stream));
             if (int rc = copy(V.bands + pb * 243, (int64_t)n * 243)) return rc;
@@ -1279,7 +1285,7 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
             return VBA_OK;
         }
         case VBA_DBG_RHS: {
-            launch_assemble(V, 0, h->stream);
+            if (!std::getenv("VBA_DBG_RAW_BANDS")) launch_assemble(V, 0, h->stream);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(h->stream));
             return copy(V.rhs + pb * 9, (int64_t)n * 9);

@@ -28,8 +28,13 @@ __device__ __forceinline__ double asm_input(const DevView& V, size_t pb, int q, 
         const double* Hr = V.prior_H + pb * 36 + (q - 135) * 6;
         const double* xp = V.prior_x + pb * 6;
         const double* st = V.states + pb * 10;
-        return Hr[0] * (xp[0] - st[0]) + Hr[1] * (xp[1] - st[1]) + Hr[2] * (xp[2] - st[2]) +
-               Hr[3] * (xp[3] - st[7]) + Hr[4] * (xp[4] - st[8]) + Hr[5] * (xp[5] - st[9]);
+        // (explicit fma chain: every path that stages this value must round it alike, see vba_math.h)
+        double r = vba_mul(Hr[0], xp[0] - st[0]);
+        r = fma(Hr[1], xp[1] - st[1], r);
+        r = fma(Hr[2], xp[2] - st[2], r);
+        r = fma(Hr[3], xp[3] - st[7], r);
+        r = fma(Hr[4], xp[4] - st[8], r);
+        return fma(Hr[5], xp[5] - st[9], r);
     }
     return 0.0;
 }

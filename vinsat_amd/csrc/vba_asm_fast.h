@@ -94,28 +94,27 @@ __device__ __forceinline__ void asm_form_row(const AsmLanes& g, const double* me
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const bool in = lane + 64 * q < 81;
-        {   // sub-diagonal
+        {   // sub-diagonal: band_entry which == 0
             const unsigned d = g.L[q];
             const int off = d & 255u, kind = (d >> 8) & 3u;
             const double f = asm_fval((d >> 10) & 3u), B = ((d >> 12) & 1u) ? kVelCoeff : 1.0;
             const double x = (kind == 1 ? pv : me)[off];
-            double v = 0.0;
-            const double t = v + (f * sigma) * (B * x);           // band_entry: v += (F_val sigma) * (D Phi)   |   v += sigma * Hl
-            v = (dyn && has_prev && kind != 0) ? t : v;
+            const double t1 = vba_mul(vba_mul(f, sigma), vba_mul(B, x));     // (F_val sigma) * (D Phi)
+            const double t2 = vba_mul(sigma, x);                             // sigma * Hl
+            const double v = (dyn && has_prev && kind != 0) ? (kind == 1 ? t1 : t2) : 0.0;
             if (in) store(lane + 64 * q, v);
         }
-        {   // super-diagonal
+        {   // super-diagonal: which == 2
             const unsigned d = g.U[q];
             const int off = d & 255u, kind = (d >> 8) & 3u;
             const double f = asm_fval((d >> 10) & 3u), B = ((d >> 12) & 1u) ? kVelCoeff : 1.0;
             const double x = me[off];
-            double v = 0.0;
-            const double t1 = v + ((B * x) * sigma) * f;          // v += (E sigma) * F_val
-            const double t2 = v + sigma * x;                       // v += sigma * Hu
-            v = (dyn && has_next && kind != 0) ? (kind == 1 ? t1 : t2) : v;
+            const double t1 = vba_mul(vba_mul(vba_mul(B, x), sigma), f);     // (E sigma) * F_val
+            const double t2 = vba_mul(sigma, x);                             // sigma * Hu
+            const double v = (dyn && has_next && kind != 0) ? (kind == 1 ? t1 : t2) : 0.0;
             if (in) store(162 + lane + 64 * q, v);
         }
-        {   // diagonal
+        {   // diagonal: which == 1
             const unsigned d = g.D[q];
             const int offH = d & 31u, pa = (d >> 5) & 7u, pb = (d >> 8) & 7u, hd = (d >> 11) & 15u, ra = (d >> 15) & 7u, rb = (d >> 18) & 7u;
             const bool hh = (d >> 21) & 1u, diagF = (d >> 22) & 1u, rot = (d >> 23) & 1u, pr = (d >> 24) & 1u;
@@ -123,7 +122,7 @@ __device__ __forceinline__ void asm_form_row(const AsmLanes& g, const double* me
             const double fv = ((d >> 25) & 1u) ? -kVelCoeff : -1.0;
             double v = 0.0;
             {
-                const double h = me[offH] * inv_wmax;
+                const double h = vba_mul(me[offH], inv_wmax);
                 v = hh ? h : v;
             }
             if (dyn) {
@@ -133,17 +132,17 @@ __device__ __forceinline__ void asm_form_row(const AsmLanes& g, const double* me
                     for (int r = 0; r < 6; ++r) {
                         const double Dr = r < 3 ? 1.0 : kVelCoeff;
                         const double xa = me[27 + 6 * r + (rotA ? 0 : pa)], xb = me[27 + 6 * r + (rotB ? 0 : pb)];
-                        const double Ea = rotA ? 0.0 : Dr * xa, Eb = rotB ? 0.0 : Dr * xb;
-                        s += (Ea * sigma) * Eb;
+                        const double Ea = rotA ? 0.0 : vba_mul(Dr, xa), Eb = rotB ? 0.0 : vba_mul(Dr, xb);
+                        s = fma(vba_mul(Ea, sigma), Eb, s);
                     }
-                    v += s;
+                    v = vba_add(v, s);
                 }
                 {
-                    const double t = v + (fv * sigma) * fv;
+                    const double t = fma(vba_mul(fv, sigma), fv, v);
                     v = (has_prev && diagF) ? t : v;
                 }
                 {
-                    const double t = v + sigma * me[72 + hd];
+                    const double t = fma(sigma, me[72 + hd], v);
                     v = rot ? t : v;
                 }
             }
@@ -151,8 +150,8 @@ __device__ __forceinline__ void asm_form_row(const AsmLanes& g, const double* me
                 const double* H = me + 99;
                 double s = 0.0;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) s += H[k * 6 + ra] * H[k * 6 + rb];
-                const double t = v + s;
+                for (int k = 0; k < 6; ++k) s = fma(H[k * 6 + ra], H[k * 6 + rb], s);
+                const double t = vba_add(v, s);
                 v = pr ? t : v;
             }
             if (in) store(81 + lane + 64 * q, v);
@@ -165,7 +164,7 @@ __device__ __forceinline__ void asm_form_row(const AsmLanes& g, const double* me
         const double fv = ((d >> 11) & 1u) ? -kVelCoeff : -1.0;
         double v = 0.0;
         {
-            const double h = me[21 + (a < 6 ? a : 0)] * inv_wmax;
+            const double h = vba_mul(me[21 + (a < 6 ? a : 0)], inv_wmax);
             v = a < 6 ? h : v;
         }
         if (dyn) {
@@ -175,17 +174,17 @@ __device__ __forceinline__ void asm_form_row(const AsmLanes& g, const double* me
                 for (int r = 0; r < 6; ++r) {
                     const double Dr = r < 3 ? 1.0 : kVelCoeff;
                     const double xa = me[27 + 6 * r + (rotA ? 0 : pa)];
-                    const double Ea = rotA ? 0.0 : Dr * xa;
-                    s += (Ea * sigma) * me[63 + r];
+                    const double Ea = rotA ? 0.0 : vba_mul(Dr, xa);
+                    s = fma(vba_mul(Ea, sigma), me[63 + r], s);
                 }
-                v -= s;
+                v = vba_add(v, -s);
             }
             {
-                const double t = v - (fv * sigma) * pv[63 + (rotA ? 0 : ra)];
+                const double t = fma(vba_mul(fv, sigma), -pv[63 + (rotA ? 0 : ra)], v);
                 v = (has_prev && !rotA) ? t : v;
             }
             {
-                const double t = v - sigma * me[69 + (rotA ? a - 3 : 0)];
+                const double t = fma(sigma, -me[69 + (rotA ? a - 3 : 0)], v);
                 v = rotA ? t : v;
             }
         }
@@ -194,8 +193,8 @@ __device__ __forceinline__ void asm_form_row(const AsmLanes& g, const double* me
             const double* r6 = me + 135;
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) s += H[k * 6 + (rotA ? 0 : ra)] * r6[k];
-            const double t = v + s;
+            for (int k = 0; k < 6; ++k) s = fma(H[k * 6 + (rotA ? 0 : ra)], r6[k], s);
+            const double t = vba_add(v, s);
             v = !rotA ? t : v;
         }
         if (live) store(243 + lane, v);

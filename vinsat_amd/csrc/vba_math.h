@@ -424,14 +424,18 @@ struct AsmRow {
 // Prior of BA_reg (BA_filtering.py:146, 157-159, 166; prior_gpu BA_utils.py:617-627): r = H d, Jp = -H on the
 // position / velocity columns (vel_coeff = 1 as called), so J^T J gains H^T H and the right-hand side H^T r there.
 // The rotation part of prior_gpu is analytically constant (G(q)^T q = 0): no gradient, no Hessian.
+// (Every sum of products of the assembly is written with explicit fma / vba_mul / vba_add: three code paths form these
+// entries -- per entry here, in uniform passes in vba_asm_fast.h, column-wise in the four-windows-per-wave walk -- and under
+// -ffp-contract=fast the optimiser would contract `v - sigma * x` in one of them and not in the other, depending on how it
+// happened to if-convert the surrounding selects.  The systems must agree to the bit.)
 VBA_HD double prior_hth(const double* H, int a, int b) {
     double s = 0.0;
-    for (int k = 0; k < 6; ++k) s += H[k * 6 + a] * H[k * 6 + b];
+    for (int k = 0; k < 6; ++k) s = fma(H[k * 6 + a], H[k * 6 + b], s);
     return s;
 }
 VBA_HD double prior_htr(const double* H, const double* r, int a) {
     double s = 0.0;
-    for (int k = 0; k < 6; ++k) s += H[k * 6 + a] * r[k];
+    for (int k = 0; k < 6; ++k) s = fma(H[k * 6 + a], r[k], s);
     return s;
 }
 // r = H d for one pose: st = its state [10], xp = prior position / velocity [6]
@@ -449,7 +453,7 @@ VBA_HD double E_entry(const double* Phi, int r, int c) {
     if (c >= 3 && c < 6) return 0.0;
     const int pc = c < 3 ? c : c - 3;
     const double D = r < 3 ? 1.0 : kVelCoeff;
-    return D * Phi[6 * r + pc];
+    return vba_mul(D, Phi[6 * r + pc]);
 }
 // F = -D selects position / velocity: column c has a single non-zero at row frow(c)
 VBA_HD int F_row(int c) { return c < 3 ? c : (c >= 6 ? c - 3 : -1); }
@@ -460,27 +464,27 @@ VBA_HD double band_entry(const AsmRow& R, int which, int a, int b) {
     double v = 0.0;
     const bool rot = (a >= 3 && a < 6 && b >= 3 && b < 6);
     if (which == 1) {
-        if (a < 6 && b < 6) v = R.Hraw[sym6(a, b)] * R.inv_wmax;
+        if (a < 6 && b < 6) v = vba_mul(R.Hraw[sym6(a, b)], R.inv_wmax);
         if (R.sigma != 0.0) {
             if (R.Phi_i) {
                 double s = 0.0;
-                for (int r = 0; r < 6; ++r) s += (E_entry(R.Phi_i, r, a) * R.sigma) * E_entry(R.Phi_i, r, b);
-                v += s;
+                for (int r = 0; r < 6; ++r) s = fma(vba_mul(E_entry(R.Phi_i, r, a), R.sigma), E_entry(R.Phi_i, r, b), s);
+                v = vba_add(v, s);
             }
-            if (R.Phi_im1 && a == b && F_row(a) >= 0) v += (F_val(a) * R.sigma) * F_val(a);
-            if (rot) v += R.sigma * R.Hd[3 * (a - 3) + (b - 3)];
+            if (R.Phi_im1 && a == b && F_row(a) >= 0) v = fma(vba_mul(F_val(a), R.sigma), F_val(a), v);
+            if (rot) v = fma(R.sigma, R.Hd[3 * (a - 3) + (b - 3)], v);
         }
-        if (R.prior_H && F_row(a) >= 0 && F_row(b) >= 0) v += prior_hth(R.prior_H, F_row(a), F_row(b));
+        if (R.prior_H && F_row(a) >= 0 && F_row(b) >= 0) v = vba_add(v, prior_hth(R.prior_H, F_row(a), F_row(b)));
     } else if (R.sigma != 0.0) {
         if (which == 2 && R.Phi_i) {
             const int r = F_row(b);
-            if (r >= 0) v += (E_entry(R.Phi_i, r, a) * R.sigma) * F_val(b);
-            if (rot) v += R.sigma * R.Hu[3 * (a - 3) + (b - 3)];
+            if (r >= 0) v = vba_mul(vba_mul(E_entry(R.Phi_i, r, a), R.sigma), F_val(b));
+            if (rot) v = vba_mul(R.sigma, R.Hu[3 * (a - 3) + (b - 3)]);         // (exclusive: a rotation column has no F row)
         }
         if (which == 0 && R.Phi_im1) {
             const int r = F_row(a);
-            if (r >= 0) v += (F_val(a) * R.sigma) * E_entry(R.Phi_im1, r, b);
-            if (rot) v += R.sigma * R.Hl[3 * (a - 3) + (b - 3)];
+            if (r >= 0) v = vba_mul(vba_mul(F_val(a), R.sigma), E_entry(R.Phi_im1, r, b));
+            if (rot) v = vba_mul(R.sigma, R.Hl[3 * (a - 3) + (b - 3)]);
         }
     }
     return v;
@@ -488,20 +492,20 @@ VBA_HD double band_entry(const AsmRow& R, int which, int a, int b) {
 
 VBA_HD double rhs_entry(const AsmRow& R, int a) {
     double v = 0.0;
-    if (a < 6) v = R.braw[a] * R.inv_wmax;
+    if (a < 6) v = vba_mul(R.braw[a], R.inv_wmax);
     if (R.sigma != 0.0) {
         if (R.Phi_i) {
             double s = 0.0;
-            for (int r = 0; r < 6; ++r) s += (E_entry(R.Phi_i, r, a) * R.sigma) * R.rorb_i[r];
-            v -= s;
+            for (int r = 0; r < 6; ++r) s = fma(vba_mul(E_entry(R.Phi_i, r, a), R.sigma), R.rorb_i[r], s);
+            v = vba_add(v, -s);
         }
         if (R.Phi_im1) {
             const int r = F_row(a);
-            if (r >= 0) v -= (F_val(a) * R.sigma) * R.rorb_im1[r];
+            if (r >= 0) v = fma(vba_mul(F_val(a), R.sigma), -R.rorb_im1[r], v);
         }
-        if (a >= 3 && a < 6) v -= R.sigma * R.qgrad[a - 3];
+        if (a >= 3 && a < 6) v = fma(R.sigma, -R.qgrad[a - 3], v);
     }
-    if (R.prior_H && F_row(a) >= 0) v += prior_htr(R.prior_H, R.prior_r, F_row(a));
+    if (R.prior_H && F_row(a) >= 0) v = vba_add(v, prior_htr(R.prior_H, R.prior_r, F_row(a)));
     return v;
 }
 

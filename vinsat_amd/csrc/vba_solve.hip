@@ -110,7 +110,7 @@ __device__ __forceinline__ void forward_step(const double* Lmat, const double (&
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
                 const bool rot_r = (r >= 3 && r < 6), rot_j = (j >= 3 && j < 6);
-                if (!SPARSE_L || rot_r == rot_j) v -= Lmat[r * 9 + j] * xp[j];   // broadcast LDS read
+                if (!SPARSE_L || rot_r == rot_j) v = fma(-Lmat[r * 9 + j], xp[j], v);   // broadcast LDS read
             }
         }
         a[r] = v;
@@ -166,7 +166,7 @@ __device__ __forceinline__ void forward_step(const double* Lmat, const double (&
         a[k] = a[k] * inv;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            if (r != k) a[r] -= f[r] * a[k];
+            if (r != k) a[r] = fma(-f[r], a[k], a[r]);
         }
     }
 }
@@ -562,6 +562,476 @@ __global__ __launch_bounds__(64) void k_solve_packed(DevView V) {
         const unsigned long long anybad = __ballot(bad);
         if (lane == 0 && anybad) atomicOr(&s3.fl[V.par], 2u);
     }
+}
+
+// ---------------------------------------------------------------------------------------------- quad
+// Many batched windows: FOUR chains per wavefront, one per row of 16 lanes.  The walk of one window per wave is bound by
+// instruction issue (four waves per SIMD, each ~450 instructions per block step of which 19 lanes do anything), and most of
+// those instructions are the v_readlane pairs that broadcast a pivot column -- which serve one window however many lanes are
+// idle.  gfx90a and later can broadcast a lane inside every row of 16 with one DPP move (row_newbcast), so here lane c < 9
+// of a row owns column c of D' (registers A) AND column c of U (registers B), lane 9 the right-hand side (in A): a pivot is
+// 20 DPP moves + 18 multiply-adds for four windows instead of 20 readlanes + 9 multiply-adds for one.  The update
+// D' = D - L X_prev is lane-local (X_prev's column c is this lane's B).  Same operations in the same order per entry as
+// forward_step, so the same bits as k_solve.  Windows may differ in length; rows are independent (nothing crosses a row).
+constexpr int kQuad = 4;
+
+template <int K>
+__device__ __forceinline__ double bcast_row16(double v) {       // lane K of this lane's row of 16
+    const unsigned long long b = f64_bits(v);
+    // (mov_dpp: no `old` operand -- every lane is written, and update_dpp(0, ...) costs a v_mov of the zero per use)
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, 0x150 + K, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), 0x150 + K, 0xf, 0xf, false);
+    return bits_f64(((unsigned long long)hi << 32) | lo);
+}
+template <int K>
+__device__ __forceinline__ int bcast_row16_i32(int v) { return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, false); }
+
+// One block step of four chains.  c = lane inside the row.  In: A = this lane's column of [I | z_{i-1}] (lane 9: z),
+// B = column of X_{i-1}; baseA = column of [D_i + lam I | rhs_i], baseB = column of U_i.  Out: A = [I | z_i], B = X_i.
+template <bool PIVOT, int K = 0>
+__device__ __forceinline__ void quad_pivots(const double (&baseA)[9], double (&A)[9], double (&B)[9], int c, bool& bad) {
+    if constexpr (K < 9) {
+        double inv;
+        if (PIVOT) {
+            const int cnt = 9 - K;
+            double cv[9], cs[9];
+            int ci[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                if (r < cnt) { cs[r] = A[K + r]; cv[r] = fabs(cs[r]); ci[r] = K + r; }
+            }
+#pragma unroll
+            for (int step = 1; step < 9; step *= 2) {
+#pragma unroll
+                for (int r = 0; r < 9; r += 2 * step) {
+                    if (r + step < cnt) {
+                        const bool take = cv[r + step] > cv[r];       // strict: the lowest row wins a tie
+                        cv[r] = take ? cv[r + step] : cv[r];
+                        cs[r] = take ? cs[r + step] : cs[r];
+                        ci[r] = take ? ci[r + step] : ci[r];
+                    }
+                }
+            }
+            const double inv_l = fast_rcp(cs[0]);
+            const int p = bcast_row16_i32<K>(ci[0]);
+            inv = bcast_row16<K>(inv_l);
+            if (!(fabs(inv) <= 1.79e308)) bad = true;
+            const double ak = A[K], bk = B[K];
+            double nk = ak, mk = bk;
+#pragma unroll
+            for (int r = K + 1; r < 9; ++r) {     // row swap K <-> p (p is uniform over the row of lanes), branch free
+                const bool sel = (p == r);
+                const double ar = A[r], br = B[r];
+                nk = sel ? ar : nk;
+                mk = sel ? br : mk;
+                A[r] = sel ? ak : ar;
+                B[r] = sel ? bk : br;
+            }
+            A[K] = nk;
+            B[K] = mk;
+        } else {
+            bad = bad | ((c == K) & !(A[K] > 1e-10 * baseA[K]));
+            inv = bcast_row16<K>(fast_rcp(A[K]));
+        }
+        double f[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) f[r] = (r != K) ? bcast_row16<K>(A[r]) : 0.0;
+        A[K] = A[K] * inv;
+        B[K] = B[K] * inv;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            if (r != K) {
+                A[r] = fma(-f[r], A[K], A[r]);
+                B[r] = fma(-f[r], B[K], B[r]);
+            }
+        }
+        quad_pivots<PIVOT, K + 1>(baseA, A, B, c, bad);
+    }
+}
+
+// FORM (vba_set_fusion bit 2, default): the walk forms its blocks itself from the per-pose inputs (asm_form_row, the uniform
+// passes of vba_asm_fast.h: the same system to the bit) -- no assembly launch, and the bands (2 kB per pose written and read
+// back) never go through memory: per pose 0.8 kB of inputs instead.  The inputs of three consecutive poses of each window
+// live in an LDS ring, the loads run kFwdDepth poses ahead in registers.
+// The block is ONE wave: LDS operations of a wave execute in order, so what one lane wrote is there for the lane that reads
+// it in a later instruction -- no s_barrier, and above all no s_waitcnt vmcnt(0), which __syncthreads() carries and which
+// would make every block step wait for the loads it has just issued for four steps ahead.  The fence keeps the compiler
+// from moving LDS accesses across.
+__device__ __forceinline__ void quad_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool PIVOT, bool FORM, bool REG>
+__global__ __launch_bounds__(64) void k_solve_quad(DevView V) {
+    constexpr int kIn = kAsmBase + (REG ? kAsmPrior : 0);
+    constexpr int kPerIn = FORM ? (kQuad * kIn + 63) / 64 : 1;
+    __shared__ double blk[2][kQuad][256];
+    __shared__ double ring[FORM ? 3 : 1][FORM ? kPerIn * 64 : 1];       // [slot][window q4 at q4 * kIn]; padded to whole passes of the wave
+    const int lane = threadIdx.x;
+    const int row = lane >> 4, c = lane & 15;
+    const int w0 = blockIdx.x * kQuad;
+    const int w = min(w0 + row, V.W - 1);
+    WinScalars& sc = V.sc[w];
+    const bool active = w0 + row < V.W && !sc.done && VBA_WINDOW_RUNS(V, w) && solver_mine<PIVOT>(V, sc);
+    const int n = active ? V.n[w] : 0;
+    int nmax = n;       // the longest chain of the four
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, kWave));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);        // (uniform: the loop bounds below are scalar branches)
+    if (nmax == 0) return;
+    const size_t sb = (size_t)w * V.n_max;
+    const double lam32 = (double)(float)sc.lam[V.par];      // torch.eye() is float32 (BA_filtering.py:54)
+    if (active && c == 0) {
+        sc.lam32 = lam32;
+        if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
+    }
+    double A[9], B[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) A[j] = B[j] = 0.0;
+    bool badp = false;
+    // The 252 entries of block i of each of the four windows, coalesced: 16 loads per lane.  One wave per SIMD has nobody to
+    // hide a round trip to memory behind, so the loads run kFwdDepth block steps ahead of their use (a ring of register
+    // sets; the loop is unrolled by the depth so that the ring index is static).
+#ifndef VBA_Q_FWD
+#define VBA_Q_FWD 2
+#endif
+#ifndef VBA_Q_BWD
+#define VBA_Q_BWD 8
+#endif
+#ifndef VBA_QX
+#define VBA_QX 0
+#endif
+    constexpr int kFwdDepth = VBA_Q_FWD, kBwdDepth = VBA_Q_BWD;
+    int nq[kQuad];
+#pragma unroll
+    for (int q4 = 0; q4 < kQuad; ++q4) nq[q4] = __shfl(n, 16 * q4, kWave);
+    double pre[FORM ? 1 : kFwdDepth][kQuad][4];
+    auto fetch = [&](int i, double (&dst)[kQuad][4]) {
+#pragma unroll
+        for (int q4 = 0; q4 < kQuad; ++q4) {
+            const int wq = min(w0 + q4, V.W - 1);
+            const bool have = i < nq[q4];
+            const size_t s4 = (size_t)wq * V.n_max + (have ? i : 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = lane + 64 * q;        // (q < 3: a band entry; q == 3: lanes 51 .. 59 the right-hand side)
+                const double* src = e < 243 ? V.bands + s4 * 243 + e : V.rhs + s4 * 9 + min(e - 243, 8);
+                const double v = *src;
+                dst[q4][q] = (have && e < 252) ? v : 0.0;
+            }
+        }
+    };
+    auto stash = [&](int buf, const double (&src)[kQuad][4]) {
+#pragma unroll
+        for (int q4 = 0; q4 < kQuad; ++q4)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) blk[buf][q4][lane + 64 * q] = src[q4][q];
+    };
+    // FORM: the inputs of pose i of the four windows (kIn doubles each), kPerIn loads per lane
+    double hold[kFwdDepth][kPerIn];
+    const double inv_wmax4[1] = {1.0 / bits_f64(sc.wmax_bits[V.par])};        // (of this lane's own window)
+    // where input q = lane + 64 k of the staged layout (vba_asm.h: asm_input) lives: base pointer of pose 0 and stride per
+    // pose, decoded ONCE -- a per-element `if (q < 21) ... else if (q < 27) ...` ladder inside the walk is a few thousand
+    // basic blocks with a wait for memory at every join
+    const double* inbase[kPerIn];
+    int instride[kPerIn], inn[kPerIn], inprior[kPerIn];
+#pragma unroll
+    for (int k = 0; k < kPerIn; ++k) {
+        const int q = lane + 64 * k;
+        const int q4 = min(q / kIn, kQuad - 1), e = q - q4 * kIn;
+        const size_t pb = (size_t)min(w0 + q4, V.W - 1) * V.n_max;
+        const double* bp = V.Hraw + pb * 21 + e;
+        int st = 21;
+        if (e >= 21) { bp = V.braw + pb * 6 + (e - 21); st = 6; }
+        if (e >= 27) { bp = V.Phi + pb * 36 + (e - 27); st = 36; }
+        if (e >= 63) { bp = V.rorb + pb * 6 + (e - 63); st = 6; }
+        if (e >= 69) { bp = V.qgrad + pb * 3 + (e - 69); st = 3; }
+        if (e >= 72) { bp = V.Hd + pb * 9 + (e - 72); st = 9; }
+        if (e >= 81) { bp = V.Hu + pb * 9 + (e - 81); st = 9; }
+        if (e >= 90) { bp = V.Hl + pb * 9 + (e - 90); st = 9; }
+        if (REG && e >= 99) { bp = V.prior_H + pb * 36 + (e - 99); st = 36; }
+        inprior[k] = (REG && e >= 135 && e < kIn) ? (e - 135) : -1;
+        if (REG && e >= 135) { bp = V.prior_H + pb * 36; st = 36; }
+        inbase[k] = bp;
+        instride[k] = st;
+        const int nn = q4 == 0 ? nq[0] : (q4 == 1 ? nq[1] : (q4 == 2 ? nq[2] : nq[3]));
+        inn[k] = (q < kQuad * kIn) ? nn : 0;
+    }
+    auto in_fetch = [&](int i, double (&dst)[kPerIn]) {
+#pragma unroll
+        for (int k = 0; k < kPerIn; ++k) {
+            // (unconditional load from a clamped pose index, then a select: no branch)
+            const int ic = max(min(i, inn[k] - 1), 0);
+            const double v = inbase[k][(size_t)ic * instride[k]];
+            dst[k] = i < inn[k] ? v : 0.0;
+        }
+        if (REG) {      // the staged prior residual is a computed value: component e - 135 of H [p_prior - p ; v_prior - v]
+#pragma unroll
+            for (int k = 0; k < kPerIn; ++k) {
+                if (inprior[k] >= 0 && i < inn[k]) {
+                    const int q4 = (lane + 64 * k) / kIn;
+                    dst[k] = asm_input<REG>(V, (size_t)min(w0 + q4, V.W - 1) * V.n_max + i, 135 + inprior[k], true);
+                }
+            }
+        }
+    };
+    auto in_commit = [&](int i, const double (&src)[kPerIn]) {
+        double* slot = ring[i % 3];
+#pragma unroll
+        for (int k = 0; k < kPerIn; ++k) slot[lane + 64 * k] = src[k];
+    };
+    // FORM: block j of this lane's window, column-wise -- the lane's column of [D_j | rhs_j] (nextA, undamped) and of U_j
+    // (nextB) straight into registers, its column of L_j into blk[buf] (every lane of the row reads all of L_j).  Entry by
+    // entry the operations of band_entry / rhs_entry (vba_math.h) in their order, so the same system to the bit; what
+    // differs between the lanes (rotation column or not, which Phi column, right-hand side) is data.
+    double nextA[9], nextB[9], lastDcol[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) lastDcol[a] = 0.0;
+    const bool is_col = c < 9, is_rhs = c == 9;
+    const bool rotc = c >= 3 && c < 6, nonrot = is_col && !rotc;
+    const int pcl = c < 3 ? c : (nonrot ? c - 3 : 0);          // column of Phi / row of F that this lane's state slot maps to
+    const int crl = rotc ? c - 3 : 0;
+    const double fvc = c < 3 ? -1.0 : -kVelCoeff;
+    const double Dcl = pcl < 3 ? 1.0 : kVelCoeff;
+    auto form = [&](int j, int buf) {
+        const double* me = ring[j % 3] + row * kIn;
+        const double* pv = ring[(j + 2) % 3] + row * kIn;
+        double* Lout = blk[buf][row];
+        const bool live = j < n, has_next = j < n - 1, has_prev = j > 0 && live;
+        const double sigma = V.prm.sigma, iw = inv_wmax4[0];       // (inv_wmax4[0]: this lane's own window, see below)
+        const double fs[2] = {vba_mul(-1.0, sigma), vba_mul(-kVelCoeff, sigma)};
+        // Every LDS read below is UNCONDITIONAL -- the address is selected, one load is made, the value is selected.
+        // (`cond ? lds[i] : 0` compiles to a masked load in a basic block of its own with a full wait behind it; a few dozen
+        // of those per block step were most of this kernel's time.)
+        auto ld = [](const double* p) { return *p; };
+        // the lane's second factor of the J_f^T Sigma J_f sums: its column of E_j = D Phi_j, or r_orb (right-hand side)
+        double X[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const double Dr = r < 3 ? 1.0 : kVelCoeff;
+            const double xv = ld(me + (is_rhs ? 63 + r : 27 + 6 * r + pcl));
+            const double e = vba_mul(Dr, xv);
+            X[r] = nonrot ? e : (is_rhs ? xv : 0.0);
+        }
+        double Xp[6];
+        if (REG) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Xp[k] = ld(me + (is_rhs ? 135 + k : 99 + k * 6 + pcl));
+        }
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {
+            const bool rota = a >= 3 && a < 6;
+            const int pa = a < 3 ? a : a - 3;           // (non-rotation a)
+            double v = 0.0;
+            if (a < 6) {
+                const int idx = is_rhs ? 21 + a : sym6(a, c < 6 ? c : 0);
+                const double h = vba_mul(ld(me + idx), iw);
+                v = (is_rhs || c < 6) ? h : 0.0;
+            }
+            {
+                double sdyn = 0.0;
+                if (!rota) {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        const double Dr = r < 3 ? 1.0 : kVelCoeff;
+                        sdyn = fma(vba_mul(vba_mul(Dr, ld(me + 27 + 6 * r + pa)), sigma), X[r], sdyn);
+                    }
+                }
+                const double t = vba_add(v, is_rhs ? -sdyn : sdyn);
+                v = has_next ? t : v;
+            }
+            if (!rota) {
+                const double fsa = fs[a < 3 ? 0 : 1], fva = a < 3 ? -1.0 : -kVelCoeff;
+                const double zr = ld(pv + 63 + pa);
+                const double z = is_rhs ? -zr : fva;
+                const double t = fma(fsa, z, v);
+                v = (has_prev && (is_rhs || c == a)) ? t : v;
+            } else {
+                const double yv = ld(me + (is_rhs ? 69 + (a - 3) : 72 + 3 * (a - 3) + crl));
+                const double t = fma(sigma, is_rhs ? -yv : yv, v);
+                v = (is_rhs || rotc) ? t : v;
+            }
+            if (REG && !rota) {
+                double sp = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sp = fma(ld(me + 99 + k * 6 + pa), Xp[k], sp);
+                const double t = vba_add(v, sp);
+                v = (is_rhs || nonrot) ? t : v;
+            }
+            nextA[a] = (live && c < 10) ? v : 0.0;
+            // super-diagonal column and sub-diagonal column
+            double u, l;
+            if (!rota) {
+                const double fsa = fs[a < 3 ? 0 : 1];
+                const double eu = vba_mul(Dcl, ld(me + 27 + 6 * pcl + pa));              // E_entry(Phi_j, F_row(c), a)
+                u = vba_mul(vba_mul(eu, sigma), fvc);
+                const double Dra = pa < 3 ? 1.0 : kVelCoeff;
+                const double el = vba_mul(Dra, ld(pv + 27 + 6 * pa + pcl));              // E_entry(Phi_{j-1}, F_row(a), c)
+                l = vba_mul(fsa, el);
+                u = nonrot ? u : 0.0;
+                l = nonrot ? l : 0.0;
+            } else {
+                u = vba_mul(sigma, ld(me + 81 + 3 * (a - 3) + crl));
+                l = vba_mul(sigma, ld(me + 90 + 3 * (a - 3) + crl));
+                u = rotc ? u : 0.0;
+                l = rotc ? l : 0.0;
+            }
+            nextB[a] = (has_next && is_col) ? u : 0.0;
+            Lout[is_col ? a * 9 + c : 96 + 9 * (c - 9) + a] = has_prev ? l : 0.0;      // (lanes without a column: a spare slot each)
+            lastDcol[a] = j == n - 1 ? nextA[a] : lastDcol[a];      // last_hessian (BA_filtering.py:97): kept, stored after the walk
+        }
+#ifdef VBA_DEBUG_FORM
+        if (active && live) {
+            const size_t pp = sb + j;
+#pragma unroll
+            for (int a = 0; a < 9; ++a) {
+                if (is_col) { V.bands[pp * 243 + 81 + a * 9 + c] = nextA[a]; V.bands[pp * 243 + 162 + a * 9 + c] = nextB[a]; V.bands[pp * 243 + a * 9 + c] = has_prev ? Lout[a * 9 + c] : 0.0; }
+                if (is_rhs) V.rhs[pp * 9 + a] = nextA[a];
+            }
+        }
+#endif
+    };
+    if (FORM) {
+        for (int e = lane; e < 3 * kPerIn * 64; e += 64) (&ring[0][0])[e] = 0.0;
+        for (int e = lane; e < 2 * kQuad * 256; e += 64) (&blk[0][0][0])[e] = 0.0;      // (only the sub-diagonal block goes through LDS)
+        quad_sync();
+        double first[2][kPerIn];
+        in_fetch(0, first[0]);
+        in_fetch(1, first[1]);
+#pragma unroll
+        for (int k = 0; k < kFwdDepth; ++k) in_fetch(2 + k, hold[(2 + k) % kFwdDepth]);
+        in_commit(0, first[0]);
+        in_commit(1, first[1]);
+        quad_sync();
+        form(0, 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kFwdDepth; ++k) fetch(k, pre[k]);       // (beyond the end of a chain: zeros, no access)
+        stash(0, pre[0]);
+        fetch(kFwdDepth, pre[0]);
+    }
+    quad_sync();
+    for (int i0 = 0; i0 < nmax; i0 += kFwdDepth) {
+#pragma unroll
+        for (int k = 0; k < kFwdDepth; ++k) {
+            const int i = i0 + k;
+            if (i >= nmax) break;
+            const int buf = i & 1;
+            const double* b = blk[buf][row];
+            // this lane's column of [D_i + lam I | rhs_i] and of U_i
+            double baseA[9];
+            if (FORM) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) baseA[r] = r == c ? nextA[r] + lam32 : nextA[r];
+            } else {
+                const double* pa = c < 9 ? b + 81 + c : b + 243;
+                const int stride = c < 9 ? 9 : 1;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    double v = c < 10 ? pa[r * stride] : 0.0;
+                    if (r == c) v += lam32;
+                    baseA[r] = v;
+                }
+            }
+            // D' = D - L X_{i-1}, y = g - L z_{i-1}: lane local (sparse L: [pp 0 pv; 0 rr 0; vp 0 vv])
+            double xp[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) xp[j] = c < 9 ? B[j] : (c == 9 ? A[j] : 0.0);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                double v = baseA[r];
+                if (FORM || i > 0) {        // (FORM: the sub-diagonal block of block 0 is formed as zeros)
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) {
+                        const bool rot_r = (r >= 3 && r < 6), rot_j = (j >= 3 && j < 6);
+                        if (rot_r == rot_j) v = fma(-b[r * 9 + j], xp[j], v);      // LDS read, one address per row of lanes
+                    }
+                }
+                A[r] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) B[r] = FORM ? nextB[r] : (c < 9 ? b[162 + r * 9 + c] : 0.0);
+            if (!(VBA_QX & 1)) quad_pivots<PIVOT>(baseA, A, B, c, badp);
+            if (active && i < n && c < 10) {        // column c of X_i, or z_i: one predicated run of stores
+                double* dst = c < 9 ? V.Xs + (sb + i) * 81 + c : V.zs + (sb + i) * 9;
+                const int stride = c < 9 ? 9 : 1;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) dst[r * stride] = c < 9 ? B[r] : A[r];
+            }
+            // block i + 1 goes to the other buffer (its loads were issued kFwdDepth steps ago); its register set takes the
+            // loads of block i + 1 + kFwdDepth
+            if (FORM) {
+                // ring: poses i, i + 1 (and the stale i - 1, whose slot pose i + 2 takes once block i + 1 is formed)
+                const int kh = (k + 2) % kFwdDepth;     // (static once the loop is unrolled)
+                if (i + 1 < nmax) {
+                    if (!(VBA_QX & 2)) form(i + 1, buf ^ 1);
+                    in_commit(i + 2, hold[kh]);
+                    in_fetch(i + 2 + kFwdDepth, hold[kh]);
+                }
+            } else {
+                const int kn = (k + 1) % kFwdDepth;
+                if (i + 1 < nmax) {
+                    stash(buf ^ 1, pre[kn]);
+                    fetch(i + 1 + kFwdDepth, pre[kn]);
+                }
+            }
+            quad_sync();
+        }
+    }
+    quad_sync();
+    if (FORM && active && is_col) {
+#pragma unroll
+        for (int a = 0; a < 9; ++a) V.lastD[(size_t)w * 81 + a * 9 + c] = lastDcol[a];
+    }
+    // backward sweep: lane c < 9 of a row of lanes owns row c of its window; the rows of X run kBwdDepth steps ahead
+    const int r = c < 9 ? c : 0;
+    const bool mine = active && c < 9;
+    double x = 0.0;
+    double Xring[kBwdDepth][10];
+    auto fetch_row = [&](int i, double (&dst)[10]) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) dst[j] = 0.0;
+        if (mine && i >= 0 && i < n) {
+            const double* X = V.Xs + (sb + i) * 81 + r * 9;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) dst[j] = X[j];
+            dst[9] = V.zs[(sb + i) * 9 + r];
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < kBwdDepth; ++k) fetch_row(nmax - 1 - k, Xring[k]);
+    for (int i0 = nmax - 1; i0 >= 0; i0 -= kBwdDepth) {
+#pragma unroll
+        for (int k = 0; k < kBwdDepth; ++k) {
+            const int i = i0 - k;
+            if (i < 0) break;
+            double cur[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) cur[j] = Xring[k][j];
+            fetch_row(i - kBwdDepth, Xring[k]);
+            double v = cur[9];
+            const double xb[9] = {bcast_row16<0>(x), bcast_row16<1>(x), bcast_row16<2>(x), bcast_row16<3>(x), bcast_row16<4>(x),
+                                  bcast_row16<5>(x), bcast_row16<6>(x), bcast_row16<7>(x), bcast_row16<8>(x)};
+            if (i < n - 1) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) v -= cur[j] * xb[j];
+            }
+            if (i < n) {        // (i == n - 1: x = z, the last block of this chain)
+                x = v;
+                if (mine) V.dpose[(sb + i) * 9 + r] = x;
+            }
+        }
+    }
+    quad_sync();
+    // flags + retraction, every row of lanes for its own window
+    const unsigned long long badmask = __ballot(badp && active);
+    const unsigned long long rowmask = 0xffffull << (16 * row);
+    if (active && c == 0 && (badmask & rowmask)) atomicOr(&sc.fl[V.par], PIVOT ? 4u : (8u | 16u));
+    bool bad = false;
+    if (active) bad = retract_range(V, sb, n, c, 16);
+    const unsigned long long anybad = __ballot(bad);
+    if (active && c == 0 && (anybad & rowmask)) atomicOr(&sc.fl[V.par], 2u);
 }
 
 // ================================================================================================== partitioned
@@ -1865,7 +2335,7 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
 // latency mode with a partitioned chain whose chunk (blocks + staged inputs + elimination scratch) fits the LDS of a CU:
 // the chunk kernel forms its blocks itself and k_assemble is not launched (vba_api.hip asks the same question)
 // ... and the sequential walk of the batched mode forms them pose by pose (vba_set_fusion bit 2)
-static bool walk_forms_blocks(const DevView& V) { return !V.lat && V.fuse_walk && !V.prm.initialize && V.chunk <= 0 && !V.pack; }
+static bool walk_forms_blocks(const DevView& V) { return !V.lat && V.fuse_walk && !V.prm.initialize && V.chunk <= 0 && V.pack != 1; }
 bool solve_forms_blocks(const DevView& V) {
     return walk_forms_blocks(V) || (V.lat && V.fuse_blocks && !V.prm.initialize && V.chunk >= 2 && V.chunk <= kFusedChunkMax);
 }
@@ -1878,8 +2348,14 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
         return;
     }
     if (V.chunk <= 0) {
-        if (V.pack) hipLaunchKernelGGL(k_solve_packed<PIVOT>, dim3((V.W + kPack - 1) / kPack), dim3(64), 0, s, V);   // equal pose counts: three windows per wavefront
-        else if (walk_forms_blocks(V)) {
+        if (V.pack == 2) {      // four windows per wavefront (DPP row broadcasts)
+            const dim3 g((V.W + kQuad - 1) / kQuad), b(64);
+            if (!walk_forms_blocks(V)) hipLaunchKernelGGL((k_solve_quad<PIVOT, false, false>), g, b, 0, s, V);
+            else if (V.reg) hipLaunchKernelGGL((k_solve_quad<PIVOT, true, true>), g, b, 0, s, V);
+            else hipLaunchKernelGGL((k_solve_quad<PIVOT, true, false>), g, b, 0, s, V);
+        }
+        else if (V.pack) hipLaunchKernelGGL(k_solve_packed<PIVOT>, dim3((V.W + kPack - 1) / kPack), dim3(64), 0, s, V);   // equal pose counts: three windows per wavefront
+        else if (walk_forms_blocks(V)) {     // (V.pack == 0: one window per wavefront)
             if (V.reg) hipLaunchKernelGGL((k_solve_forming<PIVOT, true>), dim3(V.W), dim3(64), 0, s, V);
             else hipLaunchKernelGGL((k_solve_forming<PIVOT, false>), dim3(V.W), dim3(64), 0, s, V);
         } else hipLaunchKernelGGL(k_solve<PIVOT>, dim3(V.W), dim3(64), 0, s, V);
