@@ -293,8 +293,12 @@ int vba_schur_upload(vba_schur_handle h, const int* lm_ptr, const int* row_pose,
                      const double* X0 /*[L,3] catalogue positions*/, double sigma_prior);
 int vba_schur_set_state(vba_schur_handle h, const double* states /*[n,10]*/, const double* landmarks /*[L,3]*/);
 int vba_schur_get_state(vba_schur_handle h, double* states, double* landmarks);
-/* one LM trial at damping lamda (added to every diagonal entry of B and C); *accepted = the cost went down and the state moved */
+/* one LM trial at damping lamda (added to every diagonal entry of B and C); *accepted = the cost went down and the state moved.
+ * A reduced camera system that is not positive definite at this damping is a REJECTED trial (*accepted = 0, *cost_after =
+ * *cost_before, state untouched; vba_schur_last_info tells the failing row): the caller raises lamda as after any rejection. */
 int vba_schur_iterate(vba_schur_handle h, double lamda, double* cost_before, double* cost_after, int* accepted);
+/* 0 if the last factorisation went through, else 1 + the row of the reduced system at which it met a non-positive pivot */
+int vba_schur_last_info(vba_schur_handle h, int* info);
 /* HIP-event times of the last iterate: build (blocks + Schur complement), factor (Cholesky), solve (substitutions + update) */
 int vba_schur_last_ms(vba_schur_handle h, float* build_ms, float* factor_ms, float* solve_ms);
 /* what = 0: the step of the last iterate [6 n + 3 L]; 1: its Cholesky factor, dense lower triangular [6n, 6n] */

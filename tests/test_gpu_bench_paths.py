@@ -295,3 +295,63 @@ def test_four_windows_per_wave_solve_gives_the_bits_of_one_window_per_wave(pivot
                 assert np.array_equal(a[k], b[k]), k
     # and against the oracle: the last window's last call from the states the device held before it
     assert all(np.isfinite(x[0]).all() for x in quad[-2])
+
+
+def test_hop_integrator_chained_runs_of_the_reference_on_gpu():
+    """vba_set_integrator(h, 1) / vinsat_amd.ba.configure(integrator="hop"): the integrator the reference itself takes when it
+    sees a GPU (predict_gpu, BA_filtering.py:16-17).  Against the reference's own chained runs with that integrator
+    (tools/gen_golden.py HOPC2 / HOPGAP): the C2 window -- every call from the reference's input states with the systems of
+    calls 10 and 19, then the 20 calls chained on the device -- and the two-pass sequence through the drop-in driver (40
+    calls, a ~950 s gap: nine 100 s hops and a remainder)."""
+    from conftest import golden_inputs
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import ba as ba_mod
+    from vinsat_amd import od_pipe, synth
+    g = load_golden("hopc2")
+    inp = golden_inputs(g)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    eng = BAEngine(n, m)
+    eng.set_integrator(True)
+    eng.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
+    eng.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+    for k in range(20):
+        st_in = g[f"states_in_{k}"][0] if f"states_in_{k}" in g else (g["states0"][0] if k == 0 else g[f"states_out_{k-1}"][0])
+        out, lam, hess, ntr, flags = eng.iterate(int(g["iters"][k]), bool(g["initialize"][k]), float(g["lamda_in"][k]), st_in)
+        assert ntr == g["n_trials"][k] and lam == g["lamda_out"][k] and flags == 0, k
+        assert rel_err(out, g[f"states_out_{k}"][0]) < 1e-8, k
+        if f"A_bands_{k}" in g:
+            A = eng.debug("bands")
+            A[:, 1] += eng.debug("scalars")[4] * np.eye(9)
+            assert rel_err(A, g[f"A_bands_{k}"][0]) < 1e-11, k
+            assert rel_err(eng.debug("rhs"), g[f"JTr_{k}"][0].reshape(n, 9)) < 1e-9, k
+            assert np.abs(eng.debug("r_pred") - g[f"r_pred_{k}"][0]).max() < 1e-9, k
+            D = np.array([1, 1, 1, 100.0, 100, 100])
+            Jf = g[f"Jf_blocks_{k}"][:, 0]
+            Phi = eng.debug("Phi")
+            assert rel_err((D[None, :, None] * Phi[:-1])[:, :, :3], Jf[:, :, :3]) < 1e-12
+            assert rel_err((D[None, :, None] * Phi[:-1])[:, :, 3:], Jf[:, :, 6:]) < 1e-12
+    eng.set_states(g["states0"][0], 1e-4)
+    eng.run_schedule([int(x) for x in g["iters"]], [bool(x) for x in g["initialize"]])
+    st, lam, _, ntr, flags = eng.get_states()
+    assert lam == g["lamda_out"][19] and flags == 0
+    assert rel_err(st, g["states_out_19"][0]) < 1e-7
+    eng.close()
+    # the two-pass sequence through the drop-in driver
+    gg = load_golden("hopgap")
+    det, orb = synth.make_two_pass_sequence()
+    ba_mod.release()
+    ba_mod.configure(integrator="hop")
+    try:
+        rec = []
+        errors, first_det, times = od_pipe.streaming_version(detections=det, orbit_np=orb, record=rec)
+    finally:
+        ba_mod.configure(integrator="rk4")
+        ba_mod.release()
+    assert [r["states"].shape[1] for r in rec] == list(gg["n_poses_per_call"])
+    for k in range(40):
+        ref = gg[f"states_out_{k}"][0]
+        st = rec[k]["states"][0].numpy()
+        assert np.abs(st[:, :3] - ref[:, :3]).max() / np.abs(ref[:, :3]).max() < 1e-6, k
+        assert rel_err(st, ref) < 1e-6, k
+        assert rec[k]["lamda"] == gg["lamda_out"][k]
+    assert rel_err(errors.numpy(), gg["errors"]) < 1e-5

@@ -88,3 +88,28 @@ def test_result_files_round_trip(tmp_path):
     tt = errors_eval.time_to_error(e, t, threshold_km=5.0)
     assert tt.shape == (2,) and tt[0] == t[0][np.argmax(e[0] < 5.0)]
     assert np.isnan(errors_eval.time_to_error([np.array([9.0, 8.0])], [np.array([1, 2])])[0])
+
+
+def test_two_pass_sequence_with_the_hop_integrator_matches_reference_run():
+    """The same two-pass sequence run by the reference with its GPU-default integrator (predict_gpu's <=100 s hops,
+    BA_utils.py:52-71: tools/gen_golden.py HOPGAP -> tests/golden/hopgap.npz): all 40 calls, with a gap of ~950 s inside the
+    second batch (nine 100 s hops and a remainder instead of ~950 one-second steps)."""
+    g = load_golden("hopgap")
+    det, orb = synth.make_two_pass_sequence()
+
+    def ba(iter, states, velocities, imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences, Sigma, V, lamda_init,
+           poses_gt_eci, initialize=False):
+        st, lam, hess, _ = O.ba_iteration(iter, states[0].numpy(), imu_meas[0, :, -1, 6:10].numpy(), landmarks[0].numpy(),
+                                          landmarks_xyz[0].numpy(), ii, time_idx, intrinsics[0].numpy(), confidences.numpy(),
+                                          lamda_init, initialize=initialize, hop=True)
+        return torch.from_numpy(st)[None], velocities, lam, torch.from_numpy(hess)[None]
+
+    rec = []
+    errors, first_det, times = od_pipe.streaming_version(detections=det, orbit_np=orb, ba=ba, record=rec)
+    assert [r["states"].shape[1] for r in rec] == list(g["n_poses_per_call"])
+    for k in range(40):
+        assert rel_err(rec[k]["states"][0].numpy(), g[f"states_out_{k}"][0]) < 1e-9, k
+        assert rec[k]["lamda"] == g["lamda_out"][k]
+    assert rel_err(errors.numpy(), g["errors"]) < 1e-6
+    plain = load_golden("gap")
+    assert rel_err(g["states_out_39"][0], plain["states_out_39"][0]) > 1e-9     # another integrator, another result

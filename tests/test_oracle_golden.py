@@ -169,3 +169,37 @@ def test_conditioning_of_the_degenerate_random_windows(seed, degenerate):
         ends[solver] = st
     drift = np.abs(ends["banded"] - ends["dense"]).max() / np.abs(ends["dense"]).max()
     assert (drift > 1e-6) if degenerate else (drift < 1e-9), drift
+
+
+def test_hop_integrator_chained_c2_run_of_the_reference():
+    """tests/golden/hopc2.npz: the reference's driver on the C2 window with its GPU-default integrator -- predict_gpu's
+    arithmetic: predict (BA_utils.py:457-527) with propagate_orbit_dynamics_skip (:52-71) in place of propagate_orbit_dynamics,
+    the only line in which the two functions differ besides device moves (tools/gen_golden.py HOPC2).  Every call from the
+    reference's own input states, then all 20 chained; the systems of calls 10 and 19."""
+    g = load_golden("hopc2")
+    inp = golden_inputs(g)
+    n = inp["K"].shape[0]
+    for k in range(20):
+        st_in = g[f"states_in_{k}"][0] if f"states_in_{k}" in g else (g["states0"][0] if k == 0 else g[f"states_out_{k-1}"][0])
+        dbg = {}
+        st, lam, last_h, ntr = O.ba_iteration(int(g["iters"][k]), st_in, inp["cumrot"], inp["uv"], inp["xyz"], inp["ii"], inp["time_idx"],
+                                              inp["K"], inp["conf"], float(g["lamda_in"][k]), initialize=bool(g["initialize"][k]),
+                                              solver="dense", hop=True, debug=dbg)
+        assert rel_err(st, g[f"states_out_{k}"][0]) < 1e-9, k
+        assert lam == g["lamda_out"][k] and ntr == g["n_trials"][k]
+        if f"A_bands_{k}" in g:
+            assert rel_err(dbg["trials"][0]["A"], g[f"A_bands_{k}"][0]) < 1e-11, k
+            assert rel_err(dbg["rhs"], g[f"JTr_{k}"][0].reshape(n, 9)) < 1e-9, k
+            assert np.abs(dbg["r_pred"] - g[f"r_pred_{k}"][0]).max() < 1e-9
+            assert rel_err(dbg["E"], g[f"Jf_blocks_{k}"][:, 0]) < 1e-13
+    st, lam = g["states0"][0], 1e-4
+    for k in range(20):
+        st, lam, _, ntr = O.ba_iteration(int(g["iters"][k]), st, inp["cumrot"], inp["uv"], inp["xyz"], inp["ii"], inp["time_idx"], inp["K"],
+                                         inp["conf"], lam, initialize=bool(g["initialize"][k]), solver="banded", hop=True)
+        assert ntr == g["n_trials"][k] and lam == g["lamda_out"][k]
+    assert rel_err(st, g["states_out_19"][0]) < 1e-8
+    # ... and it IS another integrator (one 5 s step instead of five 1 s steps): the dynamics residuals of call 10 differ from
+    # those of the plain C2 run, although the converged states agree to 1e-13 at these short gaps (tests/golden/hopgap.npz,
+    # with its ~950 s gap, is where the states differ: tests/test_od_pipe_host.py)
+    c2 = load_golden("c2")
+    assert np.abs(g["r_pred_10"][0] - c2["r_pred_10"][0]).max() > 1e-10     # (RK4 at 5 s vs 1 s on a LEO arc: 4e-10 km)

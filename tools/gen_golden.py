@@ -14,7 +14,7 @@ replaced by minimal equivalents before the import:
 ``torch_scatter`` (segment sum / mean, semantics fixed by the call sites
 ``BA_utils.py:1376-1382``) and ``ipdb`` (debugger hook, no-op).
 
-Usage: python tools/gen_golden.py [C1 C2 C3 C4 GAP HOP REGC1 REGC2 PRIORPROP REJ C5S]
+Usage: python tools/gen_golden.py [C1 C2 C3 C4 GAP HOP REGC1 REGC2 PRIORPROP REJ C5S HOPC2 HOPGAP]
 Outputs are data only (inputs + expected outputs), compressed .npz.
 """
 from __future__ import annotations
@@ -192,9 +192,23 @@ class Capture:
         self.od_pipe.BA = self._BA
 
 
-def run_config(name, od_pipe, baf, full_iters, store_inputs, store_states, drop=()):
-    if name == "GAP":
+def run_config(name, od_pipe, baf, full_iters, store_inputs, store_states, drop=(), hop=False):
+    if hop:
+        # The reference's GPU default: on a machine with a GPU, BA takes predict_gpu (BA_filtering.py:16-17), which is
+        # predict (BA_utils.py:457-527) with the coarse integrator propagate_orbit_dynamics_skip (:52-71) in place of
+        # propagate_orbit_dynamics (:73-87) and nothing else changed (the two functions differ in that line and in .cuda()
+        # / .cpu() moves only).  Here: the CPU branch with that one function swapped, i.e. predict_gpu's arithmetic.
+        import BA.BA_utils as bu
+        orig_prop = bu.propagate_orbit_dynamics
+        bu.propagate_orbit_dynamics = bu.propagate_orbit_dynamics_skip
+        try:
+            return run_config(name, od_pipe, baf, full_iters, store_inputs, store_states, drop)
+        finally:
+            bu.propagate_orbit_dynamics = orig_prop
+    if name in ("GAP", "HOPGAP"):
         det, orbit = synth.make_two_pass_sequence()
+    elif name == "HOPC2":
+        det, orbit = synth.make_sequence("C2", seed=0)
     elif name == "REJ":
         # confidences of 3 (> 1): the weighted trial residual (BA_filtering.py:66-69) no longer undercuts the unweighted
         # initial one for free, so the LM loop of plain BA rejects trials (:72-77) -- 1 to 9 trials per call
@@ -418,6 +432,10 @@ PLAN = {
     "REJ": dict(full_iters=(1, 5, 9, 16), store_inputs=True, store_states="all", drop=("landmark_est", "Jg", "Jf_blocks", "Hq_bands", "trial_est")),
     # the first 500 poses of the C5 orbit (3 s stride, 250 observations per pose): SURVEY 8(c)(ii)
     "C5S": dict(full_iters=(), store_inputs=False, store_states=(0, 9, 10, 14, 19)),
+    # chained runs with the integrator the reference itself takes when it sees a GPU (predict_gpu): the C2 window (5 s gaps:
+    # one 5 s step instead of five 1 s steps) and the two-pass sequence (a gap of several hundred seconds: 100 s hops)
+    "HOPC2": dict(full_iters=(10, 19), store_inputs=True, store_states="all", hop=True, drop=("landmark_est", "Jg", "Hq_bands", "trial_est")),
+    "HOPGAP": dict(full_iters=(), store_inputs=True, store_states="all", hop=True),
 }
 
 

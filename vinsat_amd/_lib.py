@@ -63,6 +63,7 @@ SIGNATURES = {
     "vba_schur_set_state": (c_int, [c_void_p, PD, PD]),
     "vba_schur_get_state": (c_int, [c_void_p, PD, PD]),
     "vba_schur_iterate": (c_int, [c_void_p, c_double, PD, PD, POINTER(c_int)]),
+    "vba_schur_last_info": (c_int, [c_void_p, POINTER(c_int)]),
     "vba_schur_last_ms": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float)]),
     "vba_schur_debug_fetch": (c_int, [c_void_p, c_int, PD, c_int64]),
 }

@@ -57,6 +57,23 @@ def _token(x):
     return ("obj", id(x))
 
 
+def configure(integrator=None):
+    """Settings of the cached engine that the reference's call surface has no argument for.
+
+    ``integrator``: ``"rk4"`` (default) = one-second RK4 steps, the reference's CPU branch ``predict``
+    (``BA_utils.py:73-87``) -- the parity target; ``"hop"`` = the <=100 s hops of ``predict_gpu``
+    (``BA_utils.py:52-71, 529-602``), which is what the reference itself runs when it sees a GPU
+    (``BA_filtering.py:16-17``).  Takes effect from the next call on."""
+    if integrator is not None:
+        if integrator not in ("rk4", "hop"):
+            raise ValueError("integrator must be 'rk4' or 'hop'")
+        _cache["hop"] = integrator == "hop"
+        eng = _cache.get("eng")
+        if eng is not None:
+            eng.set_integrator(_cache["hop"])
+        _cache["resident"] = None
+
+
 def invalidate():
     """Forget what is on the device: the next call uploads its window again (needed after an in-place edit of a
     NumPy argument, which no identity check can see)."""
@@ -82,6 +99,7 @@ def _engine_for(args, n, m, device):
             eng.close()
         eng = BAEngine(max(n, 16), max(m, 256), windows=1, device=device)
         eng.n_max, eng.m_max, eng.device = max(n, 16), max(m, 256), device
+        eng.set_integrator(bool(_cache.get("hop", False)))
         _cache["eng"] = eng
         invalidate()
     key = (n, m) + tuple(_token(a) for a in args)

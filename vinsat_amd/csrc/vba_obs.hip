@@ -616,8 +616,15 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     // Inline select (V.sel_inline: latency mode, carried keys in bin buckets): this kernel STARTS the call -- no select
     // kernel in front of it.  In a chained schedule its blocks evaluate the accept test of the call in front themselves
     // (warm_front) and go on only if that first trial was cleanly accepted.
-    const bool fold_here = V.sel_inline && V.call >= 0 && V.fold && sc.pending == V.call - 1 && sc.call_idx == V.call - 1;
-    if (!fold_here) VBA_SKIP_CALL(V, w);
+    // One relaxed atomic read of the two words, once per block.  The extra block of THIS grid (below) commits the call in front
+    // and writes call_idx = V.call while other blocks may not have started yet -- an intra-grid race that is benign because
+    // both outcomes let a block proceed: a block that still sees (pending, call_idx) = (call - 1, call - 1) takes fold_here,
+    // one that already sees call_idx = V.call passes the ordinary "window is at this call" test; no other value can be seen
+    // (the commit block is the only writer during this kernel, and it writes only after a clean accept).
+    const int seen_call = __atomic_load_n(&sc.call_idx, __ATOMIC_RELAXED);
+    const int seen_pending = __atomic_load_n(&sc.pending, __ATOMIC_RELAXED);
+    const bool fold_here = V.sel_inline && V.call >= 0 && V.fold && seen_pending == V.call - 1 && seen_call == V.call - 1;
+    if (!fold_here && !((V.call < 0 || seen_call == V.call) && (V.redo == 2 || (sc.miss != 0) == (V.redo != 0)))) return;     // VBA_SKIP_CALL on the snapshot
     // The accept test only GATES: nothing this kernel computes depends on it, and a trial that turns out not to be clean just
     // leaves no trace -- what this kernel writes on the way (weights, per-pose sums, the pose-chain factor of its rider
     // blocks) lives per call parity, the later trials of the call in front still find theirs.

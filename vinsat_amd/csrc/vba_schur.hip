@@ -489,6 +489,7 @@ struct vba_schur_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {};
     int* d_info = nullptr;
+    int last_info = 0;              // 0, or 1 + the row at which the last factorisation met a non-positive pivot
     double* S0 = nullptr;       // states buffers
     double* S1 = nullptr;
     double* X0buf = nullptr;
@@ -508,6 +509,7 @@ int vba_schur_create(int device, int n, int64_t m, int L, int nblk, int64_t npai
     if (!out) return sfail(VBA_EINVAL, "null out");
     *out = nullptr;
     if (n < 1 || m < 1 || L < 1 || nblk < n || npairs < m) return sfail(VBA_EINVAL, "sizes out of range");
+    if (m > INT32_MAX || npairs > INT32_MAX) return sfail(VBA_EINVAL, "m and npairs must fit 32-bit indices (CSR and pair lists are int32)");
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) return sfail(VBA_ENODEV, "no HIP device visible");
     if (device < 0 || device >= cnt) return sfail(VBA_EINVAL, "device index out of range");
@@ -673,10 +675,23 @@ int vba_schur_iterate(vba_schur_handle h, double lamda, double* cost_before, dou
     SCHK(hipMemcpyAsync(&info, h->d_info, 4, hipMemcpyDeviceToHost, s));
     SCHK(hipStreamSynchronize(s));
     for (int k = 0; k < 3; ++k) (void)hipEventElapsedTime(&h->ms[k], h->ev[k], h->ev[k + 1]);
-    if (info != 0) return sfail(VBA_ESTATE, "reduced camera system not positive definite at row " + std::to_string(info - 1));
+    h->last_info = info;
+    if (info != 0) {
+        // Not positive definite at this damping: the ordinary LM answer to a failed factorisation is a rejected trial (the
+        // caller raises lamda), not an error.  The state is untouched; vba_schur_last_info reports the failing row.
+        *cost_after = *cost_before;
+        *accepted = 0;
+        return VBA_OK;
+    }
     if (int rc = schur_cost(h, V.states_new, V.X_new, cost_after)) return rc;
     *accepted = (*cost_after < *cost_before) ? 1 : 0;
     if (*accepted) { std::swap(h->S0, h->S1); std::swap(h->X0buf, h->X1buf); }
+    return VBA_OK;
+}
+
+int vba_schur_last_info(vba_schur_handle h, int* info) {
+    if (!h || !info) return sfail(VBA_EINVAL, "null argument");
+    *info = h->last_info;
     return VBA_OK;
 }
 
