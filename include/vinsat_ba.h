@@ -43,7 +43,9 @@ enum {
 enum {
     VBA_FLAG_LAMBDA_EXHAUSTED = 1u, /* "lamda too large": no trial improved, last trial kept (BA_filtering.py:75-77) */
     VBA_FLAG_NONFINITE = 2u,        /* NaN/Inf met in the solve or the residuals */
-    VBA_FLAG_ZERO_PIVOT = 4u        /* a diagonal block was numerically singular */
+    VBA_FLAG_ZERO_PIVOT = 4u,       /* a diagonal block was numerically singular */
+    VBA_FLAG_HOST_CHANGED = 1u << 30 /* vba_iterate_resident only: a watched host buffer (vba_set_host_watch) no longer holds the bytes
+                                       that were uploaded -- the result was computed from the OLD window: upload again and repeat the call */
 };
 
 /* selectors for vba_debug_fetch: intermediates of the LAST vba_iterate call, window 0 unless stated */
@@ -229,6 +231,19 @@ int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const d
  * from the keys the last accepted trial left behind (vba_set_key_carry).  Same bits as vba_iterate. */
 int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out,
                          double* last_hessian, int* n_trials, unsigned* flags);
+
+/* Pipelining of the driver loop (default on; handles of one window).  vba_iterate_resident returns call k as soon as its
+ * accept test is known and has by then enqueued call k + 1 speculatively (iter + 1 / the same phase until the caller has
+ * been seen doing something else after that iter), so the device works through the caller's host-side turnaround; a call
+ * that was not asked for after all is waited for and dropped, at the price of the carried keys.  Results are bit-identical
+ * to vba_step.  While a speculated call is in flight VBA_DBG_DPOSE reports ITS step: switch the pipeline off to debug.
+ * vba_pipeline_stats: speculated calls that were used / dropped. */
+int vba_set_pipeline(vba_handle h, int on);
+/* Host buffers of the caller whose content was uploaded (e.g. the ndarray arguments ii / time_idx of BA()) and that the caller
+ * might edit in place: every vba_iterate_resident compares `live` with the reference `copy` (bytes each, both must stay valid;
+ * 4 slots, live == NULL clears one) while the device works and reports a difference as VBA_FLAG_HOST_CHANGED. */
+int vba_set_host_watch(vba_handle h, int slot, const void* live, const void* copy, int64_t bytes);
+int vba_pipeline_stats(vba_handle h, int* hits, int* discards);
 
 /* Copy an intermediate of the last step of `window` to host memory; *count receives the number of
  * doubles written (capacity is checked). */

@@ -355,3 +355,87 @@ def test_hop_integrator_chained_runs_of_the_reference_on_gpu():
         assert rel_err(st, ref) < 1e-6, k
         assert rec[k]["lamda"] == gg["lamda_out"][k]
     assert rel_err(errors.numpy(), gg["errors"]) < 1e-5
+
+
+def _ba_args(inp, n):
+    import torch
+    imu = torch.zeros((1, n, 1, 10), dtype=torch.float64)
+    imu[0, :, 0, 6:10] = torch.from_numpy(inp["cumrot"])
+    return dict(imu=imu, uv=torch.from_numpy(inp["uv"])[None], xyz=torch.from_numpy(inp["xyz"])[None], K=torch.from_numpy(inp["K"])[None],
+                conf=torch.from_numpy(inp["conf"]), ii=inp["ii"].copy(), t=inp["time_idx"].copy())
+
+
+@pytest.mark.parametrize("fixture", ["c2", "rej"])
+def test_pipelined_driver_loop_gives_the_bits_of_call_by_call_steps(fixture):
+    """vinsat_amd.ba.BA in the reference's loop shape (od_pipe.py:1036-1040).  Behind every call that feeds back the previous
+    result the library enqueues the next call speculatively (iter + 1; the phase change at iter 10 is a wrong guess the first
+    time and learnt afterwards); the results must be the bits of vba_step-by-step runs and of the reference's fixtures -- also
+    when calls reject trials and exhaust lamda (rej.npz: 1 .. 9 trials per call), where the speculated call finds the accept
+    test of the call in front not clean and skips itself."""
+    import torch
+    from conftest import golden_inputs
+    from vinsat_amd import ba as ba_mod
+    from vinsat_amd.engine import BAEngine
+    g = load_golden(fixture)
+    inp = golden_inputs(g)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    a = _ba_args(inp, n)
+    ba_mod.release()
+    outs = []
+    for rep in range(3):        # the second and third window profit from what the first one taught
+        st, lam = torch.from_numpy(g["states0"][0].copy())[None], 1e-4
+        seq = []
+        for k in range(20):
+            st, _, lam, hess = ba_mod.BA(int(g["iters"][k]), st, None, a["imu"], a["uv"], a["xyz"], a["ii"], a["t"], a["K"], a["conf"], 1e-3, 1e-3,
+                                         lam, None, initialize=bool(g["initialize"][k]))
+            assert ba_mod.BA.last["n_trials"] == g["n_trials"][k] and lam == g["lamda_out"][k], (rep, k)
+            seq.append((st.numpy()[0].copy(), lam, hess.numpy()[0].copy()))
+        outs.append(seq)
+    hits, discards = ba_mod._cache["eng"].pipeline_stats()
+    # most calls were found already enqueued (a call that rejects trials closes the chain: the next one starts afresh)
+    assert hits >= (45 if fixture == "c2" else 10), (hits, discards)
+    ba_mod.release()
+    # the same schedule step by step on a plain engine
+    e = BAEngine(n, m)
+    e.set_pipeline(False)
+    e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
+    e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+    e.set_states(g["states0"][0], 1e-4)
+    for k in range(20):
+        e.step(int(g["iters"][k]), bool(g["initialize"][k]))
+        st, lam, hess, ntr, flags = e.get_states()
+        for rep in range(3):
+            assert np.array_equal(outs[rep][k][0], st) and outs[rep][k][1] == lam and np.array_equal(outs[rep][k][2], hess), (rep, k)
+        assert rel_err(st, g[f"states_out_{k}"][0]) < 1e-6, k
+    e.close()
+
+
+def test_BA_sees_in_place_edits_of_its_numpy_arguments(c2):
+    """The reference passes ii and time_idx as ndarrays; a drop-in must not serve stale device data when the caller edits one
+    of them in place between calls (no identity check can see that): the content is compared with a private copy."""
+    import torch
+    from conftest import golden_inputs
+    from vinsat_amd import ba as ba_mod
+    g, inp = c2, golden_inputs(c2)
+    n = inp["K"].shape[0]
+    a = _ba_args(inp, n)
+    ba_mod.release()
+    st0 = torch.from_numpy(g["states0"][0].copy())[None]
+
+    def call():
+        return ba_mod.BA(0, st0, None, a["imu"], a["uv"], a["xyz"], a["ii"], a["t"], a["K"], a["conf"], 1e-3, 1e-3, 1e-4, None, initialize=True)[0].numpy().copy()
+
+    base = call()
+    assert np.array_equal(call(), base)
+    k = 1234                                    # one row moves to the neighbouring pose: nothing a strided sample would see
+    assert a["ii"][k] + 1 < n
+    a["ii"][k] += 1
+    a["ii"].sort()
+    edited = call()
+    assert not np.array_equal(edited, base)
+    fresh = dict(a, ii=a["ii"].copy())
+    ba_mod.release()
+    ref = ba_mod.BA(0, st0, None, fresh["imu"], fresh["uv"], fresh["xyz"], fresh["ii"], fresh["t"], fresh["K"], fresh["conf"], 1e-3, 1e-3, 1e-4, None,
+                    initialize=True)[0].numpy()
+    assert np.array_equal(edited, ref)
+    ba_mod.release()

@@ -75,13 +75,19 @@ def test_lm_converges_like_the_cpu_restatement_and_is_repeatable():
     e2.close()
 
 
-def test_indefinite_system_is_reported_not_hidden():
+def test_indefinite_system_is_a_rejected_trial_not_an_error():
+    """A reduced camera system that is not positive definite at the given damping fails its Cholesky factorisation: the
+    ordinary LM response is a rejected trial (the caller raises lamda), with the failing row on record -- not an abort."""
     d = _problem(12, 150, 5)
     d["w"] = -d["w"]                    # negative weights: the reduced system is not positive definite
-    from vinsat_amd import _lib
     e = _engine(d)
-    with pytest.raises(_lib.VbaError):
-        e.iterate(0.0)
+    before = e.get_state()
+    c0, c1, ok = e.iterate(0.0)
+    assert not ok and c1 == c0 and e.last_info() > 0
+    after = e.get_state()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])      # the state is untouched
+    hist = e.solve(lamda0=1e-4, max_iters=4)            # the driver keeps going (and keeps rejecting: nothing to gain here)
+    assert all(not h[2] for h in hist) and hist[-1][3] > hist[0][3]
     e.close()
 
 

@@ -33,6 +33,9 @@ SIGNATURES = {
     "vba_set_chunk_waves": (c_int, [c_void_p, c_int]),
     "vba_set_warm_select": (c_int, [c_void_p, c_int]),
     "vba_set_warm_shift": (c_int, [c_void_p, c_int]),
+    "vba_set_pipeline": (c_int, [c_void_p, c_int]),
+    "vba_set_host_watch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64]),
+    "vba_pipeline_stats": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "vba_set_bucket_cap": (c_int, [c_void_p, c_int]),
     "vba_warm_select_misses": (c_int, [c_void_p, POINTER(c_int)]),
     "vba_set_pivoting": (c_int, [c_void_p, c_int]),
@@ -46,7 +49,8 @@ SIGNATURES = {
     "vba_step": (c_int, [c_void_p, c_int, c_int]),
     "vba_run_schedule": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "vba_iterate": (c_int, [c_void_p, c_int, c_int, c_double, PD, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
-    "vba_iterate_resident": (c_int, [c_void_p, c_int, c_int, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
+    # (buffers as plain addresses: building a typed pointer object per call costs more than the call)
+    "vba_iterate_resident": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vba_debug_fetch": (c_int, [c_void_p, c_int, c_int, PD, c_int64, PI64]),
     "vba_last_step_ms": (c_int, [c_void_p, POINTER(c_float)]),
     "vba_step_profiled": (c_int, [c_void_p, c_int, c_int, POINTER(c_float)]),

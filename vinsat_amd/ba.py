@@ -15,12 +15,14 @@ the reference's (``[1,n,10]``, ``[1,9,9]``).
 What makes the reference's loop ``for iter in range(20): states, ... = BA(iter, states, ...)``
 (``od_pipe.py:1036-1040``) cheap here:
 
-* the window arguments (observations, per-pose constants) are uploaded once: a call whose arguments are
-  the SAME objects / buffers as the previous call's skips the upload.  "Same" is decided by identity, not by
-  content: buffer address, shape, strides, dtype, torch's in-place modification counter ``_version``, and -- for
-  NumPy arrays, which carry no such counter -- a 64-element strided sample.  The arguments of the last upload are
-  kept referenced, so an address cannot be recycled by another live array.  A caller that rewrites a NumPy
-  argument in place between calls must call :func:`invalidate` (or pass a new array);
+* the window arguments (observations, per-pose constants) are uploaded once: a call whose arguments are the SAME
+  buffers with the SAME content as the previous call's skips the upload.  For torch tensors "same" is decided by identity:
+  buffer address, shape, strides, dtype and torch's in-place modification counter ``_version`` (a write through a
+  ``.numpy()`` alias or ``.data`` does not bump that counter: call :func:`invalidate` after such a write).  NumPy arrays
+  carry no such counter, so their CONTENT is compared, byte for byte, with a private copy taken at the upload (``ii`` and
+  ``time_idx`` are what the reference passes as ndarrays: 0.4 MB at 500 / 50k, ~8 us of memcmp) -- an in-place edit is
+  seen and uploads the window again.  The arguments of the last upload are kept referenced, so an address cannot be
+  recycled by another live array;
 * a call whose ``states`` IS the tensor the previous call returned (and whose ``lamda_init`` is the value it
   returned) uploads nothing at all: the device already holds both (``vba_iterate_resident``).
 
@@ -46,15 +48,36 @@ def _np(x):
 
 
 def _token(x):
-    """Identity of an argument's buffer (not its content): see the module docstring."""
+    """Identity of an argument's buffer (torch: plus its in-place counter); the content of NumPy arrays is checked
+    separately (host watch, see :func:`_engine_for`), see the module docstring."""
     ver = getattr(x, "_version", None)
     if ver is not None:                                    # torch.Tensor
-        return (x.data_ptr(), tuple(x.shape), x.stride(), str(x.dtype), ver)
+        return (x.data_ptr(), tuple(x.shape), x.stride(), x.dtype, ver)
     if isinstance(x, np.ndarray):
-        flat = x.reshape(-1) if x.flags.c_contiguous else x.ravel()
-        sample = flat[:: max(1, flat.size // 64)]
-        return (x.__array_interface__["data"][0], x.shape, x.strides, x.dtype.str, sample.tobytes())
+        return (x.__array_interface__["data"][0], x.shape, x.strides, x.dtype.str)
     return ("obj", id(x))
+
+
+def _same_objects(args):
+    """The cheap test that almost every call of a driver loop passes: the very same Python objects as at the upload, torch
+    tensors with an unchanged in-place counter (ndarrays: their content is compared by the library while the device
+    works, see ``vba_set_host_watch``)."""
+    refs = _cache.get("refs")
+    if refs is None:
+        return False
+    vers = _cache["vers"]
+    for a, r, v in zip(args, refs, vers):
+        if a is not r or getattr(a, "_version", None) != v:
+            return False
+    return True
+
+
+def _numpy_unchanged(args):
+    """True if every ndarray among ``args`` still holds the bytes of the private copy taken when it was uploaded."""
+    for a, c in zip(args, _cache.get("np_copies", ())):
+        if c is not None and not (a.shape == c.shape and a.dtype == c.dtype and np.array_equal(a, c)):
+            return False
+    return True
 
 
 def configure(integrator=None):
@@ -75,11 +98,18 @@ def configure(integrator=None):
 
 
 def invalidate():
-    """Forget what is on the device: the next call uploads its window again (needed after an in-place edit of a
-    NumPy argument, which no identity check can see)."""
+    """Forget what is on the device: the next call uploads its window again (needed after a torch argument was written
+    through an alias that does not bump its ``_version``; edits of NumPy arguments are seen by themselves)."""
     _cache.pop("key", None)
     _cache.pop("refs", None)
+    _cache.pop("vers", None)
+    _cache.pop("nm", None)
+    _cache.pop("np_copies", None)
     _cache["resident"] = None
+    eng = _cache.get("eng")
+    if eng is not None and getattr(eng, "h", None):
+        for k in range(4):
+            eng.set_host_watch(k)
 
 
 def release():
@@ -102,8 +132,10 @@ def _engine_for(args, n, m, device):
         eng.set_integrator(bool(_cache.get("hop", False)))
         _cache["eng"] = eng
         invalidate()
+    if _cache.get("nm") == (n, m) and _same_objects(args):
+        return eng              # (ndarray contents: watched by the library during the call)
     key = (n, m) + tuple(_token(a) for a in args)
-    if _cache.get("key") != key:
+    if _cache.get("key") != key or not _numpy_unchanged(args):
         imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences = args
         cum = np.ascontiguousarray(_np(imu_meas)[0, :, -1, 6:10])
         uv = _np(landmarks).reshape(-1, 2)
@@ -119,8 +151,20 @@ def _engine_for(args, n, m, device):
         eng.upload_observations(xyz, uv, conf, ii_, n)
         eng.upload_window(K, cum, t)
         _cache["key"] = key
-        _cache["refs"] = args           # keeps the buffers alive: their addresses cannot be reused while cached
+        _cache["np_copies"] = tuple(a.copy() if isinstance(a, np.ndarray) else None for a in args)
         _cache["resident"] = None
+    # (also when only the Python objects are new -- fresh slices of the same buffers, as the reference's driver makes them)
+    _cache["nm"] = (n, m)
+    _cache["refs"] = args               # keeps the buffers alive: their addresses cannot be reused while cached
+    _cache["vers"] = tuple(getattr(a, "_version", None) for a in args)
+    # the library compares the live ndarrays with the copies that were uploaded during every resident call
+    slot = 0
+    for a, c in zip(args, _cache["np_copies"]):
+        if c is not None and slot < 4 and a.flags.c_contiguous:
+            eng.set_host_watch(slot, a, c)
+            slot += 1
+    for k in range(slot, 4):
+        eng.set_host_watch(k)
     return eng
 
 
@@ -132,7 +176,9 @@ def _shape_of(states):
 
 
 def _rows(landmarks):
-    shp = tuple(landmarks.shape)
+    shp = landmarks.shape
+    if len(shp) == 3:
+        return shp[0] * shp[1]
     return int(np.prod(shp[:-1])) if len(shp) > 1 else shp[0] // 2
 
 
@@ -152,14 +198,37 @@ def _wrap(out, lam, hess, reg):
     return st, torch.from_numpy(hess)[None]
 
 
+_HOST_CHANGED = 1 << 30
+
+
+def _call(eng, reg, iter, initialize, states, lamda_init, reupload):
+    """One call on the cached engine: resident if the states are the previous result, else with the states sent up.  A
+    resident call during which the library found a watched ndarray edited is repeated on the window as it is now."""
+    if _take_resident(states, lamda_init, reg):
+        out, lam, hess, n_trials, flags = eng.iterate_resident(iter, initialize)
+        if flags & _HOST_CHANGED:
+            invalidate()
+            eng = reupload()
+            out, lam, hess, n_trials, flags = eng.iterate(iter, initialize, float(lamda_init), _np(states)[0])
+    else:
+        if not _numpy_unchanged(_cache.get("refs", ())):      # (no resident call, no watch: compare here)
+            invalidate()
+            eng = reupload()
+        out, lam, hess, n_trials, flags = eng.iterate(iter, initialize, float(lamda_init), _np(states)[0])
+    return out, lam, hess, n_trials, flags & 7
+
+
 def BA(iter, states, velocities, imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences, Sigma, V,
        lamda_init, poses_gt_eci, initialize=False, device=0):
-    n = _shape_of(states)
-    eng = _engine_for((imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences), n, _rows(landmarks), device)
-    if _take_resident(states, lamda_init, False):
-        out, lam, hess, n_trials, flags = eng.iterate_resident(int(iter), bool(initialize))
-    else:
-        out, lam, hess, n_trials, flags = eng.iterate(int(iter), bool(initialize), float(lamda_init), _np(states)[0])
+    shp = states.shape
+    if len(shp) != 3 or shp[0] != 1 or shp[2] != 10:
+        _shape_of(states)
+    n = shp[1]
+    args = (imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences)
+    m = _rows(landmarks)
+    eng = _engine_for(args, n, m, device)
+    out, lam, hess, n_trials, flags = _call(eng, False, int(iter), bool(initialize), states, lamda_init,
+                                            lambda: _engine_for(args, n, m, device))
     if flags & 1:
         print("lamda too large")          # reference BA_filtering.py:76
     BA.last = dict(n_trials=n_trials, flags=flags)
@@ -181,20 +250,22 @@ def BA_reg(iter, states, velocities, states_prior, velocity_prior, hessian_state
     n = _shape_of(states)
     eng = _engine_for((imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences), n, _rows(landmarks), device)
     pkey = (_token(states_prior), _token(hessian_state_t))
-    if _cache.get("prior_key") != pkey or _cache.get("prior_for") != _cache.get("key"):
+    pc = _cache.get("prior_copies", (None, None))
+    same_bytes = all(c is None or np.array_equal(a, c) for a, c in zip((states_prior, hessian_state_t), pc))
+    if _cache.get("prior_key") != pkey or _cache.get("prior_for") != _cache.get("key") or not same_bytes:
         sp = _np(states_prior).reshape(-1, 10)
         Hs = _np(hessian_state_t).reshape(-1, 6, 6)
         if not (sp.shape[0] == n and Hs.shape[0] == n):
             raise ValueError("the prior must have one row per pose")
         eng.upload_prior(sp, Hs)
         _cache["prior_key"], _cache["prior_for"], _cache["prior_refs"] = pkey, _cache.get("key"), (states_prior, hessian_state_t)
+        _cache["prior_copies"] = tuple(a.copy() if isinstance(a, np.ndarray) else None for a in (states_prior, hessian_state_t))
         _cache["resident"] = None
     eng.set_prior(True)
     try:
-        if _take_resident(states, lamda_init, True):
-            out, lam, hess, n_trials, flags = eng.iterate_resident(int(iter), bool(initialize))
-        else:
-            out, lam, hess, n_trials, flags = eng.iterate(int(iter), bool(initialize), float(lamda_init), _np(states)[0])
+        args = (imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences)
+        out, lam, hess, n_trials, flags = _call(eng, True, int(iter), bool(initialize), states, lamda_init,
+                                                lambda: _engine_for(args, n, _rows(landmarks), device))
     finally:
         eng.set_prior(False)
     if flags & 1:

@@ -102,6 +102,17 @@ struct vba_context {
     int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
     size_t dbg_cap = 0;
+    // Pipelined driver loop (vba_iterate_resident, see iterate_pipelined): the call that was enqueued speculatively behind
+    // the one that has just been returned, the chain it belongs to and what has been learnt about the caller's schedule
+    struct Spec { bool valid = false; int iter = 0, init = 0; bool reg = false; int c = 0; } spec;
+    int chain_par0 = 0;                     // parity of call 0 of the open chain
+    int pred_iter[64], pred_init[64];       // what followed a resident call with iter & 63 (-1: not seen yet, -2: nothing resident)
+    int prev_res_iter = -1;                 // iter of the previous resident call (for learning), -1: none
+    int pipeline = 1;                       // vba_set_pipeline
+    int spec_hits = 0, spec_discards = 0;   // diagnostics (vba_pipeline_stats)
+    struct Watch { const void* live = nullptr; const void* copy = nullptr; size_t bytes = 0; } watch[4];   // vba_set_host_watch
+    double* h_states_map = nullptr;         // [2][n_max][10] mapped pinned host memory (DevView::host_states), one-window handles
+    hipEvent_t ev_first = nullptr;
 };
 
 namespace {
@@ -137,6 +148,26 @@ int read_heads(vba_handle h) {
 }
 
 const volatile WinHead* head(vba_handle h, int w) { return h->h_head + w; }
+
+// A call that vba_iterate_resident enqueued speculatively (iterate_pipelined) and that the caller did not ask for after all
+// -- or that anything else than the next resident call is about to disturb: wait for it and forget it.  It has run its
+// front and its first trial but nobody decided it: its input states, the result the caller holds, are intact (call
+// parity), its trial states and everything keyed to them are dropped.  `boundary`: the caller left the resident loop
+// (uploads, new states): remember not to speculate behind a call with that iter again.
+int settle(vba_handle h, bool boundary = false) {
+    if (!h || !h->spec.valid) return VBA_OK;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->par = (h->chain_par0 + h->spec.c) & 1;      // S[par]: the input of the speculated call = the last result
+    h->carry_ok = 0;                                // its trial consumed the carried keys and left its own
+    h->need_hist_reset = true;
+    h->hist_dirty = false;
+    h->spec.valid = false;
+    h->spec_discards++;
+    if (boundary && h->prev_res_iter >= 0) h->pred_iter[h->prev_res_iter & 63] = -2;
+    h->prev_res_iter = -1;
+    return VBA_OK;
+}
 
 int ready(vba_handle h) {
     for (int w = 0; w < h->W; ++w)
@@ -302,7 +333,12 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     // the second stream carries the dynamics factor beside the observation kernels and exists only where that is done (many
     // windows): a process maps its streams onto a few hardware queues, and every idle stream of another handle is one more
     // to share them with
-    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+    for (int k = 0; k < 64; ++k) h->pred_iter[k] = h->pred_init[k] = -1;
+    h->V.host_states = nullptr;
+    if ((windows == 1 && (hipEventCreateWithFlags(&h->ev_first, hipEventDisableTiming) != hipSuccess ||
+                          hipHostMalloc((void**)&h->h_states_map, (size_t)2 * n_max * 10 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                          hipHostGetDevicePointer((void**)&h->V.host_states, h->h_states_map, 0) != hipSuccess)) ||
+        hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
         (windows >= 16 && hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -335,9 +371,12 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
 
 int vba_destroy(vba_handle h) {
     if (!h) return VBA_OK;
+    (void)settle(h);
     hipSetDevice(h->device);
     if (h->own_stream) { hipStreamSynchronize(h->own_stream); hipStreamDestroy(h->own_stream); }
     if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); }
+    if (h->ev_first) hipEventDestroy(h->ev_first);
+    if (h->h_states_map) hipHostFree(h->h_states_map);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -358,6 +397,7 @@ int vba_destroy(vba_handle h) {
 
 int vba_set_solver2(vba_handle h, int chunk, int chunk2) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     if (chunk < 2 || chunk > 60 || (chunk2 != 0 && chunk2 != -1 && (chunk2 < 2 || chunk2 > 60)))
         return fail(VBA_EINVAL, "chunk sizes must be in [2, 60] (chunk2 = 0: single level, -1: cyclic reduction)");
     if (chunk2 == -1 && (h->n_max + chunk - 1) / chunk - 1 > 128)
@@ -370,6 +410,7 @@ int vba_set_solver2(vba_handle h, int chunk, int chunk2) {
 
 int vba_set_solver(vba_handle h, int chunk) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     h->V.chunk2 = 0;
     if (chunk == -1) {      // default: many windows supply their own parallelism (one wave walks each chain);
         h->no_pack = 0;     // otherwise the chain is cut into chunks and the reduced system over the (at most 64)
@@ -408,12 +449,14 @@ int vba_set_solver(vba_handle h, int chunk) {
 
 int vba_set_integrator(vba_handle h, int hop100) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     h->V.hop = hop100 ? 1 : 0;
     return VBA_OK;
 }
 
 int vba_set_accumulate_lanes(vba_handle h, int lanes) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     if (lanes == 0) {
         const double avg = (double)h->m_max / (double)h->n_max;
         int G = 4;
@@ -429,6 +472,7 @@ int vba_set_accumulate_lanes(vba_handle h, int lanes) {
 
 int vba_set_key_carry(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     h->carry_enabled = on != 0;
     h->carry_ok = false;
     return VBA_OK;
@@ -436,6 +480,7 @@ int vba_set_key_carry(vba_handle h, int on) {
 
 int vba_set_fusion(vba_handle h, int mask) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     if (mask < 0 || mask > 31) return fail(VBA_EINVAL, "mask must be in [0, 31]");
     h->fusion = mask;
     return VBA_OK;
@@ -443,6 +488,7 @@ int vba_set_fusion(vba_handle h, int mask) {
 
 int vba_set_chunk_waves(vba_handle h, int waves) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     if (waves != 1 && waves != 2) return fail(VBA_EINVAL, "waves must be 1 or 2");
     h->chunk_waves = waves;
     return VBA_OK;
@@ -450,6 +496,7 @@ int vba_set_chunk_waves(vba_handle h, int waves) {
 
 int vba_set_warm_select(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     h->warm_enabled = on == 2 ? 2 : (on != 0);
     h->inline_select = on != 3;     // 3: warm select as its own kernel (k_select_warm), the round-2 mid-point; comparison / tests
     return VBA_OK;
@@ -457,6 +504,7 @@ int vba_set_warm_select(vba_handle h, int on) {
 
 int vba_set_warm_shift(vba_handle h, int shift) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     if (shift < 42 || shift > 51) return fail(VBA_EINVAL, "shift must be in [42, 51]");
     h->V.warm_shift = shift;
     h->carry_ok = 0;            // a histogram binned with another width cannot be resolved
@@ -465,10 +513,34 @@ int vba_set_warm_shift(vba_handle h, int shift) {
 
 int vba_set_bucket_cap(vba_handle h, int cap) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     if (!h->bucket_cap_alloc) return fail(VBA_ESTATE, "this handle has no bin buckets (16 windows or more)");
     if (cap != 0 && (cap < 8 || cap > h->bucket_cap_alloc)) return fail(VBA_EINVAL, "cap must be 0 (default) or in [8, allocated capacity]");
     h->V.bucket_cap = cap ? cap : h->bucket_cap_alloc;
     h->carry_ok = 0;            // buckets filled with another stride are not addressable any more
+    return VBA_OK;
+}
+
+int vba_set_host_watch(vba_handle h, int slot, const void* live, const void* copy, int64_t bytes) {
+    if (!h || slot < 0 || slot >= 4) return fail(VBA_EINVAL, "bad argument (4 watch slots)");
+    if (live && (!copy || bytes < 1)) return fail(VBA_EINVAL, "a watched buffer needs its reference copy and a size");
+    h->watch[slot].live = live;
+    h->watch[slot].copy = live ? copy : nullptr;
+    h->watch[slot].bytes = live ? (size_t)bytes : 0;
+    return VBA_OK;
+}
+
+int vba_set_pipeline(vba_handle h, int on) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc = settle(h)) return rc;
+    h->pipeline = on != 0;
+    return VBA_OK;
+}
+
+int vba_pipeline_stats(vba_handle h, int* hits, int* discards) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (hits) *hits = h->spec_hits;
+    if (discards) *discards = h->spec_discards;
     return VBA_OK;
 }
 
@@ -480,6 +552,7 @@ int vba_warm_select_misses(vba_handle h, int* count) {
 
 int vba_set_pivoting(vba_handle h, int always) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     h->pivot_mode = always ? 1 : 0;
     return VBA_OK;
 }
@@ -492,6 +565,7 @@ int vba_solver_fallbacks(vba_handle h, int* count) {
 
 int vba_set_stream(vba_handle h, void* hip_stream, int external) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     hipStreamSynchronize(h->stream);
     h->stream = external ? (hipStream_t)hip_stream : h->own_stream;
     return VBA_OK;
@@ -500,6 +574,7 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external) {
 int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const double* xyz, const double* uv,
                             const double* conf, const int64_t* ii) {
     if (int rc = check_window(h, window)) return rc;
+    if (int rc_settle = settle(h, true)) return rc_settle;
     if (!xyz || !uv || !conf || !ii) return fail(VBA_EINVAL, "null observation array");
     h->carry_ok = false;
     if (n < 2 || n > h->n_max) return fail(VBA_EINVAL, "n out of range (need 2 <= n <= n_max)");
@@ -553,6 +628,7 @@ int vba_upload_observations(vba_handle h, int window, int n, int64_t m, const do
 int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics, const double* cumrot_last,
                       const int64_t* time_idx) {
     if (int rc = check_window(h, window)) return rc;
+    if (int rc_settle = settle(h, true)) return rc_settle;
     if (!intrinsics || !cumrot_last || !time_idx) return fail(VBA_EINVAL, "null pose-constant array");
     h->carry_ok = false;
     if (n < 2 || n > h->n_max) return fail(VBA_EINVAL, "n out of range (need 2 <= n <= n_max)");
@@ -586,6 +662,7 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
 
 int vba_upload_prior(vba_handle h, int window, int n, const double* states_prior, const double* hessian_state) {
     if (int rc = check_window(h, window)) return rc;
+    if (int rc_settle = settle(h, true)) return rc_settle;
     if (!states_prior || !hessian_state) return fail(VBA_EINVAL, "null prior array");
     if (!h->have_obs[window] && !h->have_win[window]) return fail(VBA_ESTATE, "upload the window before its prior");
     if (n != h->n[window]) return fail(VBA_EINVAL, "the prior needs one row per pose of the window");
@@ -612,6 +689,7 @@ int vba_set_prior(vba_handle h, int on) {
 
 int vba_set_states(vba_handle h, int window, const double* states, double lamda) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h, true)) return rc_settle;
     if (!states) return fail(VBA_EINVAL, "null states");
     h->carry_ok = 0;
     double* S = h->S[h->par];           // the input buffer of the next call
@@ -662,6 +740,7 @@ static void unpack_scalars(const WinScalars* sc, int par, double* lamda, double*
 int vba_get_states(vba_handle h, int window, double* states, double* lamda, double* last_hessian, int* n_trials,
                    unsigned* flags) {
     if (int rc = check_window(h, window)) return rc;
+    if (int rc_settle = settle(h)) return rc_settle;
     if (!h->have_state[window]) return fail(VBA_ESTATE, "no states uploaded");
     HIPCHK(hipSetDevice(h->device));
     const int n = h->n[window];
@@ -709,6 +788,7 @@ struct CallSpec {
 
 struct CallCtx {
     DevView V;
+    hipEvent_t after_first = nullptr;   // recorded behind the kernel that starts the call (the folded accept test of the call in front is in it)
     bool fuse_assemble = false;     // first trial's landmark-only solve rides in k_assemble<true> (batched windows)
     bool assembled = false;         // an assembly kernel ran (profile bookkeeping)
     bool bands_ready = false;       // bands / rhs are in memory (the fused landmark-only assembly does not write them)
@@ -815,6 +895,7 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
     if (V.median_ready) launch_select_finish(V, s);
     mark(3);
     launch_obs_accumulate(V, s);
+    if (C.after_first && V.sel_inline) HIPCHK(hipEventRecord(C.after_first, s));
     mark(4);
     if (!init && !overlap && !ride) launch_dynamics(V, s);
     if (overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
@@ -865,6 +946,7 @@ void enqueue_trial(vba_handle h, CallCtx& C, const CallSpec& c, bool first, hipE
 // trial (valid if that trial ends the call: h->back_valid), so that vba_iterate needs one wait instead of two.
 static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool emit = true, int readback = -1) {
     if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -979,6 +1061,70 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
 
 int vba_step(vba_handle h, int iter, int initialize) { return step_impl(h, iter, initialize, nullptr); }
 
+// The first trial of call q.call has been evaluated for the windows that stand at it (stall_at[w] == q.call) but was not
+// cleanly accepted by the kernel that was to start the next call (or the call's warm select missed): finish the call the
+// ordinary way -- decide, repeat the front with the exact digits where the select missed, further LM trials, the pivoted
+// repeat -- until every such window has moved on.  Shared by vba_run_schedule and the pipelined vba_iterate_resident.
+static int finish_stalled_call(vba_handle h, const CallSpec& q, const std::vector<int>& stall_at, long& trials) {
+    hipStream_t s = h->stream;
+    const int sc_call = q.call;
+    static const bool trace = std::getenv("VBA_TRACE") != nullptr;
+    CallCtx C;
+    view_for_call(h, C.V, q);
+    DevView& V = C.V;
+    // the front of this call has run (for the windows that reached it); what is on the device of it:
+    C.fuse_assemble = q.initialize && h->pivot_mode == 0 && V.fused_trial != 1;
+    C.assembled = q.initialize ? V.fused_trial != 1 : !solve_forms_blocks(V);
+    C.bands_ready = C.assembled && !C.fuse_assemble;
+    auto at_call = [&](int w) { return stall_at[w] == sc_call && head(h, w)->call_idx == sc_call; };
+    bool any_miss = false;
+    for (int w = 0; w < h->W; ++w) any_miss = any_miss || (at_call(w) && (head(h, w)->flags & 32u));
+    // (1) the first trial of the windows that got that far has been evaluated but not decided (the decision was left
+    //     to the next call's first kernel, which found it not clean): decide it now
+    V.pending_only = 1;
+    launch_decide(V, nullptr, 0, s);
+    V.pending_only = 0;
+    // (2) windows whose warm select missed repeat the front with the exact digits and run their first trial
+    if (any_miss) {
+        for (int w = 0; w < h->W; ++w) if (at_call(w) && (head(h, w)->flags & 32u)) h->h_head[w].flags = 0;
+        h->warm_misses++;
+        V.redo = 1;
+        if (int rc = enqueue_front(h, C, q, true, nullptr)) return rc;
+        enqueue_trial(h, C, q, true);
+        launch_decide(V, nullptr, 0, s);
+        V.redo = 0;
+        ++trials;
+    }
+    HIPCHK(hipGetLastError());
+    if (int rc = read_heads(h)) return rc;
+    bool finished = false;
+    for (int trial = 0; trial <= 24; ++trial) {
+        bool repeat = false, all = true;
+        for (int w = 0; w < h->W; ++w) {
+            if (!at_call(w)) continue;
+            all = false;
+            repeat = repeat || (head(h, w)->flags & 8u);
+        }
+        if (all) { finished = true; break; }
+        if (trial == 24) break;
+        if (repeat && V.pivot == 0) { V.pivot = 2; h->fallbacks++; }
+        enqueue_trial(h, C, q, false);
+        launch_decide(V, nullptr, 0, s);
+        HIPCHK(hipGetLastError());
+        if (int rc = read_heads(h)) return rc;
+        ++trials;
+        if (trace) {
+            std::fprintf(stderr, "[vba]   call %d round %d pivot %d:", sc_call, trial, V.pivot);
+            for (int w = 0; w < h->W && w < 8; ++w)
+                std::fprintf(stderr, " w%d(call %d done %d flags %u ntr %d lam %g)", w, head(h, w)->call_idx, head(h, w)->done, head(h, w)->flags, head(h, w)->n_trials, head(h, w)->lamda);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    if (!finished)
+        return fail(VBA_ESTATE, "LM loop of call " + std::to_string(sc_call) + " did not terminate (no outcome reported by the device)");
+    return VBA_OK;
+}
+
 // The 20-call loop of the driver (od_pipe.py:1036-1040) as ONE host call.  The kernels of every call are enqueued
 // back to back with a single LM trial each and, on carried keys, without a decide launch between them: the first kernel
 // of call c + 1 evaluates the accept test of call c itself.  A window whose first trial is not cleanly accepted (rejected,
@@ -987,6 +1133,7 @@ int vba_step(vba_handle h, int iter, int initialize) { return step_impl(h, iter,
 // vba_step calls.
 int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* inits, int* trials_total) {
     if (!h || !iters || !inits || ncalls < 1) return fail(VBA_EINVAL, "bad argument");
+    if (int rc_settle = settle(h)) return rc_settle;
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -1058,60 +1205,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             std::fprintf(stderr, "\n");
         }
         for (int sc_call : stalled) {
-            const CallSpec q = spec(sc_call, false);
-            CallCtx C;
-            view_for_call(h, C.V, q);
-            DevView& V = C.V;
-            // the front of this call has run (for the windows that reached it); what is on the device of it:
-            C.fuse_assemble = q.initialize && h->pivot_mode == 0 && V.fused_trial != 1;
-            C.assembled = q.initialize ? V.fused_trial != 1 : !solve_forms_blocks(V);
-            C.bands_ready = C.assembled && !C.fuse_assemble;
-            auto at_call = [&](int w) { return stall_at[w] == sc_call && head(h, w)->call_idx == sc_call; };
-            bool any_miss = false;
-            for (int w = 0; w < h->W; ++w) any_miss = any_miss || (at_call(w) && (head(h, w)->flags & 32u));
-            // (1) the first trial of the windows that got that far has been evaluated but not decided (the decision was left
-            //     to the next call's first kernel, which found it not clean): decide it now
-            V.pending_only = 1;
-            launch_decide(V, nullptr, 0, s);
-            V.pending_only = 0;
-            // (2) windows whose warm select missed repeat the front with the exact digits and run their first trial
-            if (any_miss) {
-                for (int w = 0; w < h->W; ++w) if (at_call(w) && (head(h, w)->flags & 32u)) h->h_head[w].flags = 0;
-                h->warm_misses++;
-                V.redo = 1;
-                if (int rc = enqueue_front(h, C, q, true, nullptr)) return rc;
-                enqueue_trial(h, C, q, true);
-                launch_decide(V, nullptr, 0, s);
-                V.redo = 0;
-                ++trials;
-            }
-            HIPCHK(hipGetLastError());
-            if (int rc = read_heads(h)) return rc;
-            bool finished = false;
-            for (int trial = 0; trial <= 24; ++trial) {
-                bool repeat = false, all = true;
-                for (int w = 0; w < h->W; ++w) {
-                    if (!at_call(w)) continue;
-                    all = false;
-                    repeat = repeat || (head(h, w)->flags & 8u);
-                }
-                if (all) { finished = true; break; }
-                if (trial == 24) break;
-                if (repeat && V.pivot == 0) { V.pivot = 2; h->fallbacks++; }
-                enqueue_trial(h, C, q, false);
-                launch_decide(V, nullptr, 0, s);
-                HIPCHK(hipGetLastError());
-                if (int rc = read_heads(h)) return rc;
-                ++trials;
-                if (trace) {
-                    std::fprintf(stderr, "[vba]   call %d round %d pivot %d:", sc_call, trial, V.pivot);
-                    for (int w = 0; w < h->W && w < 8; ++w)
-                        std::fprintf(stderr, " w%d(call %d done %d flags %u ntr %d lam %g)", w, head(h, w)->call_idx, head(h, w)->done, head(h, w)->flags, head(h, w)->n_trials, head(h, w)->lamda);
-                    std::fprintf(stderr, "\n");
-                }
-            }
-            if (!finished)
-                return fail(VBA_ESTATE, "LM loop of call " + std::to_string(sc_call) + " did not terminate (no outcome reported by the device)");
+            if (int rc = finish_stalled_call(h, spec(sc_call, false), stall_at, trials)) return rc;
         }
         next = stalled.front() + 1;
         if (next >= ncalls) { complete = true; break; }
@@ -1154,14 +1248,165 @@ int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const d
     return take_back(h, states_out, lamda_out, last_hessian, n_trials, flags);
 }
 
+// The driver loop `for iter in range(20): states, ... = BA(iter, states, ...)` (od_pipe.py:1036-1040) hands every call the
+// result of the one before, through the host.  Served call by call the device idles while the host unpacks one result and
+// enqueues the next call, and the host idles while the device works.  Here the two overlap: behind the call that is being
+// returned the NEXT call is enqueued speculatively (what follows iter k is learnt from the caller: k + 1 until told
+// otherwise), its first kernel evaluates the accept test of the call in front -- exactly the chained schedule of
+// vba_run_schedule, one link at a time -- and the host waits only for that kernel plus a 40 kB copy on a side stream,
+// while the rest of the speculated call runs under the caller's feet.  When the caller comes back with the predicted
+// arguments the call is already on its way.  A wrong guess costs one call's worth of device time and the carried keys
+// (settle); a first trial that is not cleanly accepted sends this call through the ordinary LM loop.  Same bits as
+// vba_step: the kernels, their order inside a call and the accept test are those of the chained schedule.
+static bool host_watch_changed(vba_handle h) {
+    for (const auto& w : h->watch)
+        if (w.live && std::memcmp(w.live, w.copy, w.bytes) != 0) return true;
+    return false;
+}
+
+static bool can_pipeline(vba_handle h) {
+    // (the trial kernel must be the one that forms the trial states: it also writes them to mapped host memory)
+    return h->pipeline && h->W == 1 && h->h_states_map && h->carry_enabled && h->warm_enabled == 1 && h->fold_enabled && h->inline_select &&
+           h->V.wbucket != nullptr && (h->fusion & 1) && h->pivot_mode == 0 && h->V.chunk > 0 && h->V.lat;
+}
+
+static int iterate_pipelined(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out, double* last_hessian,
+                             int* n_trials, unsigned* flags) {
+    if (int rc = ready(h)) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    constexpr int emit_kind = 2;
+    initialize = initialize ? 1 : 0;
+    // what the caller did after the previous resident call: remember it
+    if (h->prev_res_iter >= 0) {
+        h->pred_iter[h->prev_res_iter & 63] = iter;
+        h->pred_init[h->prev_res_iter & 63] = initialize;
+    }
+    bool consumed = false;
+    if (h->spec.valid) {
+        if (h->spec.iter == iter && h->spec.init == initialize && h->spec.reg == h->reg) {
+            consumed = true;
+            h->spec_hits++;
+        } else if (int rc = settle(h)) {
+            return rc;
+        }
+    }
+    struct Abandon {
+        vba_handle h; bool armed = true;
+        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = 0; h->spec.valid = false; h->prev_res_iter = -1; } }
+    } abandon{h};
+    auto call_spec = [&](int c, int it, int in, int carry, bool fold) {
+        CallSpec q;
+        q.iter = it; q.initialize = in; q.call = c; q.par = (h->chain_par0 + c) & 1;
+        q.carry = carry; q.emit = emit_kind; q.fold = fold;
+        return q;
+    };
+    bool watch_changed = false;
+    int c;                      // index of THIS call in the open chain
+    if (consumed) {
+        c = h->spec.c;
+        h->spec.valid = false;
+    } else {                    // open a chain with this call as its call 0
+        const int carry0 = h->carry_ok;
+        h->carry_ok = 0;
+        h->chain_par0 = h->par;
+        c = 0;
+        const CallSpec q = call_spec(0, iter, initialize, carry0, false);
+        CallCtx C;
+        view_for_call(h, C.V, q);
+        if (h->need_hist_reset) {
+            DevView Q = C.V;
+            for (int p = 0; p < 2; ++p) { Q.par = p; launch_clear_hist(Q, 1, s); }
+            h->need_hist_reset = false;
+            h->hist_dirty = false;
+        }
+        if (!carry0 && h->hist_dirty) launch_clear_hist(C.V, 0, s);
+        launch_reset_calls(C.V, s);
+        h->h_head[0].call_idx = 0; h->h_head[0].done = 0; h->h_head[0].flags = 0;
+        if (int rc = enqueue_front(h, C, q, false, nullptr)) return rc;
+        enqueue_trial(h, C, q, true);
+    }
+    h->hist_dirty = true;
+    // the call behind it, speculatively: its first kernel decides this one
+    int ni = h->pred_iter[iter & 63], nin = h->pred_init[iter & 63];
+    if (ni == -1) { ni = iter + 1; nin = initialize; }
+    const bool speculate = ni >= 0;
+    const CallSpec qc = call_spec(c, iter, initialize, emit_kind, false);       // (this call, as the stalled path needs it)
+    const int par_c = qc.par;
+    if (speculate) {
+        const CallSpec qn = call_spec(c + 1, ni, nin, emit_kind, true);
+        CallCtx C;
+        view_for_call(h, C.V, qn);
+        fill_params(C.V.prev, iter, initialize);
+        C.after_first = h->ev_first;
+        if (int rc = enqueue_front(h, C, qn, false, nullptr)) return rc;
+        enqueue_trial(h, C, qn, true);
+        // the first kernel of the speculated call has decided this one; the trial states and the outcome are in mapped host
+        // memory by then (k_trial, fold_commit): no copy, the rest of the speculated call runs on under the caller's feet
+        HIPCHK(hipGetLastError());
+        watch_changed = host_watch_changed(h);      // (while the device works)
+        HIPCHK(hipEventSynchronize(h->ev_first));
+    } else {                    // nothing resident is expected behind this call: decide it with a launch of its own
+        CallCtx C;
+        view_for_call(h, C.V, qc);
+        launch_decide(C.V, nullptr, 0, s);
+        HIPCHK(hipGetLastError());
+        watch_changed = host_watch_changed(h);
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    h->stepped = true;
+    h->last_iter = iter;
+    h->last_init = initialize;
+    h->back_valid = false;
+    const bool clean = (int)head(h, 0)->call_idx >= c + 1;
+    if (clean) {
+        h->par = par_c ^ 1;             // the trial buffer of this call is the next call's input
+        const volatile WinHead* hd = head(h, 0);
+        if (states_out) std::memcpy(states_out, h->h_states_map + (size_t)par_c * h->n_max * 10, (size_t)h->n[0] * 80);
+        if (lamda_out) *lamda_out = hd->lamda;
+        if (last_hessian) for (int k = 0; k < 81; ++k) last_hessian[k] = hd->last_hessian[k];
+        if (n_trials) *n_trials = 1;    // (a clean first trial)
+        if (flags) *flags = (hd->flags & 7u) | (watch_changed ? VBA_FLAG_HOST_CHANGED : 0u);
+        if (speculate) {
+            h->spec.valid = true; h->spec.iter = ni; h->spec.init = nin; h->spec.reg = h->reg; h->spec.c = c + 1;
+            h->carry_ok = 0;            // (the keys of the result belong to the speculated call now; settle() keeps the books)
+        } else {
+            h->carry_ok = emit_kind;
+        }
+        h->prev_res_iter = iter;
+        abandon.armed = false;
+        return VBA_OK;
+    }
+    // Not a clean first trial (rejected, pivot check failed, warm select missed): the speculated call has skipped itself
+    // (the window never moved on to it); finish this call the ordinary way.
+    HIPCHK(hipStreamSynchronize(s));
+    {
+        std::vector<int> stall_at(1, c);
+        long trials = 0;
+        if ((int)head(h, 0)->call_idx != c) return fail(VBA_ESTATE, "pipelined call: the window is at call " + std::to_string(head(h, 0)->call_idx) + ", expected " + std::to_string(c));
+        if (int rc = finish_stalled_call(h, qc, stall_at, trials)) return rc;
+    }
+    h->par = par_c ^ 1;
+    h->carry_ok = emit_kind;            // the accepted (or last) trial left the next call's keys behind
+    h->prev_res_iter = iter;
+    abandon.armed = false;
+    if (int rc = vba_get_states(h, 0, states_out, lamda_out, last_hessian, n_trials, flags)) return rc;
+    if (flags && watch_changed) *flags |= VBA_FLAG_HOST_CHANGED;
+    return VBA_OK;
+}
+
 // The next call of a driver loop that hands BA() the states it got back from the previous call: nothing to upload, the
 // device already holds them (and the carried keys of the last accepted trial stay usable).
 int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out, double* last_hessian,
                          int* n_trials, unsigned* flags) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (!h->stepped) return fail(VBA_ESTATE, "vba_iterate_resident follows a call that left its result on the device");
+    if (can_pipeline(h)) return iterate_pipelined(h, iter, initialize, states_out, lamda_out, last_hessian, n_trials, flags);
+    const bool watch_changed = host_watch_changed(h);
     if (int rc = step_impl(h, iter, initialize, nullptr, true, 0)) return rc;
-    return take_back(h, states_out, lamda_out, last_hessian, n_trials, flags);
+    if (int rc = take_back(h, states_out, lamda_out, last_hessian, n_trials, flags)) return rc;
+    if (flags && watch_changed) *flags |= VBA_FLAG_HOST_CHANGED;
+    return VBA_OK;
 }
 
 int vba_last_step_ms(vba_handle h, float* ms) {
@@ -1173,6 +1418,7 @@ int vba_last_step_ms(vba_handle h, float* ms) {
 
 int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t capacity, int64_t* count) {
     if (int rc = check_window(h, window)) return rc;
+    if (int rc_settle = settle(h)) return rc_settle;
     if (!out || !count) return fail(VBA_EINVAL, "null output");
     if (!h->stepped) return fail(VBA_ESTATE, "no step has run");
     HIPCHK(hipSetDevice(h->device));
@@ -1322,6 +1568,7 @@ static void sharded_view(vba_handle h, DevView& V) {
 
 int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, double* d_abs_local) {
     if (!h || !d_abs_local || m_total < 1) return fail(VBA_EINVAL, "bad argument");
+    if (int rc_settle = settle(h)) return rc_settle;
     if (h->W != 1) return fail(VBA_EINVAL, "sharded mode uses a single window per handle");
     if (h->reg) return fail(VBA_EINVAL, "sharded mode does not take a prior (vba_set_prior)");
     if (int rc = ready(h)) return rc;

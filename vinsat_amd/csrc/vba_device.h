@@ -93,6 +93,7 @@ struct WinHead {
     int n_trials;
     unsigned flags;
     int call_idx;
+    double last_hessian[81];        // of the call that has just been decided (BA_filtering.py:97), so that a pipelined call needs no copy
 };
 
 // Everything a kernel needs; passed by value.  Arrays of W windows use the *_max strides.
@@ -125,6 +126,8 @@ struct DevView {
     StepParams prm;                 // per-call constants, travel with the kernel arguments
     StepParams prev;                // those of the call in front (fold: its accept test is evaluated with them)
     WinHead* host_head;             // [W] mapped pinned host memory: k_decide publishes the outcome here
+    double* host_states;            // [2 (call parity)][n_max][10] mapped pinned host memory or null (one-window handles): the trial kernel
+                                    // that forms the trial states also writes them here -- the result of the call if the trial is accepted
     WinScalars* sc;                 // [W]
     // observations, pose sorted, SoA.  One contiguous block per window -- [ox | oy | oz | ou | ov | oconf] of m_pad doubles
     // each, then opose (m_pad ints) and the CSR pose_ptr (n_max + 1 ints) -- so that a window is uploaded with ONE copy;

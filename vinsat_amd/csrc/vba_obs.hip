@@ -228,7 +228,11 @@ __device__ __forceinline__ void fold_commit(const DevView& V, int w, const Decid
     WinScalars& sc = V.sc[w];
     const int t = threadIdx.x, par = V.par;
     const double lam32 = sc.lam32;      // of the decided call's solve
-    if (t < 81) sc.last_hessian[t] = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
+    if (t < 81) {
+        const double hv = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
+        sc.last_hessian[t] = hv;
+        V.host_head[w].last_hessian[t] = hv;
+    }
     if (t == 0) {
         sc.lam[par] = d.lam_out;
         sc.sum_in[par] = d.sum_next;
@@ -1084,6 +1088,10 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
                         for (int r = 0; r < 10; ++r) V.states_new[(sb + j) * 10 + r] = o[r];
 #pragma unroll
                         for (int r = 0; r < 9; ++r) V.dpose[(sb + j) * 9 + r] = d9[r];
+                        if (V.host_states) {        // (one-window handles: sb == 0)
+#pragma unroll
+                            for (int r = 0; r < 10; ++r) V.host_states[((size_t)par * V.n_max + j) * 10 + r] = o[r];
+                        }
                     }
                 }
                 if (FUSED == 1 && live && j == n - 1) {     // last_hessian of a landmark-only call: H / w_max on the 6x6, zeros elsewhere

@@ -2294,7 +2294,11 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
         return;
     }
     if (d.stop) {
-        if (t < 81) sc.last_hessian[t] = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
+        if (t < 81) {
+            const double hv = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
+            sc.last_hessian[t] = hv;
+            V.host_head[w].last_hessian[t] = hv;
+        }
     } else if (V.emit) {            // rejected: the next trial histograms its own keys
         for (int b = t; b < kSelBins; b += 256) hist_next[b] = 0u;
     }

@@ -34,6 +34,9 @@ class BAEngine:
         self.windows = windows
         self.n = [0] * windows
         self.m = [0] * windows
+        # out-parameters of the per-call entry points, made once: lamda, n_trials, flags and their addresses
+        lam, nt, fl = c_double(), c_int(), c_uint()
+        self._scal = (lam, nt, fl, ctypes.addressof(lam), ctypes.addressof(nt), ctypes.addressof(fl))
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
@@ -84,6 +87,16 @@ class BAEngine:
     def set_warm_shift(self, shift):
         """Tuning / test knob: log2 of the warm-bin width in bit patterns (52 = a binade)."""
         _lib.check(self.lib.vba_set_warm_shift(self.h, int(shift)), self.lib)
+
+    def set_pipeline(self, on):
+        """True (default): ``iterate_resident`` overlaps the caller's turnaround with a speculatively enqueued next call."""
+        _lib.check(self.lib.vba_set_pipeline(self.h, int(bool(on))), self.lib)
+
+    def pipeline_stats(self):
+        """(speculated calls used, speculated calls dropped)."""
+        a, b = c_int(), c_int()
+        _lib.check(self.lib.vba_pipeline_stats(self.h, byref(a), byref(b)), self.lib)
+        return a.value, b.value
 
     def set_bucket_cap(self, cap):
         """Test knob: keys a bin bucket can hold (0 = default); a fuller bin makes the call that needs it miss."""
@@ -172,12 +185,20 @@ class BAEngine:
     def iterate_resident(self, it, initialize):
         """``BA()`` on window 0 from the states and damping the previous call left on the device."""
         out = np.empty((self.n[0], 10))
-        lam = c_double()
         hess = np.empty((9, 9))
-        nt, fl = c_int(), c_uint()
-        _lib.check(self.lib.vba_iterate_resident(self.h, int(it), int(bool(initialize)), _p(out), byref(lam), _p(hess),
-                                                 byref(nt), byref(fl)), self.lib)
-        return out, lam.value, hess, nt.value, fl.value
+        sc = self._scal
+        rc = self.lib.vba_iterate_resident(self.h, int(it), 1 if initialize else 0, out.__array_interface__["data"][0],
+                                           sc[3], hess.__array_interface__["data"][0], sc[4], sc[5])
+        if rc:
+            _lib.check(rc, self.lib)
+        return out, sc[0].value, hess, sc[1].value, sc[2].value
+
+    def set_host_watch(self, slot, live=None, copy=None):
+        """Watch a caller's ndarray against the copy that was uploaded (see ``vba_set_host_watch``); ``live=None`` clears."""
+        if live is None:
+            _lib.check(self.lib.vba_set_host_watch(self.h, int(slot), None, None, 0), self.lib)
+        else:
+            _lib.check(self.lib.vba_set_host_watch(self.h, int(slot), live.ctypes.data, copy.ctypes.data, live.nbytes), self.lib)
 
     # "begin" = two back-to-back event records (the overhead every class contains), no kernel
     KERNELS = ("begin", "residual", "select", "accumulate", "dynamics", "assemble", "solve", "trial", "decide")

@@ -130,6 +130,12 @@ class SchurBA:
         self._check(self.lib.vba_schur_iterate(self.h, float(lamda), byref(c0), byref(c1), byref(acc)))
         return c0.value, c1.value, bool(acc.value)
 
+    def last_info(self):
+        """0 if the last factorisation went through, else 1 + the row at which it met a non-positive pivot."""
+        v = c_int()
+        self._check(self.lib.vba_schur_last_info(self.h, byref(v)))
+        return v.value
+
     def last_ms(self):
         a, b, c = c_float(), c_float(), c_float()
         self._check(self.lib.vba_schur_last_ms(self.h, byref(a), byref(b), byref(c)))
