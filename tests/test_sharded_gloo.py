@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, staged=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -31,7 +31,8 @@ def _worker(rank, world, port, tmp):
         b = shard_bounds(m, world)
         lo, hi = int(b[rank]), int(b[rank + 1])
         eng = OracleStageEngine(xyz[lo:hi], uv[lo:hi], conf[lo:hi], ii[lo:hi], inp["K"], inp["cumrot"], inp["time_idx"])
-        sba = ShardedBA(eng, inp["K"].shape[0], hi - lo, m)
+        from vinsat_amd.dist import HostStagedCollectives
+        sba = ShardedBA(eng, inp["K"].shape[0], hi - lo, m, collectives=HostStagedCollectives() if staged else None)
         st, lam = g["states0"][0], 1e-4
         ref, lam_ref = st.copy(), lam
         sba.set_states(st, lam)
@@ -63,6 +64,14 @@ def test_sharded_ba_matches_unsharded_oracle(world, tmp_path):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     trials = np.load(tmp_path / f"trials_{world}.npy")
     assert trials.shape == (7,)
+
+
+def test_host_staged_transport_carries_the_same_exchanges(tmp_path):
+    """vinsat_amd.dist.HostStagedCollectives (the transport of the two-process GPU test: device -> host -> gloo -> device)
+    behind the same ShardedBA control flow, here on CPU tensors."""
+    port = 29650 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    assert np.load(tmp_path / "trials_2.npy").shape == (7,)
 
 
 def test_shard_bounds_cover_rows():

@@ -777,6 +777,7 @@ namespace {
 // Latency mode, landmark-only call: 2 kernels (accumulate, trial); full call: 6 (+ assembly, chunks, two
 // cyclic-reduction kernels).  Call parity p: input states S[p], trial states S[p ^ 1] (see WinScalars).
 struct CallSpec {
+    bool host_out = false;  // pipelined vba_iterate_resident: trial states and last_hessian also go to mapped host memory
     int iter = 0, initialize = 0;
     int call = -1;          // index inside a chained schedule, -1: stand-alone
     int par = 0;
@@ -812,6 +813,7 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     }
     V.states_new = h->S[c.par ^ 1];
     V.states_prev = h->S[c.par];
+    if (!c.host_out) V.host_states = nullptr;
     V.emit = c.emit;
     V.carry = c.carry;
     V.fold = c.fold ? 1 : 0;
@@ -1299,6 +1301,7 @@ static int iterate_pipelined(vba_handle h, int iter, int initialize, double* sta
         CallSpec q;
         q.iter = it; q.initialize = in; q.call = c; q.par = (h->chain_par0 + c) & 1;
         q.carry = carry; q.emit = emit_kind; q.fold = fold;
+        q.host_out = true;
         return q;
     };
     bool watch_changed = false;

@@ -231,7 +231,7 @@ __device__ __forceinline__ void fold_commit(const DevView& V, int w, const Decid
     if (t < 81) {
         const double hv = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
         sc.last_hessian[t] = hv;
-        V.host_head[w].last_hessian[t] = hv;
+        if (V.host_states) V.host_head[w].last_hessian[t] = hv;     // (a pipelined call reads its result from host memory)
     }
     if (t == 0) {
         sc.lam[par] = d.lam_out;

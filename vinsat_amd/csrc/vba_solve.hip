@@ -2297,7 +2297,7 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
         if (t < 81) {
             const double hv = V.lastD[(size_t)w * 81 + t] + ((t / 9 == t % 9) ? lam32 : 0.0);
             sc.last_hessian[t] = hv;
-            V.host_head[w].last_hessian[t] = hv;
+            if (V.host_states) V.host_head[w].last_hessian[t] = hv;     // (a pipelined call reads its result from host memory)
         }
     } else if (V.emit) {            // rejected: the next trial histograms its own keys
         for (int b = t; b < kSelBins; b += 256) hist_next[b] = 0u;

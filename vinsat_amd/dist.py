@@ -74,11 +74,38 @@ class HipStageEngine:
         self.eng.close()
 
 
+class HostStagedCollectives:
+    """``all_gather_into_tensor`` for DEVICE tensors over a CPU process group (gloo): device -> host, gather, host -> device.
+
+    A rehearsal / test transport, not a fast path: RCCL needs one device per rank, so two ranks that share a GPU -- the only
+    way to run the multi-process + HIP-stage-kernel combination on a one-GPU box -- cannot use it.  Same interface as the
+    ``torch.distributed`` module as far as :class:`ShardedBA` uses it."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+
+    def get_world_size(self, group=None):
+        return self.dist.get_world_size(self.group)
+
+    def get_rank(self, group=None):
+        return self.dist.get_rank(self.group)
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        host_in = inp.detach().cpu()                    # (synchronises with the stream the stage kernels ran on)
+        host_out = self.torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather_into_tensor(host_out, host_in, group=self.group)
+        out.copy_(host_out)
+
+
 class ShardedBA:
     """One window, rows sharded over the ranks of ``group`` (default: the world group)."""
 
-    def __init__(self, engine, n, m_local, m_total, group=None):
+    def __init__(self, engine, n, m_local, m_total, group=None, collectives=None):
         import torch.distributed as dist
+        if collectives is not None:
+            dist = collectives
         self.dist = dist
         self.group = group
         self.engine = engine
@@ -98,10 +125,12 @@ class ShardedBA:
         self.n_trials = 0
 
     @classmethod
-    def from_window(cls, win, device=0, group=None):
+    def from_window(cls, win, device=0, group=None, collectives=None):
         """Build the GPU-backed sharded solver for a :class:`vinsat_amd.od_pipe.Window` on this rank."""
         import torch.distributed as dist
         from .engine import BAEngine
+        if collectives is not None:
+            dist = collectives
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         n, m = win.time_idx.size, win.ii.size
         b = shard_bounds(m, world)
@@ -109,7 +138,7 @@ class ShardedBA:
         eng = BAEngine(n, max(hi - lo, 1), windows=1, device=device)
         eng.upload_observations(win.landmarks_xyz[lo:hi], win.landmarks_uv[lo:hi], win.confidences[lo:hi], win.ii[lo:hi], n)
         eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
-        return cls(HipStageEngine(eng), n, hi - lo, m, group)
+        return cls(HipStageEngine(eng), n, hi - lo, m, group, collectives)
 
     def set_states(self, states, lamda):
         self.engine.set_states(states, lamda)
