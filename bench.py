@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--windows", type=int, default=4096, help="windows per launch of the batched series (0 = skip)")
     ap.add_argument("--batched-steps", type=int, default=40)
-    ap.add_argument("--profile-tag", default="r02", help="profiles/<tag>_w1_traffic.json / _mfma.json supply roofline.traffic / .mfma")
+    ap.add_argument("--profile-tag", default="r03", help="profiles/<tag>_w1_traffic.json / _mfma.json supply roofline.traffic / .mfma")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = every core of this box)")
     ap.add_argument("--no-sharded", action="store_true")
@@ -488,8 +488,10 @@ def run_rank(args):
         ba_mod.release()            # its handle (memory, stream) is not needed any more
         python_ba = {"value": 100 / dtp, "unit": "BA iterations/s", "ms_per_call": 1e3 * dtp / 100,
                      "note": "vinsat_amd.ba.BA called as the reference's driver calls BA (for iter in range(20): states, ... = "
-                             "BA(iter, states, ...)): window uploaded once (identity check), states fed back stay on the device, "
-                             "one host synchronisation and 40 kB read-back per call"}
+                             "BA(iter, states, ...)): window uploaded once (identity check; ndarray arguments compared byte for byte "
+                             "by the library while the device works), states fed back stay on the device, and behind every call the "
+                             "next one is enqueued speculatively (vba_set_pipeline): the host waits for the kernel that decides the "
+                             "call and reads the result from mapped host memory"}
 
     # ---- batched windows: W independent windows per launch
     batched = None

@@ -1280,8 +1280,11 @@ void launch_select(const DevView& V, bool with_digit0, hipStream_t s) {
 void launch_select_warm(const DevView& V, hipStream_t s) {
     const int64_t count = 2 * V.m_max;
     if (V.W >= 16) {
-        const int nb = (int)((count + 256 * 32 - 1) / (256 * 32));
-        hipLaunchKernelGGL((k_select_warm<32>), dim3(nb > 0 ? nb : 1, V.W), dim3(256), 0, s, V);
+#ifndef VBA_SELW_ITEMS
+#define VBA_SELW_ITEMS 32
+#endif
+        const int nb = (int)((count + 256 * VBA_SELW_ITEMS - 1) / (256 * VBA_SELW_ITEMS));
+        hipLaunchKernelGGL((k_select_warm<VBA_SELW_ITEMS>), dim3(nb > 0 ? nb : 1, V.W), dim3(256), 0, s, V);
     } else {
         const int nb = (int)((count + 256 * kSelItems - 1) / (256 * kSelItems));
         hipLaunchKernelGGL((k_select_warm<kSelItems>), dim3(nb > 0 ? nb : 1, V.W), dim3(256), 0, s, V);
