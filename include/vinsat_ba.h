@@ -155,7 +155,8 @@ int vba_set_bucket_cap(vba_handle h, int cap);
  *   bit 0: the trial kernel forms the step of each pose itself (landmark-only phase: the 6x6 solve; full phase: the
  *          recovery of the partitioned solve) -- no recovery launch and, in the landmark-only phase, no assembly + solve launch;
  *   bit 1: the chunk elimination forms the blocks of its chunk in LDS itself -- no assembly launch in the full phase, the
- *          bands never go through memory.
+ *          bands never go through memory.  With the generic formation it gained nothing (rounds 1, 2); formed by column
+ *          (asm_form_columns, a row of 16 lanes per pose row) it takes 1.1 us off the average call: default since round 3.
  *   bit 2: (16 windows and more, sequential driver) the solve of the full phase forms each block from the per-pose inputs
  *          itself -- no assembly launch, the bands never go through memory.  Bit-exact.  With one window per wavefront
  *          (k_solve_forming) it measured slower than assembly + walk (the walk was bound by instruction issue); since the
@@ -165,12 +166,9 @@ int vba_set_bucket_cap(vba_handle h, int cap);
  *          ~600 instructions per thread there), on par at 4096 windows (1.77 vs 1.85 ms).
  *   bit 4: only ONE cyclic-reduction level of the reduced system runs on its own CUs in front of the one-workgroup kernel
  *          (k_cr_level0) instead of two (k_cr_level01, default).  Same bits; 0.9 us per call slower.  Comparison / tests.
- * Default 13 (bits 0, 2 and 3).  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
+ * Default 15 (bits 0 .. 3).  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
  * formed by 16 lanes together (formed redundantly by every thread it was 6 us SLOWER: instruction issue of a single wave
- * is the time in this mode); bit 1 gains nothing (the assembly costs the elimination's block what its own launch cost)
- * and stays off -- also in its two-wave form, where the four waves of the block form the rows in uniform passes
- * (vba_asm_fast.h) before two of them eliminate from both ends: 56.7 against 56.2 us per call.  All masks are covered by the
- * parity tests. */
+ * is the time in this mode); bit 1, see above (48.0 against 49.1 us per call).  All masks are covered by the parity tests. */
 int vba_set_fusion(vba_handle h, int mask);
 
 /* Partitioned solve: waves per chunk.  2 (default): every chunk of 4 or more blocks is eliminated from both ends by two

@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
-"""Batched chain (W windows of C3, 20 calls) for a list of vba_set_fusion masks (diagnostic)."""
+"""One C3 window: us per call of the chained 20-call schedule for several vba_set_fusion masks, and whether the final states
+are bit-equal to the first mask's."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np
 from vinsat_amd import od_pipe, synth
 from vinsat_amd.engine import BAEngine
-W = int(sys.argv[1]); masks = [int(x) for x in sys.argv[2:]] or [1, 5]
-det, orb = synth.make_sequence("C3"); win = od_pipe.prepare_window(det, orb); st0 = od_pipe.initial_guess(win)
+masks = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["13", "15"])]
+det, orb = synth.make_sequence("C3")
+win = od_pipe.prepare_window(det, orb)
+st0 = od_pipe.initial_guess(win)
 n, m = win.time_idx.size, win.ii.size
-e = BAEngine(n, m, windows=W)
-for w in range(W):
-    e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n, window=w)
-    e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx, window=w)
 iters, inits = list(range(20)), [k < 10 for k in range(20)]
+ref = None
 for rep in range(2):
-    for mk in masks:
-        e.set_fusion(mk)
-        e.set_states(st0, 1e-4, window=-1); e.run_schedule(iters, inits)
+    for mask in masks:
+        e = BAEngine(n, m)
+        e.set_fusion(mask)
+        e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+        e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+        for r in range(5):
+            e.set_states(st0, 1e-4); e.run_schedule(iters, inits)
         t0 = time.perf_counter()
-        for r in range(3):
-            e.set_states(st0, 1e-4, window=-1); e.run_schedule(iters, inits)
-        dt = (time.perf_counter() - t0) / 60
-        print(f"W {W} mask {mk}: {1e3 * dt:.3f} ms per step, {W / dt:.0f} it/s", flush=True)
-e.close()
+        for r in range(50):
+            e.set_states(st0, 1e-4); e.run_schedule(iters, inits)
+        dt = (time.perf_counter() - t0) / 1000
+        st = e.get_states()[0]
+        if ref is None:
+            ref = st
+        print(f"mask {mask}: {1e6 * dt:.2f} us per call, bits equal to first: {np.array_equal(st, ref)}", flush=True)
+        e.close()

@@ -97,7 +97,7 @@ struct vba_context {
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
     int inline_select = 1;                  // latency mode: warm select inside the accumulation (bin buckets); vba_set_warm_select(h, 3) turns it off
     int chunk_waves = 2;                    // vba_set_chunk_waves
-    int fusion = 13;                        // vba_set_fusion (default: the trial kernel forms the step, uniform-pass assembly, block-forming walk)
+    int fusion = 15;                        // vba_set_fusion (default: the trial kernel forms the step, the solves form their own blocks, uniform-pass assembly)
     int bucket_cap_alloc = 0;               // allocated capacity of a bin bucket (vba_set_bucket_cap lowers the one in use)
     int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch

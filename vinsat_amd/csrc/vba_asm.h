@@ -39,6 +39,25 @@ __device__ __forceinline__ double asm_input(const DevView& V, size_t pb, int q, 
     return 0.0;
 }
 
+// The same value with the ADDRESS selected and one unconditional load (no per-element branch ladder: a thread that stages
+// several inputs has all its loads in flight together).  REG's prior residual (q >= 135) is computed: that alone branches.
+template <bool REG>
+__device__ __forceinline__ double asm_input_nobranch(const DevView& V, size_t pb, int q) {
+    const double* p = V.Hraw + pb * 21 + q;
+    p = q >= 21 ? V.braw + pb * 6 + (q - 21) : p;
+    p = q >= 27 ? V.Phi + pb * 36 + (q - 27) : p;
+    p = q >= 63 ? V.rorb + pb * 6 + (q - 63) : p;
+    p = q >= 69 ? V.qgrad + pb * 3 + (q - 69) : p;
+    p = q >= 72 ? V.Hd + pb * 9 + (q - 72) : p;
+    p = q >= 81 ? V.Hu + pb * 9 + (q - 81) : p;
+    p = q >= 90 ? V.Hl + pb * 9 + (q - 90) : p;
+    if (REG) {
+        p = q >= 99 ? V.prior_H + pb * 36 + (q >= 135 ? 0 : q - 99) : p;
+        if (q >= 135) return asm_input<REG>(V, pb, q, true);
+    }
+    return *p;
+}
+
 // slots [0, slots) of `in` receive the inputs of poses first .. first + slots - 1 (zeros outside [0, n)); every thread
 // of the block takes part (stride = block size); the caller synchronises
 template <bool REG>

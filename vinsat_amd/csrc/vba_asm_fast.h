@@ -201,4 +201,119 @@ __device__ __forceinline__ void asm_form_row(const AsmLanes& g, const double* me
     }
 }
 
+// ---------------------------------------------------------------------------------------------- column-wise formation
+// The same pose row formed by COLUMN: lane c of a row of 16 lanes gets column c of the diagonal block D_j (c < 9; lane 9: the
+// right-hand side), of the super-diagonal block U_j and of the sub-diagonal block L_j in registers -- the layout in which the
+// four-windows-per-wave walk (k_solve_quad) and the chunk elimination that forms its own blocks hold them.  Entry by
+// entry the operations of band_entry / rhs_entry (vba_math.h) in their order, so the same system to the bit; what differs
+// between the lanes (rotation column or not, which Phi column, right-hand side) is data.  ~250 instructions for the 16
+// lanes of a row, i.e. for FOUR pose rows per wave, where the uniform passes above cost ~400 per pose row.
+// Every read of the staged inputs is UNCONDITIONAL: the address is selected, one load is made, the value is selected
+// (`cond ? lds[i] : 0` compiles to a masked load in a basic block of its own with a full wait behind it; a few dozen of
+// those per block were most of the walk's time at one wave per SIMD).
+struct AsmColLane {
+    bool is_col, is_rhs, rotc, nonrot;
+    int pcl;            // column of Phi / row of F that this lane's state slot maps to (0 for a rotation slot)
+    int crl;            // rotation slot: its index 0..2
+    double fvc, Dcl;    // F_val of the lane's column; D of Phi row pcl
+};
+
+__device__ __forceinline__ AsmColLane asm_col_lane(int c) {
+    AsmColLane L;
+    L.is_col = c < 9;
+    L.is_rhs = c == 9;
+    L.rotc = c >= 3 && c < 6;
+    L.nonrot = L.is_col && !L.rotc;
+    L.pcl = c < 3 ? c : (L.nonrot ? c - 3 : 0);
+    L.crl = L.rotc ? c - 3 : 0;
+    L.fvc = c < 3 ? -1.0 : -kVelCoeff;
+    L.Dcl = L.pcl < 3 ? 1.0 : kVelCoeff;
+    return L;
+}
+
+// me / pv: staged inputs of pose j and of pose j - 1 (vba_asm.h layout); live: the pose exists (else zeros); A: column of
+// [D_j | rhs_j] WITHOUT damping; B: column of U_j; Lc: column of L_j (zeros in lanes without a column).
+template <bool REG>
+__device__ __forceinline__ void asm_form_columns(const AsmColLane& L, int c, const double* me, const double* pv, bool live, bool has_next,
+                                                 bool has_prev, double sigma, double iw, double (&A)[9], double (&B)[9], double (&Lc)[9]) {
+    const bool is_col = L.is_col, is_rhs = L.is_rhs, rotc = L.rotc, nonrot = L.nonrot;
+    const int pcl = L.pcl, crl = L.crl;
+    const double fs[2] = {vba_mul(-1.0, sigma), vba_mul(-kVelCoeff, sigma)};
+    // the lane's second factor of the J_f^T Sigma J_f sums: its column of E_j = D Phi_j, or r_orb (right-hand side)
+    double X[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const double Dr = r < 3 ? 1.0 : kVelCoeff;
+        const double xv = me[is_rhs ? 63 + r : 27 + 6 * r + pcl];
+        const double e = vba_mul(Dr, xv);
+        X[r] = nonrot ? e : (is_rhs ? xv : 0.0);
+    }
+    double Xp[6];
+    if (REG) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Xp[k] = me[is_rhs ? 135 + k : 99 + k * 6 + pcl];
+    }
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+        const bool rota = a >= 3 && a < 6;
+        const int pa = a < 3 ? a : a - 3;           // (non-rotation a)
+        double v = 0.0;
+        if (a < 6) {
+            const int idx = is_rhs ? 21 + a : sym6(a, c < 6 ? c : 0);
+            const double h = vba_mul(me[idx], iw);
+            v = (is_rhs || c < 6) ? h : 0.0;
+        }
+        {
+            double sdyn = 0.0;
+            if (!rota) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const double Dr = r < 3 ? 1.0 : kVelCoeff;
+                    sdyn = fma(vba_mul(vba_mul(Dr, me[27 + 6 * r + pa]), sigma), X[r], sdyn);
+                }
+            }
+            const double t = vba_add(v, is_rhs ? -sdyn : sdyn);
+            v = has_next ? t : v;
+        }
+        if (!rota) {
+            const double fsa = fs[a < 3 ? 0 : 1], fva = a < 3 ? -1.0 : -kVelCoeff;
+            const double zr = pv[63 + pa];
+            const double z = is_rhs ? -zr : fva;
+            const double t = fma(fsa, z, v);
+            v = (has_prev && (is_rhs || c == a)) ? t : v;
+        } else {
+            const double yv = me[is_rhs ? 69 + (a - 3) : 72 + 3 * (a - 3) + crl];
+            const double t = fma(sigma, is_rhs ? -yv : yv, v);
+            v = (is_rhs || rotc) ? t : v;
+        }
+        if (REG && !rota) {
+            double sp = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sp = fma(me[99 + k * 6 + pa], Xp[k], sp);
+            const double t = vba_add(v, sp);
+            v = (is_rhs || nonrot) ? t : v;
+        }
+        A[a] = (live && c < 10) ? v : 0.0;
+        // super-diagonal column and sub-diagonal column
+        double u, l;
+        if (!rota) {
+            const double fsa = fs[a < 3 ? 0 : 1];
+            const double eu = vba_mul(L.Dcl, me[27 + 6 * pcl + pa]);                // E_entry(Phi_j, F_row(c), a)
+            u = vba_mul(vba_mul(eu, sigma), L.fvc);
+            const double Dra = pa < 3 ? 1.0 : kVelCoeff;
+            const double el = vba_mul(Dra, pv[27 + 6 * pa + pcl]);                  // E_entry(Phi_{j-1}, F_row(a), c)
+            l = vba_mul(fsa, el);
+            u = nonrot ? u : 0.0;
+            l = nonrot ? l : 0.0;
+        } else {
+            u = vba_mul(sigma, me[81 + 3 * (a - 3) + crl]);
+            l = vba_mul(sigma, me[90 + 3 * (a - 3) + crl]);
+            u = rotc ? u : 0.0;
+            l = rotc ? l : 0.0;
+        }
+        B[a] = (has_next && is_col) ? u : 0.0;
+        Lc[a] = (has_prev && is_col) ? l : 0.0;
+    }
+}
+
 }  // namespace vba

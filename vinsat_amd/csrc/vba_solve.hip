@@ -781,104 +781,25 @@ __global__ __launch_bounds__(64) void k_solve_quad(DevView V) {
 #pragma unroll
         for (int k = 0; k < kPerIn; ++k) slot[lane + 64 * k] = src[k];
     };
-    // FORM: block j of this lane's window, column-wise -- the lane's column of [D_j | rhs_j] (nextA, undamped) and of U_j
-    // (nextB) straight into registers, its column of L_j into blk[buf] (every lane of the row reads all of L_j).  Entry by
-    // entry the operations of band_entry / rhs_entry (vba_math.h) in their order, so the same system to the bit; what
-    // differs between the lanes (rotation column or not, which Phi column, right-hand side) is data.
+    // FORM: block j of this lane's window, column-wise (asm_form_columns, vba_asm_fast.h) -- the lane's column of
+    // [D_j | rhs_j] (nextA, undamped) and of U_j (nextB) straight into registers, its column of L_j into blk[buf] (every lane
+    // of the row reads all of L_j).
     double nextA[9], nextB[9], lastDcol[9];
 #pragma unroll
     for (int a = 0; a < 9; ++a) lastDcol[a] = 0.0;
-    const bool is_col = c < 9, is_rhs = c == 9;
-    const bool rotc = c >= 3 && c < 6, nonrot = is_col && !rotc;
-    const int pcl = c < 3 ? c : (nonrot ? c - 3 : 0);          // column of Phi / row of F that this lane's state slot maps to
-    const int crl = rotc ? c - 3 : 0;
-    const double fvc = c < 3 ? -1.0 : -kVelCoeff;
-    const double Dcl = pcl < 3 ? 1.0 : kVelCoeff;
+    const AsmColLane cl = asm_col_lane(c);
+    const bool is_col = cl.is_col, is_rhs = cl.is_rhs;
+    (void)is_rhs;
     auto form = [&](int j, int buf) {
         const double* me = ring[j % 3] + row * kIn;
         const double* pv = ring[(j + 2) % 3] + row * kIn;
         double* Lout = blk[buf][row];
         const bool live = j < n, has_next = j < n - 1, has_prev = j > 0 && live;
-        const double sigma = V.prm.sigma, iw = inv_wmax4[0];       // (inv_wmax4[0]: this lane's own window, see below)
-        const double fs[2] = {vba_mul(-1.0, sigma), vba_mul(-kVelCoeff, sigma)};
-        // Every LDS read below is UNCONDITIONAL -- the address is selected, one load is made, the value is selected.
-        // (`cond ? lds[i] : 0` compiles to a masked load in a basic block of its own with a full wait behind it; a few dozen
-        // of those per block step were most of this kernel's time.)
-        auto ld = [](const double* p) { return *p; };
-        // the lane's second factor of the J_f^T Sigma J_f sums: its column of E_j = D Phi_j, or r_orb (right-hand side)
-        double X[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const double Dr = r < 3 ? 1.0 : kVelCoeff;
-            const double xv = ld(me + (is_rhs ? 63 + r : 27 + 6 * r + pcl));
-            const double e = vba_mul(Dr, xv);
-            X[r] = nonrot ? e : (is_rhs ? xv : 0.0);
-        }
-        double Xp[6];
-        if (REG) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) Xp[k] = ld(me + (is_rhs ? 135 + k : 99 + k * 6 + pcl));
-        }
+        double lcol[9];
+        asm_form_columns<REG>(cl, c, me, pv, live, has_next, has_prev, V.prm.sigma, inv_wmax4[0], nextA, nextB, lcol);
 #pragma unroll
         for (int a = 0; a < 9; ++a) {
-            const bool rota = a >= 3 && a < 6;
-            const int pa = a < 3 ? a : a - 3;           // (non-rotation a)
-            double v = 0.0;
-            if (a < 6) {
-                const int idx = is_rhs ? 21 + a : sym6(a, c < 6 ? c : 0);
-                const double h = vba_mul(ld(me + idx), iw);
-                v = (is_rhs || c < 6) ? h : 0.0;
-            }
-            {
-                double sdyn = 0.0;
-                if (!rota) {
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        const double Dr = r < 3 ? 1.0 : kVelCoeff;
-                        sdyn = fma(vba_mul(vba_mul(Dr, ld(me + 27 + 6 * r + pa)), sigma), X[r], sdyn);
-                    }
-                }
-                const double t = vba_add(v, is_rhs ? -sdyn : sdyn);
-                v = has_next ? t : v;
-            }
-            if (!rota) {
-                const double fsa = fs[a < 3 ? 0 : 1], fva = a < 3 ? -1.0 : -kVelCoeff;
-                const double zr = ld(pv + 63 + pa);
-                const double z = is_rhs ? -zr : fva;
-                const double t = fma(fsa, z, v);
-                v = (has_prev && (is_rhs || c == a)) ? t : v;
-            } else {
-                const double yv = ld(me + (is_rhs ? 69 + (a - 3) : 72 + 3 * (a - 3) + crl));
-                const double t = fma(sigma, is_rhs ? -yv : yv, v);
-                v = (is_rhs || rotc) ? t : v;
-            }
-            if (REG && !rota) {
-                double sp = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) sp = fma(ld(me + 99 + k * 6 + pa), Xp[k], sp);
-                const double t = vba_add(v, sp);
-                v = (is_rhs || nonrot) ? t : v;
-            }
-            nextA[a] = (live && c < 10) ? v : 0.0;
-            // super-diagonal column and sub-diagonal column
-            double u, l;
-            if (!rota) {
-                const double fsa = fs[a < 3 ? 0 : 1];
-                const double eu = vba_mul(Dcl, ld(me + 27 + 6 * pcl + pa));              // E_entry(Phi_j, F_row(c), a)
-                u = vba_mul(vba_mul(eu, sigma), fvc);
-                const double Dra = pa < 3 ? 1.0 : kVelCoeff;
-                const double el = vba_mul(Dra, ld(pv + 27 + 6 * pa + pcl));              // E_entry(Phi_{j-1}, F_row(a), c)
-                l = vba_mul(fsa, el);
-                u = nonrot ? u : 0.0;
-                l = nonrot ? l : 0.0;
-            } else {
-                u = vba_mul(sigma, ld(me + 81 + 3 * (a - 3) + crl));
-                l = vba_mul(sigma, ld(me + 90 + 3 * (a - 3) + crl));
-                u = rotc ? u : 0.0;
-                l = rotc ? l : 0.0;
-            }
-            nextB[a] = (has_next && is_col) ? u : 0.0;
-            Lout[is_col ? a * 9 + c : 96 + 9 * (c - 9) + a] = has_prev ? l : 0.0;      // (lanes without a column: a spare slot each)
+            Lout[is_col ? a * 9 + c : 96 + 9 * (c - 9) + a] = lcol[a];      // (lanes without a column: a spare slot each)
             lastDcol[a] = j == n - 1 ? nextA[a] : lastDcol[a];      // last_hessian (BA_filtering.py:97): kept, stored after the walk
         }
 #ifdef VBA_DEBUG_FORM
@@ -1604,27 +1525,59 @@ __global__ __launch_bounds__(256) void k_solve_chunks_ts_fused(DevView V, int s)
     double* elim = smem;                                                     // scratch of the elimination
     double* blocks = smem + twosided_lds_doubles(s);                         // [s + 1][252]
     double* in = blocks + (size_t)(s + 1) * 252;                             // [s + 2][kAsmIn]: poses j0 - 1 .. j1
-    asm_stage<REG>(V, w, n, true, j0 - 1, nblk + 1, in, tid, 256);
+    // staging: four loads per thread in flight at a time (the address is selected, never the load: vba_asm.h)
+    {
+        const int total = (nblk + 1) * kAsmIn;
+        for (int e0 = 0; e0 < total; e0 += 4 * 256) {
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + tid + 256 * k;
+                const int slot = e / kAsmIn, q = e - slot * kAsmIn;
+                const int i = j0 - 1 + slot;
+                const bool ok = e < total && i >= 0 && i < n;
+                v[k] = asm_input_nobranch<REG>(V, sb + (ok ? i : 0), ok ? q : 0);
+                v[k] = ok ? v[k] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + tid + 256 * k;
+                if (e < total) in[e] = v[k];
+            }
+        }
+    }
     __syncthreads();
     const double inv_wmax = 1.0 / bits_f64(sc.wmax_bits[V.par]);
     {
-        const int lane = tid & 63, wave = tid >> 6;
-        const AsmLanes g = asm_lanes(lane);
-        for (int q = wave; q < nblk; q += 4) {
-            const int i = j0 + q;
-            double* blk = blocks + (size_t)q * 252;
-            const bool sep = has_sep && i == j1, last = i == n - 1;
-            asm_form_row<REG>(g, in + (size_t)(q + 1) * kAsmIn, in + (size_t)q * kAsmIn, i < n - 1, i > 0, V.prm.sigma, inv_wmax, lane,
-                              [&](int e, double v) {
-                                  blk[e] = v;
-                                  // what later kernels read from memory: the right separator's diagonal block and right-hand side
-                                  // (reduced system), the last pose's diagonal block (last_hessian)
-                                  if (e >= 243) { if (sep) V.rhs[(sb + i) * 9 + (e - 243)] = v; }
-                                  else if (e >= 81 && e < 162) {
-                                      if (sep) V.bands[(sb + i) * 243 + e] = v;
-                                      if (last) V.lastD[(size_t)w * 81 + (e - 81)] = v;
-                                  }
-                              });
+        // formation by column: a row of 16 lanes per pose row, sixteen pose rows per pass of the workgroup
+        const int lane = tid & 63, wave = tid >> 6, row = lane >> 4, cc = lane & 15;
+        const AsmColLane cl = asm_col_lane(cc);
+        for (int q0 = 0; q0 < nblk; q0 += 16) {
+            const int q = q0 + wave * 4 + row;
+            const bool have = q < nblk;
+            const int qq = have ? q : 0;
+            const int i = j0 + qq;
+            double* blk = blocks + (size_t)qq * 252;
+            const bool sep = have && has_sep && i == j1, last = have && i == n - 1;
+            double A[9], B[9], Lc[9];
+            asm_form_columns<REG>(cl, cc, in + (size_t)(qq + 1) * kAsmIn, in + (size_t)qq * kAsmIn, true, i < n - 1, i > 0, V.prm.sigma, inv_wmax, A, B, Lc);
+            if (have && cc < 10) {
+#pragma unroll
+                for (int a9 = 0; a9 < 9; ++a9) {
+                    if (cc < 9) {
+                        blk[a9 * 9 + cc] = Lc[a9];
+                        blk[81 + a9 * 9 + cc] = A[a9];
+                        blk[162 + a9 * 9 + cc] = B[a9];
+                        // what later kernels read from memory: the right separator's diagonal block (reduced system), the
+                        // last pose's diagonal block (last_hessian)
+                        if (sep) V.bands[(sb + i) * 243 + 81 + a9 * 9 + cc] = A[a9];
+                        if (last) V.lastD[(size_t)w * 81 + a9 * 9 + cc] = A[a9];
+                    } else {
+                        blk[243 + a9] = A[a9];
+                        if (sep) V.rhs[(sb + i) * 9 + a9] = A[a9];
+                    }
+                }
+            }
         }
     }
     __syncthreads();
