@@ -149,6 +149,17 @@ int read_heads(vba_handle h) {
 
 const volatile WinHead* head(vba_handle h, int w) { return h->h_head + w; }
 
+// The second stream of handles with many windows carries the dynamics factor beside the streaming observation kernels.
+// VBA_AUX_PRIO (diagnostic): 1 = highest priority, -1 = lowest, unset / 0 = default.
+hipError_t create_aux_stream(hipStream_t* s) {
+    const char* e = std::getenv("VBA_AUX_PRIO");
+    const int want = e ? std::atoi(e) : 0;
+    if (want == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, want > 0 ? greatest : least);
+}
+
 // A call that vba_iterate_resident enqueued speculatively (iterate_pipelined) and that the caller did not ask for after all
 // -- or that anything else than the next resident call is about to disturb: wait for it and forget it.  It has run its
 // front and its first trial but nobody decided it: its input states, the result the caller holds, are intact (call
@@ -339,7 +350,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
                           hipHostMalloc((void**)&h->h_states_map, (size_t)2 * n_max * 10 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
                           hipHostGetDevicePointer((void**)&h->V.host_states, h->h_states_map, 0) != hipSuccess)) ||
         hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        (windows >= 16 && hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) ||
+        (windows >= 16 && create_aux_stream(&h->aux_stream) != hipSuccess) ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||

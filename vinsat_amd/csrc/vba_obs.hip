@@ -310,13 +310,12 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
     constexpr int PAIRS = ITEMS / 2;        // two keys (16 bytes) per load
     const double2* keys2 = reinterpret_cast<const double2*>(keys);
     const int64_t npair = count / 2;
-    double2 pk[PRELOAD ? PAIRS : 1];
-    if (PRELOAD) {
+    // (both forms request their keys before the histogram is resolved: the resolve is a dependent round trip plus a scan)
+    double2 pk[PAIRS];
 #pragma unroll
-        for (int it = 0; it < PAIRS; ++it) {
-            const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + t;
-            pk[it] = idx < npair ? keys2[idx] : make_double2(0.0, 0.0);
-        }
+    for (int it = 0; it < PAIRS; ++it) {
+        const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + t;
+        pk[it] = idx < npair ? keys2[idx] : make_double2(0.0, 0.0);
     }
     const unsigned long long lo = sc.warm_lo[V.par];
     unsigned bin, in_bin;
@@ -326,13 +325,12 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
         // Many windows per launch, coarse warm bins (1/8 binade: a few per cent of the keys match).  A returning atomic per
         // wave instruction would be a chain of ITEMS dependent round trips; instead the block counts its matches first,
         // reserves its share of the list with ONE atomic and then writes.  The keys stay in registers in between.
-        double2 kk[PAIRS];
+        double2 (&kk)[PAIRS] = pk;
         unsigned long long mbits = 0ull;        // bit 2 it: kk[it].x matches, bit 2 it + 1: kk[it].y
 #pragma unroll
         for (int it = 0; it < PAIRS; ++it) {
             const int64_t idx = ((int64_t)blockIdx.x * PAIRS + it) * 256 + t;
             const bool have = idx < npair;
-            kk[it] = have ? keys2[idx] : make_double2(0.0, 0.0);
             if (have && warm_bin(f64_bits(kk[it].x), lo, V.warm_shift) == bin) mbits |= 1ull << (2 * it);
             if (have && warm_bin(f64_bits(kk[it].y), lo, V.warm_shift) == bin) mbits |= 2ull << (2 * it);
         }

@@ -781,25 +781,108 @@ __global__ __launch_bounds__(64) void k_solve_quad(DevView V) {
 #pragma unroll
         for (int k = 0; k < kPerIn; ++k) slot[lane + 64 * k] = src[k];
     };
-    // FORM: block j of this lane's window, column-wise (asm_form_columns, vba_asm_fast.h) -- the lane's column of
-    // [D_j | rhs_j] (nextA, undamped) and of U_j (nextB) straight into registers, its column of L_j into blk[buf] (every lane
-    // of the row reads all of L_j).
+    // (The formation below is asm_form_columns of vba_asm_fast.h written out in place: called as the function, with the column
+    // of L_j handed back in registers and stored afterwards, this kernel took 3.5 ms instead of 2.3 -- fewer instructions,
+    // worse order, and one wave per SIMD has nothing to cover that with.  The two are the same arithmetic: the fusion tests
+    // compare them bit for bit.)
+    // FORM: block j of this lane's window, column-wise -- the lane's column of [D_j | rhs_j] (nextA, undamped) and of U_j
+    // (nextB) straight into registers, its column of L_j into blk[buf] (every lane of the row reads all of L_j).  Entry by
+    // entry the operations of band_entry / rhs_entry (vba_math.h) in their order, so the same system to the bit; what
+    // differs between the lanes (rotation column or not, which Phi column, right-hand side) is data.
     double nextA[9], nextB[9], lastDcol[9];
 #pragma unroll
     for (int a = 0; a < 9; ++a) lastDcol[a] = 0.0;
-    const AsmColLane cl = asm_col_lane(c);
-    const bool is_col = cl.is_col, is_rhs = cl.is_rhs;
-    (void)is_rhs;
+    const bool is_col = c < 9, is_rhs = c == 9;
+    const bool rotc = c >= 3 && c < 6, nonrot = is_col && !rotc;
+    const int pcl = c < 3 ? c : (nonrot ? c - 3 : 0);          // column of Phi / row of F that this lane's state slot maps to
+    const int crl = rotc ? c - 3 : 0;
+    const double fvc = c < 3 ? -1.0 : -kVelCoeff;
+    const double Dcl = pcl < 3 ? 1.0 : kVelCoeff;
     auto form = [&](int j, int buf) {
         const double* me = ring[j % 3] + row * kIn;
         const double* pv = ring[(j + 2) % 3] + row * kIn;
         double* Lout = blk[buf][row];
         const bool live = j < n, has_next = j < n - 1, has_prev = j > 0 && live;
-        double lcol[9];
-        asm_form_columns<REG>(cl, c, me, pv, live, has_next, has_prev, V.prm.sigma, inv_wmax4[0], nextA, nextB, lcol);
+        const double sigma = V.prm.sigma, iw = inv_wmax4[0];       // (inv_wmax4[0]: this lane's own window, see below)
+        const double fs[2] = {vba_mul(-1.0, sigma), vba_mul(-kVelCoeff, sigma)};
+        // Every LDS read below is UNCONDITIONAL -- the address is selected, one load is made, the value is selected.
+        // (`cond ? lds[i] : 0` compiles to a masked load in a basic block of its own with a full wait behind it; a few dozen
+        // of those per block step were most of this kernel's time.)
+        auto ld = [](const double* p) { return *p; };
+        // the lane's second factor of the J_f^T Sigma J_f sums: its column of E_j = D Phi_j, or r_orb (right-hand side)
+        double X[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const double Dr = r < 3 ? 1.0 : kVelCoeff;
+            const double xv = ld(me + (is_rhs ? 63 + r : 27 + 6 * r + pcl));
+            const double e = vba_mul(Dr, xv);
+            X[r] = nonrot ? e : (is_rhs ? xv : 0.0);
+        }
+        double Xp[6];
+        if (REG) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Xp[k] = ld(me + (is_rhs ? 135 + k : 99 + k * 6 + pcl));
+        }
 #pragma unroll
         for (int a = 0; a < 9; ++a) {
-            Lout[is_col ? a * 9 + c : 96 + 9 * (c - 9) + a] = lcol[a];      // (lanes without a column: a spare slot each)
+            const bool rota = a >= 3 && a < 6;
+            const int pa = a < 3 ? a : a - 3;           // (non-rotation a)
+            double v = 0.0;
+            if (a < 6) {
+                const int idx = is_rhs ? 21 + a : sym6(a, c < 6 ? c : 0);
+                const double h = vba_mul(ld(me + idx), iw);
+                v = (is_rhs || c < 6) ? h : 0.0;
+            }
+            {
+                double sdyn = 0.0;
+                if (!rota) {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        const double Dr = r < 3 ? 1.0 : kVelCoeff;
+                        sdyn = fma(vba_mul(vba_mul(Dr, ld(me + 27 + 6 * r + pa)), sigma), X[r], sdyn);
+                    }
+                }
+                const double t = vba_add(v, is_rhs ? -sdyn : sdyn);
+                v = has_next ? t : v;
+            }
+            if (!rota) {
+                const double fsa = fs[a < 3 ? 0 : 1], fva = a < 3 ? -1.0 : -kVelCoeff;
+                const double zr = ld(pv + 63 + pa);
+                const double z = is_rhs ? -zr : fva;
+                const double t = fma(fsa, z, v);
+                v = (has_prev && (is_rhs || c == a)) ? t : v;
+            } else {
+                const double yv = ld(me + (is_rhs ? 69 + (a - 3) : 72 + 3 * (a - 3) + crl));
+                const double t = fma(sigma, is_rhs ? -yv : yv, v);
+                v = (is_rhs || rotc) ? t : v;
+            }
+            if (REG && !rota) {
+                double sp = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sp = fma(ld(me + 99 + k * 6 + pa), Xp[k], sp);
+                const double t = vba_add(v, sp);
+                v = (is_rhs || nonrot) ? t : v;
+            }
+            nextA[a] = (live && c < 10) ? v : 0.0;
+            // super-diagonal column and sub-diagonal column
+            double u, l;
+            if (!rota) {
+                const double fsa = fs[a < 3 ? 0 : 1];
+                const double eu = vba_mul(Dcl, ld(me + 27 + 6 * pcl + pa));              // E_entry(Phi_j, F_row(c), a)
+                u = vba_mul(vba_mul(eu, sigma), fvc);
+                const double Dra = pa < 3 ? 1.0 : kVelCoeff;
+                const double el = vba_mul(Dra, ld(pv + 27 + 6 * pa + pcl));              // E_entry(Phi_{j-1}, F_row(a), c)
+                l = vba_mul(fsa, el);
+                u = nonrot ? u : 0.0;
+                l = nonrot ? l : 0.0;
+            } else {
+                u = vba_mul(sigma, ld(me + 81 + 3 * (a - 3) + crl));
+                l = vba_mul(sigma, ld(me + 90 + 3 * (a - 3) + crl));
+                u = rotc ? u : 0.0;
+                l = rotc ? l : 0.0;
+            }
+            nextB[a] = (has_next && is_col) ? u : 0.0;
+            Lout[is_col ? a * 9 + c : 96 + 9 * (c - 9) + a] = has_prev ? l : 0.0;      // (lanes without a column: a spare slot each)
             lastDcol[a] = j == n - 1 ? nextA[a] : lastDcol[a];      // last_hessian (BA_filtering.py:97): kept, stored after the walk
         }
 #ifdef VBA_DEBUG_FORM
@@ -841,10 +924,21 @@ __global__ __launch_bounds__(64) void k_solve_quad(DevView V) {
             const int buf = i & 1;
             const double* b = blk[buf][row];
             // this lane's column of [D_i + lam I | rhs_i] and of U_i
-            double baseA[9];
+            double baseA[9], baseB[9];
             if (FORM) {
 #pragma unroll
-                for (int r = 0; r < 9; ++r) baseA[r] = r == c ? nextA[r] + lam32 : nextA[r];
+                for (int r = 0; r < 9; ++r) {
+                    baseA[r] = r == c ? nextA[r] + lam32 : nextA[r];
+                    baseB[r] = nextB[r];
+                }
+                // Block i + 1 is formed HERE, in front of the elimination of block i and in the same basic block (nothing
+                // below branches): its LDS reads and multiply-adds are independent of the pivot chain, and interleaved with it
+                // they fill the chain's bubbles -- behind the elimination they were a second latency-bound phase.  Beyond the
+                // end of every chain it forms zeros / harmless values (no branch to skip it).
+                const int kh = (k + 2) % kFwdDepth;     // (static once the loop is unrolled)
+                if (!(VBA_QX & 2)) form(i + 1, buf ^ 1);
+                in_commit(i + 2, hold[kh]);
+                in_fetch(i + 2 + kFwdDepth, hold[kh]);
             } else {
                 const double* pa = c < 9 ? b + 81 + c : b + 243;
                 const int stride = c < 9 ? 9 : 1;
@@ -853,6 +947,7 @@ __global__ __launch_bounds__(64) void k_solve_quad(DevView V) {
                     double v = c < 10 ? pa[r * stride] : 0.0;
                     if (r == c) v += lam32;
                     baseA[r] = v;
+                    baseB[r] = c < 9 ? b[162 + r * 9 + c] : 0.0;
                 }
             }
             // D' = D - L X_{i-1}, y = g - L z_{i-1}: lane local (sparse L: [pp 0 pv; 0 rr 0; vp 0 vv])
@@ -872,25 +967,20 @@ __global__ __launch_bounds__(64) void k_solve_quad(DevView V) {
                 A[r] = v;
             }
 #pragma unroll
-            for (int r = 0; r < 9; ++r) B[r] = FORM ? nextB[r] : (c < 9 ? b[162 + r * 9 + c] : 0.0);
+            for (int r = 0; r < 9; ++r) B[r] = baseB[r];
             if (!(VBA_QX & 1)) quad_pivots<PIVOT>(baseA, A, B, c, badp);
-            if (active && i < n && c < 10) {        // column c of X_i, or z_i: one predicated run of stores
+            {   // column c of X_i, or z_i.  No branch: a lane with nothing to store writes into the chunk-solution scratch of its
+                // window (unused by this driver) instead
+                const bool st_ok = active && i < n && c < 10;
                 double* dst = c < 9 ? V.Xs + (sb + i) * 81 + c : V.zs + (sb + i) * 9;
-                const int stride = c < 9 ? 9 : 1;
+                dst = st_ok ? dst : V.csol + sb * 171 + (size_t)lane * 9;
+                const int stride = st_ok && c < 9 ? 9 : 1;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) dst[r * stride] = c < 9 ? B[r] : A[r];
             }
-            // block i + 1 goes to the other buffer (its loads were issued kFwdDepth steps ago); its register set takes the
-            // loads of block i + 1 + kFwdDepth
-            if (FORM) {
-                // ring: poses i, i + 1 (and the stale i - 1, whose slot pose i + 2 takes once block i + 1 is formed)
-                const int kh = (k + 2) % kFwdDepth;     // (static once the loop is unrolled)
-                if (i + 1 < nmax) {
-                    if (!(VBA_QX & 2)) form(i + 1, buf ^ 1);
-                    in_commit(i + 2, hold[kh]);
-                    in_fetch(i + 2 + kFwdDepth, hold[kh]);
-                }
-            } else {
+            if (!FORM) {
+                // block i + 1 goes to the other buffer (its loads were issued kFwdDepth steps ago); its register set takes the
+                // loads of block i + 1 + kFwdDepth
                 const int kn = (k + 1) % kFwdDepth;
                 if (i + 1 < nmax) {
                     stash(buf ^ 1, pre[kn]);
