@@ -672,10 +672,25 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     if (blockIdx.x * PPB >= n) return;
     const StepParams& prm = V.prm;
     const int sub = threadIdx.x % G;
-    const int i = blockIdx.x * PPB + threadIdx.x / G;
-    const size_t pb = (size_t)w * V.n_max + (i < n ? i : 0);
     const size_t ob = (size_t)w * V.obs_stride;
     const size_t mb = (size_t)w * V.m_max;
+    double wmax_l = 0.0;
+    // BATCH: a block walks several groups of PPB poses (grid = a quarter of the groups) and requests the row range of its
+    // NEXT group while it works on the current one -- the range is a dependent round trip in front of the first
+    // observation loads, and at two waves per SIMD nobody covers it.  Otherwise: one group per block, one pass.
+    const int gstride = BATCH ? (int)gridDim.x : 0;
+    int pf_beg = 0, pf_end = 0;
+    if (BATCH) {
+        const int i0 = blockIdx.x * PPB + threadIdx.x / G;
+        if (i0 < n) {
+            const int* ptr0 = V.pose_ptr + 2 * ob;
+            pf_beg = ptr0[i0];
+            pf_end = ptr0[i0 + 1];
+        }
+    }
+    for (int grp = blockIdx.x; grp * PPB < n; grp += gstride) {
+    const int i = grp * PPB + threadIdx.x / G;
+    const size_t pb = (size_t)w * V.n_max + (i < n ? i : 0);
 
     struct Obs { double x, y, z, u, v, c; };
     struct alignas(8) D2 { double a, b; };
@@ -710,14 +725,28 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     if (i < n) {
         pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
         const int* ptr = V.pose_ptr + 2 * ob;
-        beg = ptr[i];
-        end = ptr[i + 1];
+        if (BATCH) {
+            beg = pf_beg;
+            end = pf_end;
+        } else {
+            beg = ptr[i];
+            end = ptr[i + 1];
+        }
         if (PAIR) {
             if (beg + 2 * sub < end) nxt = load2(beg + 2 * sub);
         } else {
 #pragma unroll
             for (int d = 0; d < kAccDepth; ++d)
                 if (beg + sub + d * G < end) ring[d] = load(beg + sub + d * G);
+        }
+    }
+    if (BATCH) {        // the row range of this thread's pose in the block's next group
+        const int in = i + gstride * PPB;
+        pf_beg = pf_end = 0;
+        if (in < n) {
+            const int* ptr = V.pose_ptr + 2 * ob;
+            pf_beg = ptr[in];
+            pf_end = ptr[in + 1];
         }
     }
 
@@ -768,7 +797,6 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     // (J^T J = T G^T G T^T, T = diag(R, I)): ~130 VALU instructions per row instead of ~215.  Few rows per lane (latency
     // mode, 32 / 64 lanes per pose): the rotation per lane would cost what it saves, J is formed per row.
     constexpr bool CAM = G <= 16;
-    double wmax_l = 0.0;
     double acc[32];         // 21 + 6 sums, padded to a power of two for the halving reduction
 #pragma unroll
     for (int q = 0; q < 32; ++q) acc[q] = 0.0;
@@ -897,6 +925,8 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             else if (q < 27) B[q - 21] = acc[j];
         }
     }
+    if (!BATCH) break;
+    }       // groups of this block
     wmax_l = wave_max(wmax_l);
     if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = wmax_l;
     __syncthreads();
@@ -1304,8 +1334,12 @@ void launch_obs_accumulate(const DevView& V, hipStream_t s) {
 #endif
     constexpr bool kPair = VBA_ACC_PAIR != 0;
     if (V.median_ready && !V.dyn_in_acc && !V.sel_inline && (G == 8 || G == 16)) {      // many windows per launch
-        if (G == 8) hipLaunchKernelGGL((k_obs_accumulate<8, kPair, true>), g, b, 0, s, V);
-        else hipLaunchKernelGGL((k_obs_accumulate<16, false, true>), g, b, 0, s, V);
+#ifndef VBA_ACC_GROUPS
+#define VBA_ACC_GROUPS 4
+#endif
+        const dim3 gb((nb + VBA_ACC_GROUPS - 1) / VBA_ACC_GROUPS, V.W);    // a block walks VBA_ACC_GROUPS groups of poses
+        if (G == 8) hipLaunchKernelGGL((k_obs_accumulate<8, kPair, true>), gb, b, 0, s, V);
+        else hipLaunchKernelGGL((k_obs_accumulate<16, false, true>), gb, b, 0, s, V);
         return;
     }
     switch (G) {
