@@ -234,7 +234,8 @@ int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_
  * accept test is known and has by then enqueued call k + 1 speculatively (iter + 1 / the same phase until the caller has
  * been seen doing something else after that iter), so the device works through the caller's host-side turnaround; a call
  * that was not asked for after all is waited for and dropped, at the price of the carried keys.  Results are bit-identical
- * to vba_step.  While a speculated call is in flight VBA_DBG_DPOSE reports ITS step: switch the pipeline off to debug.
+ * to vba_step.  The call speculated behind a pipelined call reuses its scratch (maximum weight, step, trial states), so
+ * vba_debug_fetch refuses (VBA_ESTATE) after a pipelined call: switch the pipeline off to inspect intermediates.
  * vba_pipeline_stats: speculated calls that were used / dropped. */
 int vba_set_pipeline(vba_handle h, int on);
 /* Host buffers of the caller whose content was uploaded (e.g. the ndarray arguments ii / time_idx of BA()) and that the caller

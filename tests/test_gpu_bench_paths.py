@@ -439,3 +439,60 @@ def test_BA_sees_in_place_edits_of_its_numpy_arguments(c2):
                     initialize=True)[0].numpy()
     assert np.array_equal(edited, ref)
     ba_mod.release()
+
+
+def test_pipelined_calls_survive_whatever_happens_between_them(c2):
+    """The speculated call is an implementation detail: reading the states, fetching intermediates, toggling a switch,
+    uploading the window again or running a plain step between two resident calls must neither change a result nor leave the
+    handle in a state from which the next call differs from the unpipelined sequence -- BA and BA_reg, warm-select misses
+    forced on every call included."""
+    from conftest import golden_inputs
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    gr = load_golden("reg_c2")
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+
+    def make(pipe, reg, warm):
+        e = BAEngine(n, m)
+        e.set_pipeline(pipe)
+        e.set_warm_select(warm)
+        e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
+        e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+        if reg:
+            e.upload_prior(gr["states_prior"][0], gr["hessian_state_t"][0])
+            e.set_prior(True)
+        return e
+
+    for reg, warm in ((False, 1), (True, 1), (False, 2)):
+        plain, piped = make(False, reg, warm), make(True, reg, warm)
+        rp = plain.iterate(0, True, 1e-4, g["states0"][0])
+        rq = piped.iterate(0, True, 1e-4, g["states0"][0])
+        assert np.array_equal(rp[0], rq[0])
+        for k in range(1, 20):
+            init = k < 10
+            rp = plain.iterate_resident(k, init)
+            rq = piped.iterate_resident(k, init)
+            assert np.array_equal(rp[0], rq[0]) and rp[1] == rq[1] and np.array_equal(rp[2], rq[2]) and rp[3] == rq[3] and rp[4] == rq[4], (reg, warm, k)
+            # something else happens to the pipelined handle between the calls
+            if k % 5 == 1:
+                st = piped.get_states()
+                assert np.array_equal(st[0], rq[0]) and st[1] == rq[1]
+            elif k % 5 == 2:
+                from vinsat_amd._lib import VbaError
+                with pytest.raises(VbaError):               # intermediates of a pipelined call are not kept: refused, loudly
+                    piped.debug("rhs")
+            elif k % 5 == 3:
+                piped.set_chunk_waves(2)                    # (a no-op value: the speculated call is dropped all the same)
+            elif k == 9:
+                piped.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])        # the same constants again: "a new window"
+                piped.set_states(rq[0], rq[1])
+                plain.set_states(rp[0], rp[1])
+                rp = plain.iterate(10, False, rp[1], rp[0])
+                rq = piped.iterate(10, False, rq[1], rq[0])
+                assert np.array_equal(rp[0], rq[0])
+        if warm == 2:
+            assert piped.warm_select_misses() > 10
+        hits, drops = piped.pipeline_stats()
+        assert hits > 0 and drops > 0
+        plain.close()
+        piped.close()

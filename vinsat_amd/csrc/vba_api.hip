@@ -109,6 +109,7 @@ struct vba_context {
     int pred_iter[64], pred_init[64];       // what followed a resident call with iter & 63 (-1: not seen yet, -2: nothing resident)
     int prev_res_iter = -1;                 // iter of the previous resident call (for learning), -1: none
     int pipeline = 1;                       // vba_set_pipeline
+    bool last_pipelined = false;            // the last call went through iterate_pipelined: a speculated call has reused its scratch
     int spec_hits = 0, spec_discards = 0;   // diagnostics (vba_pipeline_stats)
     struct Watch { const void* live = nullptr; const void* copy = nullptr; size_t bytes = 0; } watch[4];   // vba_set_host_watch
     double* h_states_map = nullptr;         // [2][n_max][10] mapped pinned host memory (DevView::host_states), one-window handles
@@ -168,7 +169,10 @@ hipError_t create_aux_stream(hipStream_t* s) {
 int settle(vba_handle h, bool boundary = false) {
     if (!h || !h->spec.valid) return VBA_OK;
     HIPCHK(hipSetDevice(h->device));
+    launch_reset_calls(h->V, h->stream);            // (also clears a missed warm select the dropped call may have recorded)
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (int w = 0; w < h->W; ++w) h->h_head[w].flags = 0;
     h->par = (h->chain_par0 + h->spec.c) & 1;      // S[par]: the input of the speculated call = the last result
     h->carry_ok = 0;                                // its trial consumed the carried keys and left its own
     h->need_hist_reset = true;
@@ -1067,6 +1071,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     h->par ^= 1;                    // the trial buffer is the next call's input
     h->carry_ok = c.emit;           // (the kind of histogram that came with the keys)
     h->stepped = true;
+    h->last_pipelined = false;
     h->last_iter = iter;
     h->last_init = initialize;
     return VBA_OK;
@@ -1233,6 +1238,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     h->par = (par0 + ncalls) & 1;
     h->carry_ok = emit_kind;
     h->stepped = true;
+    h->last_pipelined = false;
     h->last_iter = iters[ncalls - 1];
     h->last_init = inits[ncalls - 1];
     return VBA_OK;
@@ -1279,7 +1285,7 @@ static bool host_watch_changed(vba_handle h) {
 
 static bool can_pipeline(vba_handle h) {
     // (the trial kernel must be the one that forms the trial states: it also writes them to mapped host memory)
-    return h->pipeline && h->W == 1 && h->h_states_map && h->carry_enabled && h->warm_enabled == 1 && h->fold_enabled && h->inline_select &&
+    return h->pipeline && h->W == 1 && h->h_states_map && h->carry_enabled && h->warm_enabled >= 1 && h->fold_enabled && h->inline_select &&
            h->V.wbucket != nullptr && (h->fusion & 1) && h->pivot_mode == 0 && h->V.chunk > 0 && h->V.lat;
 }
 
@@ -1369,6 +1375,7 @@ static int iterate_pipelined(vba_handle h, int iter, int initialize, double* sta
         HIPCHK(hipStreamSynchronize(s));
     }
     h->stepped = true;
+    h->last_pipelined = true;
     h->last_iter = iter;
     h->last_init = initialize;
     h->back_valid = false;
@@ -1435,6 +1442,9 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
     if (int rc_settle = settle(h)) return rc_settle;
     if (!out || !count) return fail(VBA_EINVAL, "null output");
     if (!h->stepped) return fail(VBA_ESTATE, "no step has run");
+    if (h->last_pipelined)
+        return fail(VBA_ESTATE, "the last call was a pipelined vba_iterate_resident: the call speculated behind it has reused its scratch "
+                                "(maximum weight, step, trial states); switch the pipeline off (vba_set_pipeline(h, 0)) to inspect intermediates");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int n = h->n[window];

@@ -1243,6 +1243,7 @@ __global__ void k_reset_calls(DevView V) {
     if (w < V.W) {
         V.sc[w].call_idx = 0;
         V.sc[w].pending = -1;
+        V.sc[w].miss = 0;       // (a speculated call that was dropped may have recorded a missed warm select: nobody will repeat it)
     }
 }
 
