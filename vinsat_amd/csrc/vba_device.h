@@ -238,8 +238,23 @@ __device__ __forceinline__ double block_sum(double v, double* lds /*[BLOCK/64]*/
     return t;
 }
 
+// (bcast_row16 below needs these first)
 __device__ __forceinline__ unsigned long long f64_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 __device__ __forceinline__ double bits_f64(unsigned long long b) { return __longlong_as_double((long long)b); }
+
+// Lane K of this lane's ROW of 16 lanes, to every lane of the row: one DPP move per 32 bits (row_newbcast, gfx90a and later;
+// control 0x150 + K) -- no LDS crossbar round trip (ds_bpermute) and no scalar register (v_readlane serves one row only).
+template <int K>
+__device__ __forceinline__ double bcast_row16(double v) {       // lane K of this lane's row of 16
+    const unsigned long long b = f64_bits(v);
+    // (mov_dpp: no `old` operand -- every lane is written, and update_dpp(0, ...) costs a v_mov of the zero per use)
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, 0x150 + K, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), 0x150 + K, 0xf, 0xf, false);
+    return bits_f64(((unsigned long long)hi << 32) | lo);
+}
+template <int K>
+__device__ __forceinline__ int bcast_row16_i32(int v) { return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, false); }
+
 
 // Resolve one radix-select digit: given the histogram of digit p among keys matching the prefix and the
 // rank wanted inside that set, every thread of the block gets (new prefix, new rank).  256 threads.

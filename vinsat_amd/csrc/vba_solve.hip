@@ -575,17 +575,6 @@ __global__ __launch_bounds__(64) void k_solve_packed(DevView V) {
 // forward_step, so the same bits as k_solve.  Windows may differ in length; rows are independent (nothing crosses a row).
 constexpr int kQuad = 4;
 
-template <int K>
-__device__ __forceinline__ double bcast_row16(double v) {       // lane K of this lane's row of 16
-    const unsigned long long b = f64_bits(v);
-    // (mov_dpp: no `old` operand -- every lane is written, and update_dpp(0, ...) costs a v_mov of the zero per use)
-    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, 0x150 + K, 0xf, 0xf, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), 0x150 + K, 0xf, 0xf, false);
-    return bits_f64(((unsigned long long)hi << 32) | lo);
-}
-template <int K>
-__device__ __forceinline__ int bcast_row16_i32(int v) { return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, false); }
-
 // One block step of four chains.  c = lane inside the row.  In: A = this lane's column of [I | z_{i-1}] (lane 9: z),
 // B = column of X_{i-1}; baseA = column of [D_i + lam I | rhs_i], baseB = column of U_i.  Out: A = [I | z_i], B = X_i.
 template <bool PIVOT, int K = 0>

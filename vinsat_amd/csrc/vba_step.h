@@ -87,6 +87,23 @@ __device__ __forceinline__ void step_recover(int i, int n, int s, const double* 
 //   landmark-only: lane c < 7 owns column c of [A | b] (Gauss-Jordan, pivot row broadcast from lane k);
 //   recovery:      lane r < 9 forms row r of the step.
 // d9 is returned to every lane of the group.  Returns false if a pivot check failed (landmark-only form).
+template <int K>
+__device__ __forceinline__ void step_blockdiag6_pivots(double (&a)[6], double d0, int l16, bool& ok) {
+    if constexpr (K < 6) {
+        const double piv = bcast_row16<K>(a[K]);
+        if (l16 == K && !(piv > 1e-10 * d0)) ok = false;
+        const double inv = step_fast_rcp(piv);
+        double f[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) f[r] = (r != K) ? bcast_row16<K>(a[r]) : 0.0;
+        a[K] *= inv;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            if (r != K) a[r] -= f[r] * a[K];
+        step_blockdiag6_pivots<K + 1>(a, d0, l16, ok);
+    }
+}
+
 __device__ __forceinline__ bool step_blockdiag6_group(const double* H, const double* b, double inv_wmax, double lam32, int l16,
                                                       int gbase, double* d9) {
     double a[6];
@@ -96,22 +113,12 @@ __device__ __forceinline__ bool step_blockdiag6_group(const double* H, const dou
     double d0 = 0.0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) d0 = (r == c) ? a[r] : d0;
+    // (the 16 lanes of a group are a DPP row: bcast_row16<K> is one move per half where __shfl is an LDS crossbar round trip)
     bool ok = true;
+    step_blockdiag6_pivots<0>(a, d0, l16, ok);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double piv = __shfl(a[k], gbase + k, kWave);
-        if (l16 == k && !(piv > 1e-10 * d0)) ok = false;
-        const double inv = step_fast_rcp(piv);
-        double f[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) f[r] = (r != k) ? __shfl(a[r], gbase + k, kWave) : 0.0;
-        a[k] *= inv;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-            if (r != k) a[r] -= f[r] * a[k];
-    }
-#pragma unroll
-    for (int r = 0; r < 9; ++r) d9[r] = r < 6 ? __shfl(a[r], gbase + 6, kWave) : 0.0;
+    for (int r = 0; r < 9; ++r) d9[r] = r < 6 ? bcast_row16<6>(a[r]) : 0.0;
+    (void)gbase;
     return ok;
 }
 
@@ -133,8 +140,10 @@ __device__ __forceinline__ void step_recover_group(int i, int n, int s, const do
             v -= so[(1 + k) * 9 + r] * xl + so[(10 + k) * 9 + r] * xr;
         }
     }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) d9[q] = __shfl(v, gbase + q, kWave);
+    d9[0] = bcast_row16<0>(v); d9[1] = bcast_row16<1>(v); d9[2] = bcast_row16<2>(v);
+    d9[3] = bcast_row16<3>(v); d9[4] = bcast_row16<4>(v); d9[5] = bcast_row16<5>(v);
+    d9[6] = bcast_row16<6>(v); d9[7] = bcast_row16<7>(v); d9[8] = bcast_row16<8>(v);
+    (void)gbase;
 }
 
 // The trial state of pose i of window w (BA_filtering.py:55-60), formed by a 16-lane group: MODE 1 landmark-only 6x6 solve,
