@@ -89,6 +89,7 @@ struct vba_context {
     int warm_enabled = 1;           // carried keys are selected with the one-pass warm select (vba_set_warm_select; 2: forced misses, test knob)
     int last_iter = 0, last_init = 0;
     int sh_pivot = 0;                       // sharded mode: solver variant of the current call (0 unpivoted, 2 mixed after a failed check)
+    bool sh_rode = false, sh_bands_ready = false;   // sharded mode: the dynamics factor rode in the accumulation; bands / rhs are in memory
     int pack_min = 1 << 30;                 // windows from which three chains share a wavefront: never by default (measured at 1024 / 2048 / 4096
                                             // windows: one wave per window is as fast or faster, 1.52 / 1.96 / 2.70 ms vs 1.52 / 2.06 / 2.78 ms per solve);
                                             // vba_set_solver(h, -3) packs from 3 windows on
@@ -1583,10 +1584,12 @@ static void sharded_view(vba_handle h, DevView& V) {
     CallSpec c;
     c.iter = h->last_iter; c.initialize = h->last_init; c.call = -1; c.par = h->par;
     view_for_call(h, V, c);
-    V.lat = 0;
+    // Since round 3 the pose-chain part of a sharded call uses the latency-mode kernels of the handle (one window): the
+    // dynamics factor rides in the accumulation's grid, the chunk elimination forms its own blocks, the trial kernel forms
+    // the step (no assembly / recovery launches; the landmark-only phase has no solve launch at all).  What stays classic
+    // is everything keyed to the exchanges: keys recomputed per call, exact select over the gathered keys, every accept
+    // test a launch of its own on the gathered sums.
     V.fuse_walk = 0;
-    V.fused_trial = 0;
-    V.nblk_dyn = h->V.nblk_dyn;
     V.m_total = h->V.m_total;
 }
 
@@ -1624,6 +1627,9 @@ int vba_sh_stage2(vba_handle h, const double* d_abs_all, int64_t count_all, doub
     V.abs_all = d_abs_all;
     V.abs_all_count = count_all;
     launch_select(V, true, s);          // digit 0 over the gathered keys as well
+    // the dynamics factor is a function of the states only: its blocks ride in this grid
+    h->sh_rode = !h->last_init && V.lat;
+    V.dyn_in_acc = h->sh_rode ? 1 : 0;
     launch_obs_accumulate(V, s);
     launch_shard_pack(V, d_partial_local, s);
     HIPCHK(hipGetLastError());
@@ -1635,20 +1641,30 @@ int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* 
     if (h->V.m_total < 1) return fail(VBA_ESTATE, "stage1 has not run");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    DevView V;
-    sharded_view(h, V);
+    CallSpec c;
+    c.iter = h->last_iter; c.initialize = h->last_init; c.call = -1; c.par = h->par;
+    CallCtx C;
+    sharded_view(h, C.V);
+    DevView& V = C.V;
+    const bool init = h->last_init != 0;
     if (d_partial_all) {    // first trial of this call; NULL = another LM trial on the same system
         if (ranks < 1) return fail(VBA_EINVAL, "ranks must be >= 1");
         launch_shard_reduce(V, d_partial_all, ranks, s);
-        if (!h->last_init) launch_dynamics(V, s);
-        launch_assemble(V, 0, s);
+        if (!init && !h->sh_rode) launch_dynamics(V, s);
+        // who reads the bands from memory?  Nobody when the trial kernel solves the 6x6 systems itself (landmark-only) or
+        // the chunk elimination forms its own blocks (full phase)
+        const bool need_bands = init ? V.fused_trial != 1 : !solve_forms_blocks(V);
+        if (need_bands) launch_assemble(V, 0, s);
+        h->sh_bands_ready = need_bands;
+        // every rank holds bit-identical systems (rank-ordered reductions), so the checked unpivoted path and its
+        // fallback are taken by all ranks alike: stage4 reports the failed check and the caller's loop repeats stage3
+        h->sh_pivot = h->pivot_mode;
     }
-    // every rank holds bit-identical systems (rank-ordered reductions), so the checked unpivoted path and its
-    // fallback are taken by all ranks alike: stage4 reports the failed check and the caller's loop repeats stage3
-    if (d_partial_all) h->sh_pivot = h->pivot_mode;
     V.pivot = h->sh_pivot;
-    launch_solve(V, h->last_init, s);
-    launch_trial(V, s);
+    C.fuse_assemble = false;
+    C.assembled = C.bands_ready = h->sh_bands_ready;
+    enqueue_trial(h, C, c, d_partial_all != nullptr);
+    h->sh_bands_ready = C.bands_ready;      // (a pivoted repeat of a landmark-only trial assembles the blocks it reads)
     launch_shard_trial_sum(V, d_trial_local, s);
     HIPCHK(hipGetLastError());
     return VBA_OK;
