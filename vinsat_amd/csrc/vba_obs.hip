@@ -721,7 +721,11 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     PoseCam pc{};
     int beg = 0, end = 0;
     Obs ring[kAccDepth]{};
-    Obs2 nxt{};
+    Obs2 nxt{}, nxt2{};
+#ifndef VBA_ACC_PAIR_DEPTH
+#define VBA_ACC_PAIR_DEPTH 1
+#endif
+    constexpr bool kPairDepth2 = BATCH && PAIR && VBA_ACC_PAIR_DEPTH == 2;     // two pairs in flight per lane (24 more VGPRs)
     if (i < n) {
         pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
         const int* ptr = V.pose_ptr + 2 * ob;
@@ -734,6 +738,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
         }
         if (PAIR) {
             if (beg + 2 * sub < end) nxt = load2(beg + 2 * sub);
+            if (kPairDepth2 && beg + 2 * sub + 2 * G < end) nxt2 = load2(beg + 2 * sub + 2 * G);
         } else {
 #pragma unroll
             for (int d = 0; d < kAccDepth; ++d)
@@ -856,7 +861,10 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             while (k < end) {
                 const int kn = k + 2 * G;
                 const Obs2 cur = nxt;
-                if (kn < end) nxt = load2(kn);
+                if (kPairDepth2) {
+                    nxt = nxt2;
+                    if (kn + 2 * G < end) nxt2 = load2(kn + 2 * G);
+                } else if (kn < end) nxt = load2(kn);
                 process(cur.x.a, cur.y.a, cur.z.a, cur.u.a, cur.v.a, cur.c.a, k);
                 if (k + 1 < end) process(cur.x.b, cur.y.b, cur.z.b, cur.u.b, cur.v.b, cur.c.b, k + 1);
                 k = kn;
