@@ -166,6 +166,13 @@ int vba_set_bucket_cap(vba_handle h, int cap);
  *          ~600 instructions per thread there), on par at 4096 windows (1.77 vs 1.85 ms).
  *   bit 4: only ONE cyclic-reduction level of the reduced system runs on its own CUs in front of the one-workgroup kernel
  *          (k_cr_level0) instead of two (k_cr_level01, default).  Same bits; 0.9 us per call slower.  Comparison / tests.
+ *   bit 5: (latency mode, partitioned solve with two split-off levels) chunk elimination and the two cyclic-reduction levels
+ *          run as ONE grid (k_solve_resident): the consumer blocks are resident from the start and wait for their producers
+ *          on flags in device memory -- bounded: a consumer that gives up flags its window and the call returns VBA_ESTATE.
+ *   bit 6: ... and the one-workgroup tail as well (one launch for the whole solve).
+ *          Same bits as three launches.  Measured SLOWER (C3, one window: +2.5 and +6.5 us per call): a hop over a flag is two
+ *          round trips to device memory plus the write-back / invalidate of the per-XCD L2s, 4.7 us from the last producer's
+ *          last store to the consumer's first load, against ~3.2 us for a kernel boundary.  Comparison / tests only.
  * Default 15 (bits 0 .. 3).  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
  * formed by 16 lanes together (formed redundantly by every thread it was 6 us SLOWER: instruction issue of a single wave
  * is the time in this mode); bit 1, see above (48.0 against 49.1 us per call).  All masks are covered by the parity tests. */

@@ -1434,3 +1434,58 @@ def test_two_cyclic_reduction_levels_in_front_give_the_bits_of_one(chunk):
         a, b = outs
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[0][0], b[0][0]) and a[0][1] == b[0][1] and a[0][3] == b[0][3], (chunk, pivot)
         assert np.isfinite(a[1]).all() and np.abs(a[1]).max() > 0
+
+
+@pytest.mark.parametrize("chunk", [4, 6, 8])
+def test_resident_solve_gives_the_bits_of_three_launches(chunk):
+    """vba_set_fusion bits 5 / 6 (k_solve_resident): chunk elimination, the two split-off cyclic-reduction levels and -- bit 6
+    -- the one-workgroup tail as ONE grid whose consumer blocks wait for their producers on flags.  The same bodies run, so
+    the bits are those of the three launches, unpivoted and pivoted; and every block publishes its flag whatever it did, so a
+    handle whose windows differ in length (one of them below the size from which the levels are split off at all, one
+    that finishes its schedule early... none may leave a consumer waiting) comes back with the same bits too.  Not the
+    default: a hop over a flag measured slower than a kernel boundary."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    cfg = synth.WindowConfig("res", 300, 20, 5)
+    win = od_pipe.prepare_window(*synth.make_sequence(cfg, seed=11))
+    n, m = win.time_idx.size, win.ii.size
+    st0 = od_pipe.initial_guess(win, seed=11)
+    iters, inits = [9, 10, 11, 12, 13], [True, False, False, False, False]
+    for pivot in (False, True):
+        outs = []
+        for mask in (15, 15 + 32, 15 + 64):
+            e = BAEngine(n, m)
+            e.set_solver(chunk, -1)
+            e.set_pivoting(pivot)
+            e.set_fusion(mask)
+            e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+            e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+            e.set_states(st0, 1e-4)
+            e.run_schedule(iters, inits)
+            outs.append((e.get_states(), e.debug("dpose")))
+            e.close()
+        for b in outs[1:]:
+            a = outs[0]
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[0][0], b[0][0]) and a[0][1] == b[0][1] and a[0][3] == b[0][3], (chunk, pivot)
+        assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).max() > 0
+    if chunk != 8:
+        return
+    # windows of 300, 120 (14 separators: the one-workgroup variant) and 260 poses in one handle
+    cfgs = [synth.WindowConfig("r0", 300, 20, 5), synth.WindowConfig("r1", 120, 20, 5), synth.WindowConfig("r2", 260, 20, 5)]
+    wins = [od_pipe.prepare_window(*synth.make_sequence(c, seed=20 + k)) for k, c in enumerate(cfgs)]
+    n_max, m_max = max(w.time_idx.size for w in wins), max(w.ii.size for w in wins)
+    iters, inits = list(range(6, 16)), [k < 10 for k in range(6, 16)]
+    got = []
+    for mask in (15, 15 + 32, 15 + 64):
+        e = BAEngine(n_max, m_max, windows=3)
+        e.set_fusion(mask)
+        for k, w in enumerate(wins):
+            e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, w.time_idx.size, window=k)
+            e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx, window=k)
+            e.set_states(od_pipe.initial_guess(w, seed=k), 1e-4, window=k)
+        e.run_schedule(iters, inits)
+        got.append([e.get_states(window=k) for k in range(3)])
+        e.close()
+    for b in got[1:]:
+        for k in range(3):
+            assert np.array_equal(got[0][k][0], b[k][0]) and got[0][k][1] == b[k][1] and got[0][k][3] == b[k][3], k

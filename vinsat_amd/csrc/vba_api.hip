@@ -146,6 +146,9 @@ int check_window(vba_handle h, int window) {
 // k_decide wrote the outcome of the trial into mapped host memory; waiting for the stream is all that is needed
 int read_heads(vba_handle h) {
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (int w = 0; w < h->W; ++w)
+        if (h->h_head[w].flags & 64u)       // k_solve_resident: a consumer block gave up waiting for its producers
+            return fail(VBA_ESTATE, "resident solve: a block of window " + std::to_string(w) + " timed out waiting for its producers (vba_set_fusion bits 5, 6)");
     return VBA_OK;
 }
 
@@ -267,6 +270,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     need(W * N * 171 * 8);
     need(W * N * (171 + 171 + 81 + 9 + 9) * 8 + 6 * 256);
     need(W * N * (171 * 3 + 9) * 8 + 6 * 256);              // second level (over-sized: p_max <= n_max / 2 + 1)
+    need(W * (N + 8) * 4);                                  // flags of the resident solve (over-sized: chunks + groups + 1 <= n_max / 2 + 8)
     bytes += 1 << 16;
     if (hipMalloc(&h->arena.base, bytes) != hipSuccess) {
         delete h;
@@ -324,6 +328,9 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.rXs = A.take<double>(W * PM * 81); V.rzs = A.take<double>(W * PM * 9); V.rx = A.take<double>(W * PM * 9);
     V.csol2 = A.take<double>(W * PM * 171); V.cL2 = A.take<double>(W * PM * 171); V.cR2 = A.take<double>(W * PM * 171);
     V.rx2 = A.take<double>(W * PM * 9);
+    V.res_stride = n_max + 8;
+    V.res_flags = A.take<unsigned>(W * (N + 8));
+    V.resident = 0;
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
     V.hop = 0; V.pivot = 0; V.call = -1; V.emit = 0; V.carry = 0; V.dyn_in_acc = 0;
     V.par = 0; V.fold = 0; V.redo = 0; V.fused_trial = 0; V.pending_only = 0; V.warm_force_miss = 0;
@@ -337,7 +344,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
                               V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.prior_H, V.prior_x, V.absr, V.wraw, V.ckeys, V.part_init, V.part_next,
                               V.part_pred, V.part_prior, V.lastD,
                               V.part_trial, V.hist, V.Hraw, V.braw, V.xhat, V.Phi, V.rorb, V.fatt, V.qgrad, V.Hd, V.Hu, V.Hl,
-                              V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx, V.csol2, V.cL2, V.cR2, V.rx2};
+                              V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx, V.csol2, V.cL2, V.cR2, V.rx2, V.res_flags};
         bool ok = A.used <= A.size;
         for (const void* q : must) ok = ok && q != nullptr;
         if (!ok) {
@@ -497,7 +504,7 @@ int vba_set_key_carry(vba_handle h, int on) {
 int vba_set_fusion(vba_handle h, int mask) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
-    if (mask < 0 || mask > 31) return fail(VBA_EINVAL, "mask must be in [0, 31]");
+    if (mask < 0 || mask > 127) return fail(VBA_EINVAL, "mask must be in [0, 127]");
     h->fusion = mask;
     return VBA_OK;
 }
@@ -859,6 +866,7 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
         V.nblk_dyn = (V.n_max - 1 + 14) / 15;
     }
     V.fuse_blocks = (h->fusion & 2) ? 1 : 0;
+    V.resident = !V.lat ? 0 : (h->fusion & 64) ? 2 : (h->fusion & 32) ? 1 : 0;
     V.chunk_waves = h->chunk_waves;
     V.asm_rows = (h->fusion & 8) ? 1 : 0;
     V.cr_levels = (h->fusion & 16) ? 1 : 2;
@@ -1469,6 +1477,10 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
     double wmax;
     std::memcpy(&wmax, &sc.wmax_bits[V.par], 8);
     switch (what) {
+#ifdef VBA_RESIDENT_STAMPS
+        case 100:           // diagnostic build: the wall-clock stamps of the last k_solve_resident launch (raw 64-bit words)
+            return copy(V.cR2 + (size_t)window * V.res_stride * 4, (int64_t)V.res_stride * 4);
+#endif
         case VBA_DBG_EST:
         case VBA_DBG_WEIGHT:
         case VBA_DBG_JG: {

@@ -107,6 +107,10 @@ struct DevView {
     int redo;                       // 1: this launch repeats the call for the windows whose warm select missed (sc.miss), others skip
     int lat;                        // latency mode (few windows): fused kernels, see vba_api.hip
     int fuse_blocks;                // latency mode: the chunk elimination forms the blocks of its chunk itself (vba_set_fusion bit 1)
+    int resident;                   // latency mode: the solve is one grid of producer and waiting consumer blocks (k_solve_resident;
+                                    // vba_set_fusion bit 5: chunks + cyclic-reduction groups, bit 6: + the one-workgroup tail)
+    int res_stride;                 // flags per window
+    unsigned* res_flags;            // [W][res_stride] epoch of the launch that last completed the block
     double* wbucket;                // [W][2 (parity)][kSelBins][bucket_cap] carried keys by warm bin (latency mode; null: none)
     int bucket_cap;
     int median_ready;               // many windows: k_select_finish has left the median in sc.c_obs

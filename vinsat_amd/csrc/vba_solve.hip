@@ -26,6 +26,8 @@
 //                      middle), the reduced system by block cyclic reduction -- k_cr_level01 (first two levels, one
 //                      workgroup per four separators) and k_solve_reduced_cr (the rest in one workgroup) -- and the
 //                      recovery inside the trial kernel (vba_step.h).
+#include <atomic>
+
 #include "vba_asm.h"
 #include "vba_asm_fast.h"
 #include "vba_decide.h"
@@ -1579,10 +1581,8 @@ __host__ __device__ constexpr int twosided_fused_lds_doubles(int s, bool reg) {
 }
 
 template <bool PIVOT, bool REG>
-__global__ __launch_bounds__(256) void k_solve_chunks_ts_fused(DevView V, int s) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void chunks_ts_fused_body(const DevView& V, int s, int w, int c, double* smem) {
     constexpr int kAsmIn = kAsmBase + (REG ? kAsmPrior : 0);
-    const int w = blockIdx.y, c = blockIdx.x;
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
@@ -1665,6 +1665,12 @@ __global__ __launch_bounds__(256) void k_solve_chunks_ts_fused(DevView V, int s)
     const LdsBlockSource src{blocks, j0};
     chunk_eliminate_twosided<PIVOT, true>(src, n, s, c, lam32, V.csol + sb * 171, V.cL + rb * 171, V.cR + rb * 171, elim, tid, bad);
     report_pivot<PIVOT>(bad, sc, tid & 63, V.par);
+}
+
+template <bool PIVOT, bool REG>
+__global__ __launch_bounds__(256) void k_solve_chunks_ts_fused(DevView V, int s) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    chunks_ts_fused_body<PIVOT, REG>(V, s, blockIdx.y, blockIdx.x, smem);
 }
 
 // level 2: the reduced system over the level-1 separators is itself cut into chunks of s2
@@ -1934,9 +1940,7 @@ __global__ __launch_bounds__(128) void k_cr_level0(DevView V, int s) {
 // instead of communication.  In the one-workgroup kernel the first level ran 16 eliminations on the four SIMDs of one CU
 // (5.8 us, issue-bound at four waves per SIMD) -- here they are spread over 16 CUs and that kernel starts from 15 blocks.
 template <bool PIVOT>
-__global__ __launch_bounds__(256) void k_cr_level01(DevView V, int s) {
-    __shared__ __attribute__((aligned(16))) double blk[7 * 252];
-    const int w = blockIdx.y, t = blockIdx.x;
+__device__ __forceinline__ void cr_level01_body(const DevView& V, int s, int w, int t, double* blk) {
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
@@ -1985,13 +1989,17 @@ __global__ __launch_bounds__(256) void k_cr_level01(DevView V, int s) {
     report_pivot<PIVOT>(bad, sc, lane, V.par);
 }
 
+template <bool PIVOT>
+__global__ __launch_bounds__(256) void k_cr_level01(DevView V, int s) {
+    __shared__ __attribute__((aligned(16))) double blk[7 * 252];
+    cr_level01_body<PIVOT>(V, s, blockIdx.y, blockIdx.x, blk);
+}
+
 // PRE: the first level has been done by k_cr_level0; this kernel continues with the n1 / 2 folded blocks and finishes
 // with the back substitution of the level-0 blocks.
 // PRE 2: the first two levels have been done by k_cr_level01; the system solved here is over the separators 4b + 3.
-template <bool PIVOT, int PRE>
-__global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int s) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int w = blockIdx.x;
+template <bool PIVOT, int PRE, int kCrThreads>
+__device__ __forceinline__ void reduced_cr_body(const DevView& V, int s, int w, double* smem) {
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
@@ -2142,6 +2150,96 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
         }
     }
     report_pivot<PIVOT>(bad, sc, lane, V.par);
+}
+
+template <bool PIVOT, int PRE>
+__global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int s) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    reduced_cr_body<PIVOT, PRE, kCrThreads>(V, s, blockIdx.x, smem);
+}
+
+// ------------------------------------------------------------------------------------------------ resident solve
+// The three launches of the latency-mode solve (chunk elimination -> cyclic-reduction levels 0 + 1 -> the remaining levels
+// in one workgroup) as ONE grid whose consumer blocks are resident from the start and wait for their producers on flags
+// (vba_set_fusion bit 5).  Block x of window y is
+//   x <  P          : chunk x                        (produces flag x)
+//   x <  P + G      : cyclic-reduction group x - P   (waits for chunks 4t .. 4t + 7, produces flag x)
+//   x == P + G      : the one-workgroup tail         (TAIL; waits for all groups)
+// The grid (at C3: 63 + 16 + 1 blocks) is far below what the 256 CUs hold at once and blocks are dispatched in index order, so
+// every producer is running or done when a consumer starts to wait.  A flag holds the EPOCH of the launch that wrote it
+// (a counter the host increments per launch, so nothing is ever reset) and is stored by the last wave of the block to get
+// there, EVERY wave passing through resident_publish whatever path it took through its role (windows that skip the call,
+// short windows, a failed pivot check) -- a consumer can therefore never wait for a block that has nothing to say.  The
+// wait is bounded all the same: kResidentSpins polls (> 100 ms) and the window is flagged (fl bit 64 -> VBA_ESTATE).
+// Same bodies, same operations, same bits as the three launches.
+constexpr int kResidentSpins = 1 << 18;      // polls; one is a round trip to memory, ~1 us
+
+__device__ __forceinline__ void resident_publish(unsigned* flag, unsigned epoch, unsigned* lds_count, int nwaves) {
+    __threadfence();            // this wave's stores are visible device-wide before it is counted
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned before = atomicAdd(lds_count, 1u);
+        // (relaxed: the fences above have released every wave's stores; a release store would write the L2 back once more)
+        if (before == (unsigned)nwaves - 1u) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// every wave waits by itself: lane l < count watches flags[first + l]; false when the bound was hit
+__device__ __forceinline__ bool resident_wait(const unsigned* flags, int first, int count, unsigned epoch) {
+    const int lane = threadIdx.x & 63;
+    bool ok = true;
+    for (int base = 0; base < count; base += 64) {
+        const bool mine = base + lane < count;
+        const unsigned* f = flags + first + (mine ? base + lane : 0);
+        int spins = 0;
+        for (;;) {
+            const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool there = !mine || (int)(v - epoch) >= 0;
+            if (__all(there)) break;
+            if (++spins > kResidentSpins) { ok = false; break; }
+        }
+        if (!ok) break;
+    }
+    __threadfence();            // acquire: nothing read below is older than the flags
+    return ok;
+}
+
+template <bool PIVOT, bool REG, bool TAIL>
+__global__ __launch_bounds__(TAIL ? 512 : 256) void k_solve_resident(DevView V, int s, int P, int G, unsigned epoch) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ unsigned arrived;
+    constexpr int kThreads = TAIL ? 512 : 256;
+    const int w = blockIdx.y, x = blockIdx.x, tid = threadIdx.x;
+    unsigned* flags = V.res_flags + (size_t)w * V.res_stride;
+    if (tid == 0) arrived = 0u;
+#ifdef VBA_RESIDENT_STAMPS
+    // diagnostic build: 100 MHz wall clock at entry / after the wait / after the body / after the publish, wave 0 of every block
+    unsigned long long* stamp = reinterpret_cast<unsigned long long*>(V.cR2) + ((size_t)w * V.res_stride + x) * 4;
+#define VBA_RSTAMP(k) do { if (tid == 0) stamp[k] = wall_clock64(); } while (0)
+#else
+#define VBA_RSTAMP(k) do {} while (0)
+#endif
+    VBA_RSTAMP(0);
+    __syncthreads();
+    if (x < P) {
+        VBA_RSTAMP(1);
+        if (tid < 256) chunks_ts_fused_body<PIVOT, REG>(V, s, w, x, smem);
+    } else if (x < P + G) {
+        const int t = x - P;
+        if (tid < 256) {
+            const int first = 4 * t, last = 4 * t + 7 < P - 1 ? 4 * t + 7 : P - 1;
+            if (!resident_wait(flags, first, last - first + 1, epoch) && (tid & 63) == 0) atomicOr(&V.sc[w].fl[V.par], 2u | 64u);
+            VBA_RSTAMP(1);
+            cr_level01_body<PIVOT>(V, s, w, t, smem);
+        }
+    } else if (TAIL) {
+        if (!resident_wait(flags, P, G, epoch) && (tid & 63) == 0) atomicOr(&V.sc[w].fl[V.par], 2u | 64u);
+        VBA_RSTAMP(1);
+        reduced_cr_body<PIVOT, 2, kThreads>(V, s, w, smem);
+    }
+    VBA_RSTAMP(2);
+    resident_publish(flags + x, epoch, &arrived, kThreads / 64);
+    VBA_RSTAMP(3);
+#undef VBA_RSTAMP
 }
 
 // Recovery of a partitioned chain: x_i = yhat_i - Vhat_i x_left - What_i x_right for interior blocks, separators
@@ -2376,6 +2474,8 @@ bool solve_forms_blocks(const DevView& V) {
     return walk_forms_blocks(V) || (V.lat && V.fuse_blocks && !V.prm.initialize && V.chunk >= 2 && V.chunk <= kFusedChunkMax);
 }
 
+static std::atomic<unsigned> g_resident_epoch{0u};    // flags of k_solve_resident: one value per launch, process wide
+
 template <bool PIVOT>
 static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s) {
     if (initialize) {       // block diagonal: independent poses
@@ -2400,6 +2500,33 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
     const int cs = V.chunk, cs2 = V.chunk2;
     const int P = (V.n_max + cs - 1) / cs;
     const size_t lds = (512 + (size_t)cs * 252 + 162) * sizeof(double);
+    const int n0_all = P - 1;
+    const bool resident = V.resident && solve_forms_blocks(V) && V.chunk_waves == 2 && cs >= 4 && cs2 < 0 && V.cr_levels == 2 &&
+                          n0_all >= kCrSplitMin && n0_all <= 4 * kCrMax;
+    if (resident) {
+        // one grid: chunks, cyclic-reduction groups and (V.resident == 2) the one-workgroup tail, see k_solve_resident
+        const bool reg = V.reg != 0, tail = V.resident == 2;
+        const int G = (n0_all + 3) / 4;
+        size_t lds_all = (size_t)twosided_fused_lds_doubles(cs, reg) * sizeof(double);
+        if (lds_all < 7 * 252 * sizeof(double)) lds_all = 7 * 252 * sizeof(double);
+        const size_t lds_tail = ((size_t)(n0_all / 4) * 252 + (size_t)((n0_all + 3) / 4) * 9) * sizeof(double);
+        if (tail && lds_all < lds_tail) lds_all = lds_tail;
+        const unsigned epoch = ++g_resident_epoch;
+        const dim3 grid(P + G + (tail ? 1 : 0), V.W);
+        if (tail) {
+            if (reg) hipLaunchKernelGGL((k_solve_resident<PIVOT, true, true>), grid, dim3(512), lds_all, s, V, cs, P, G, epoch);
+            else hipLaunchKernelGGL((k_solve_resident<PIVOT, false, true>), grid, dim3(512), lds_all, s, V, cs, P, G, epoch);
+        } else {
+            if (reg) hipLaunchKernelGGL((k_solve_resident<PIVOT, true, false>), grid, dim3(256), lds_all, s, V, cs, P, G, epoch);
+            else hipLaunchKernelGGL((k_solve_resident<PIVOT, false, false>), grid, dim3(256), lds_all, s, V, cs, P, G, epoch);
+            hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, 2>), dim3(V.W), dim3(kCrThreads),
+                               ((size_t)(n0_all / 4) * 252 + (size_t)((n0_all + 3) / 4) * 9) * sizeof(double), s, V, cs);
+        }
+        const int n0_min = (V.n_min + cs - 1) / cs - 1;
+        if (n0_min < kCrSplitMin)       // short windows of the handle: the one-workgroup variant as before
+            hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, 0>), dim3(V.W), dim3(kCrThreads), (size_t)(kCrSplitMin - 1) * 252 * sizeof(double), s, V, cs);
+        return;
+    }
     if (solve_forms_blocks(V) && V.chunk_waves == 2 && cs >= 4) {
         const bool reg = V.reg != 0;
         const size_t ldsf = (size_t)twosided_fused_lds_doubles(cs, reg) * sizeof(double);
@@ -2447,6 +2574,8 @@ hipError_t configure_solver_device() {
     const int cap = (int)((512 + 60 * 252 + 162) * sizeof(double));     // chunks above ~30 poses exceed the default 64 KiB
     const int cap_cr = kCrMax * 252 * (int)sizeof(double);
     const int cap_f = (int)((512 + kFusedChunkMax * 252 + 162 + (kFusedChunkMax + 1) * 252 + (kFusedChunkMax + 2) * (kAsmBase + kAsmPrior)) * sizeof(double));
+    const int cap_ts = twosided_fused_lds_doubles(kFusedChunkMax, true) * 8;
+    const int cap_res = cap_ts > cap_cr + 65 * 9 * 8 ? cap_ts : cap_cr + 65 * 9 * 8;
     const struct { const void* fn; int bytes; } set[] = {
         {reinterpret_cast<const void*>(k_solve_chunks_fused<false, false>), cap_f}, {reinterpret_cast<const void*>(k_solve_chunks_fused<true, false>), cap_f},
         {reinterpret_cast<const void*>(k_solve_chunks_fused<false, true>), cap_f}, {reinterpret_cast<const void*>(k_solve_chunks_fused<true, true>), cap_f},
@@ -2459,7 +2588,11 @@ hipError_t configure_solver_device() {
         {reinterpret_cast<const void*>(k_solve_chunks2<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks2<true>), cap},
         {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 0>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 0>), cap_cr},
         {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 1>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 1>), cap_cr},
-        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 2>), cap_cr + 65 * 9 * 8}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 2>), cap_cr + 65 * 9 * 8}};
+        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 2>), cap_cr + 65 * 9 * 8}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 2>), cap_cr + 65 * 9 * 8},
+        {reinterpret_cast<const void*>(k_solve_resident<false, false, false>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, false, false>), cap_res},
+        {reinterpret_cast<const void*>(k_solve_resident<false, true, false>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, true, false>), cap_res},
+        {reinterpret_cast<const void*>(k_solve_resident<false, false, true>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, false, true>), cap_res},
+        {reinterpret_cast<const void*>(k_solve_resident<false, true, true>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, true, true>), cap_res}};
     for (const auto& e : set) {
         const hipError_t rc = hipFuncSetAttribute(e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, e.bytes);
         if (rc != hipSuccess) return rc;

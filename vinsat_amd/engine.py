@@ -70,7 +70,8 @@ class BAEngine:
         _lib.check(self.lib.vba_set_key_carry(self.h, int(bool(on))), self.lib)
 
     def set_fusion(self, mask):
-        """Latency-mode kernel fusion (bit 0: step inside the trial kernel, bit 1: blocks formed inside the chunk elimination)."""
+        """Kernel fusion mask (include/vinsat_ba.h: bit 0 step inside the trial kernel, bit 1 blocks formed inside the chunk
+        elimination, ... bits 5 / 6 the solve as one grid of waiting blocks -- measured slower, comparison only)."""
         _lib.check(self.lib.vba_set_fusion(self.h, int(mask)), self.lib)
 
     def set_chunk_waves(self, waves):
