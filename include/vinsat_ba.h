@@ -289,6 +289,21 @@ int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* 
 /* stage 4: accept test on the gathered trial sums (2 doubles per rank); *done = 1 when the LM loop ended
  * (states/lamda updated).  Synchronous. */
 int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done);
+/* The same protocol with the three exchanges issued by the LIBRARY: RCCL all-gathers on the handle's stream between the
+ * stage kernels -- one host call per BA() call and one host synchronisation per LM trial instead of four stage calls and
+ * three collectives dispatched by the caller.  RCCL is resolved at run time from `rccl_path` (a process that also uses
+ * torch.distributed names the copy it has loaded already; /opt/rocm/lib/librccl.so otherwise); libvinsat_ba.so itself does
+ * not link it.
+ *   vba_sh_unique_id: rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means;
+ *   vba_sh_comm_init: every rank of the window joins (ncclCommInitRank: collective, returns when all have);
+ *   vba_sh_call:      one BA() call (BA_filtering.py:4-98) on the sharded window: stage1 .. stage4 with the all-gathers of
+ *                     |r| keys (+inf padded slots of ceil(m_total / ranks) rows), partial normal equations and trial sums
+ *                     in between; this rank's rows (vba_upload_observations) must number at most ceil(m_total / ranks);
+ *   vba_sh_comm_destroy: leaves the communicator (vba_destroy does it as well). */
+int vba_sh_unique_id(const char* rccl_path, void* id128);
+int vba_sh_comm_init(vba_handle h, const char* rccl_path, const void* id128, int nranks, int rank);
+int vba_sh_call(vba_handle h, int iter, int initialize, int64_t m_total, int* n_trials);
+int vba_sh_comm_destroy(vba_handle h);
 
 /* ---- free-landmark Schur-complement BA: ADD-ON, PARITY UNPINNED ------------------------------------------
  * The reference keeps its landmarks fixed (BA_filtering.py:32-37) and has nothing to marginalise; this mode is the

@@ -1,0 +1,88 @@
+"""Observation-sharded mode with the exchanges issued by the LIBRARY (vba_sh_comm_init / vba_sh_call: RCCL all-gathers on
+the handle's stream, RCCL resolved at run time from the copy torch has loaded).  A one-GPU box can give RCCL one rank only
+(one device per rank), so this runs the whole native path -- unique id over a gloo control group, communicator, padded
+slots, three all-gathers per LM round -- at world size 1, against the caller-dispatched protocol (same kernels, torch's
+all_gather_into_tensor) bit for bit, the unsharded engine and the oracle.  What N ranks add is RCCL's own business: the
+buffers, counts and order of the three ncclAllGather calls are those of all_gather_into_tensor in vinsat_amd/dist.py, which
+the gloo tests (world 2, 3) and the two-process GPU test cover."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from conftest import golden_inputs, load_golden
+    from oracle import ba_oracle as O
+    from vinsat_amd.dist import HipStageEngine, ShardedBA, loaded_rccl_path
+    from vinsat_amd.engine import BAEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        assert "librccl" in loaded_rccl_path()
+        g = load_golden("c2")
+        inp = golden_inputs(g)
+        n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+        conf = inp["conf"].copy()
+        conf[:] = 3.0                        # the LM loop rejects trials: several rounds (and all-gathers) per call
+
+        def make(native):
+            eng = BAEngine(n, m)
+            eng.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
+            eng.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+            stage = HipStageEngine(eng, torch_stream=not native)
+            if native:
+                stage.attach_rccl(dist)
+            else:
+                nccl = dist.new_group(backend="nccl", device_id=torch.device("cuda", 0))
+                return ShardedBA(stage, n, m, m, group=nccl)
+            return ShardedBA(stage, n, m, m)
+
+        a, b = make(True), make(False)
+        assert a.engine.native and not b.engine.native
+        single = BAEngine(n, m)
+        single.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
+        single.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+        st, lam = g["states0"][0], 1e-4
+        a.set_states(st, lam)
+        b.set_states(st, lam)
+        ref, lam_ref, sg, lam_g = st.copy(), lam, st.copy(), lam
+        rounds = []
+        for it, init in [(0, True), (1, True), (2, True), (5, True), (10, False), (11, False), (12, False), (13, False)]:
+            na, nb = a.step(it, init), b.step(it, init)
+            sa, sb = a.get_states(), b.get_states()
+            assert na == nb and np.array_equal(sa[0], sb[0]) and sa[1] == sb[1] and sa[3] == sb[3], it     # same kernels, another dispatcher
+            ref, lam_ref, _, ntr_ref = O.ba_iteration(it, ref, inp["cumrot"], inp["uv"], inp["xyz"], inp["ii"], inp["time_idx"], inp["K"], conf,
+                                                      lam_ref, initialize=init)
+            assert sa[3] == ntr_ref and sa[1] == lam_ref and np.abs(sa[0] - ref).max() / np.abs(ref).max() < 1e-7
+            sg, lam_g, _, ntr_g, _ = single.iterate(it, init, lam_g, sg)
+            assert ntr_g == sa[3] and lam_g == sa[1] and np.abs(sa[0] - sg).max() / np.abs(sg).max() < 1e-9
+            rounds.append(na)
+        np.save(os.path.join(tmp, "rounds.npy"), np.array(rounds))
+        # a second communicator on a handle is refused; a call without one as well
+        with pytest.raises(Exception):
+            a.engine.attach_rccl(dist)
+        with pytest.raises(Exception):
+            b.engine.call(0, True, m)
+        a.close(); b.close(); single.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_library_issued_rccl_exchanges_match_the_caller_dispatched_protocol(tmp_path):
+    port = 29500 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    rounds = np.load(tmp_path / "rounds.npy")
+    assert rounds.shape == (8,) and rounds.max() > 1

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic (-DVBA_RESIDENT_STAMPS build, VBA_LIB): wall-clock stamps inside k_solve_reduced_cr<., 2> of one C3 full call:
+entry, fill done, then after every eliminate / fold of the level loop, every level of the back substitution, the level-1
+recovery and the end; us since entry.  argv[1]: fusion mask (bit 7 set = without the LDS prefetch)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from ctypes import byref, c_int64
+from vinsat_amd import od_pipe, synth, _lib
+from vinsat_amd.engine import BAEngine, _p
+mask = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+det, orb = synth.make_sequence("C3")
+win = od_pipe.prepare_window(det, orb)
+st0 = od_pipe.initial_guess(win)
+n, m = win.time_idx.size, win.ii.size
+e = BAEngine(n, m)
+e.set_fusion(mask)
+e.set_pipeline(0)
+e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+e.set_states(st0, 1e-4)
+for it in range(13):
+    e.step(it, it < 10)
+    if it < 10:
+        continue
+    out = np.empty(32)
+    cnt = c_int64()
+    _lib.check(e.lib.vba_debug_fetch(e.h, 0, 101, _p(out), out.size, byref(cnt)), e.lib)
+    t = out.view(np.uint64).astype(np.int64)
+    k = int(np.argmax(t)) + 1
+    print(f"mask {mask} call {it}:", " ".join(f"{(x - t[0]) * 0.01:.2f}" for x in t[:k]), flush=True)
+e.close()

@@ -59,6 +59,10 @@ SIGNATURES = {
     "vba_sh_stage2": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "vba_sh_stage3": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "vba_sh_stage4": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_int)]),
+    "vba_sh_unique_id": (c_int, [c_char_p, c_void_p]),
+    "vba_sh_comm_init": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int]),
+    "vba_sh_call": (c_int, [c_void_p, c_int, c_int, c_int64, POINTER(c_int)]),
+    "vba_sh_comm_destroy": (c_int, [c_void_p]),
     # free-landmark Schur add-on (parity unpinned: no counterpart in the reference)
     "vba_schur_last_error": (c_char_p, []),
     "vba_schur_create": (c_int, [c_int, c_int, c_int64, c_int, c_int, c_int64, POINTER(c_void_p)]),

@@ -8,6 +8,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: the library is resolved at run time (vba_sh_comm_init), never linked
+
 #include "../../include/vinsat_ba.h"
 #include "vba_device.h"
 #include "vba_launch.h"
@@ -90,6 +93,19 @@ struct vba_context {
     int last_iter = 0, last_init = 0;
     int sh_pivot = 0;                       // sharded mode: solver variant of the current call (0 unpivoted, 2 mixed after a failed check)
     bool sh_rode = false, sh_bands_ready = false;   // sharded mode: the dynamics factor rode in the accumulation; bands / rhs are in memory
+    // sharded mode with the exchanges issued by the library itself (vba_sh_comm_init / vba_sh_call): RCCL resolved at run time
+    struct ShComm {
+        void* dl = nullptr;
+        ncclComm_t comm = nullptr;
+        int nranks = 0, rank = 0;
+        ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+        ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+        const char* (*error_string)(ncclResult_t) = nullptr;
+        double* buf = nullptr;              // one allocation: abs_local | abs_all | partial_local | partial_all | trial_local | trial_all
+        int64_t m_total = 0, m_pad = 0;     // what buf was sized for
+        int n = 0;
+        double *abs_local = nullptr, *abs_all = nullptr, *partial_local = nullptr, *partial_all = nullptr, *trial_local = nullptr, *trial_all = nullptr;
+    } shc;
     int pack_min = 1 << 30;                 // windows from which three chains share a wavefront: never by default (measured at 1024 / 2048 / 4096
                                             // windows: one wave per window is as fast or faster, 1.52 / 1.96 / 2.70 ms vs 1.52 / 2.06 / 2.78 ms per solve);
                                             // vba_set_solver(h, -3) packs from 3 windows on
@@ -396,6 +412,7 @@ int vba_destroy(vba_handle h) {
     if (!h) return VBA_OK;
     (void)settle(h);
     hipSetDevice(h->device);
+    (void)vba_sh_comm_destroy(h);
     if (h->own_stream) { hipStreamSynchronize(h->own_stream); hipStreamDestroy(h->own_stream); }
     if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); }
     if (h->ev_first) hipEventDestroy(h->ev_first);
@@ -1700,6 +1717,128 @@ int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done)
         h->V.m_total = 0;
         h->par ^= 1;            // the trial buffer is the next call's input
     }
+    return VBA_OK;
+}
+
+// ---- the same protocol with the exchanges issued by the library: RCCL all-gathers on the handle's stream between the stage
+// kernels, one host call and (per LM trial) one synchronisation per BA() call.  RCCL is resolved at run time from the path the
+// caller names -- the copy the process has loaded already when it also uses torch.distributed -- so the library itself
+// carries no link-time dependency on it.
+namespace {
+void* open_rccl(const char* path) {
+    void* dl = dlopen(path, RTLD_NOW | RTLD_NOLOAD);        // the instance the process has loaded already, if any
+    if (!dl) dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    return dl;
+}
+}  // namespace
+
+int vba_sh_unique_id(const char* rccl_path, void* id128) {
+    if (!rccl_path || !id128) return fail(VBA_EINVAL, "null argument");
+    void* dl = open_rccl(rccl_path);
+    if (!dl) return fail(VBA_EINVAL, std::string("cannot open ") + rccl_path + ": " + dlerror());
+    auto get_id = reinterpret_cast<ncclResult_t (*)(ncclUniqueId*)>(dlsym(dl, "ncclGetUniqueId"));
+    if (!get_id) { dlclose(dl); return fail(VBA_EINVAL, "ncclGetUniqueId not found in the named library"); }
+    ncclUniqueId id;
+    const ncclResult_t rc = get_id(&id);
+    dlclose(dl);
+    if (rc != ncclSuccess) return fail(VBA_EHIP, "ncclGetUniqueId failed (" + std::to_string((int)rc) + ")");
+    static_assert(sizeof(id) == 128, "unique id size");
+    std::memcpy(id128, &id, sizeof(id));
+    return VBA_OK;
+}
+
+int vba_sh_comm_init(vba_handle h, const char* rccl_path, const void* id128, int nranks, int rank) {
+    if (!h || !rccl_path || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(VBA_EINVAL, "bad argument");
+    if (int rc_settle = settle(h)) return rc_settle;
+    if (h->W != 1) return fail(VBA_EINVAL, "sharded mode uses a single window per handle");
+    if (h->shc.comm) return fail(VBA_ESTATE, "the handle has a communicator already");
+    HIPCHK(hipSetDevice(h->device));
+    auto& S = h->shc;
+    S.dl = open_rccl(rccl_path);
+    if (!S.dl) return fail(VBA_EINVAL, std::string("cannot open ") + rccl_path + ": " + dlerror());
+    auto init_rank = reinterpret_cast<ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>(dlsym(S.dl, "ncclCommInitRank"));
+    S.all_gather = reinterpret_cast<decltype(S.all_gather)>(dlsym(S.dl, "ncclAllGather"));
+    S.comm_destroy = reinterpret_cast<decltype(S.comm_destroy)>(dlsym(S.dl, "ncclCommDestroy"));
+    S.error_string = reinterpret_cast<decltype(S.error_string)>(dlsym(S.dl, "ncclGetErrorString"));
+    if (!init_rank || !S.all_gather || !S.comm_destroy || !S.error_string) {
+        dlclose(S.dl);
+        S = {};
+        return fail(VBA_EINVAL, "the named library does not export the RCCL entry points");
+    }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    const ncclResult_t rc = init_rank(&S.comm, nranks, id, rank);       // collective: returns when every rank has joined
+    if (rc != ncclSuccess) {
+        const std::string why = S.error_string(rc);
+        dlclose(S.dl);
+        S = {};
+        return fail(VBA_EHIP, "ncclCommInitRank failed: " + why);
+    }
+    S.nranks = nranks;
+    S.rank = rank;
+    return VBA_OK;
+}
+
+int vba_sh_comm_destroy(vba_handle h) {
+    if (!h) return VBA_OK;
+    auto& S = h->shc;
+    if (!S.comm && !S.buf) return VBA_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    if (S.comm) S.comm_destroy(S.comm);
+    if (S.buf) hipFree(S.buf);
+    if (S.dl) dlclose(S.dl);
+    S = {};
+    return VBA_OK;
+}
+
+int vba_sh_call(vba_handle h, int iter, int initialize, int64_t m_total, int* n_trials) {
+    if (!h || m_total < 1) return fail(VBA_EINVAL, "bad argument");
+    auto& S = h->shc;
+    if (!S.comm) return fail(VBA_ESTATE, "vba_sh_comm_init has not run");
+    if (int rc = ready(h)) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const int n = h->n[0];
+    const int64_t m_pad = (m_total + S.nranks - 1) / S.nranks;     // equal all-gather slots
+    if (h->m[0] > m_pad) return fail(VBA_EINVAL, "this rank holds more rows than ceil(m_total / ranks)");
+    const int64_t pc = vba_sh_partial_count(n);
+    if (S.m_total != m_total || S.n != n) {       // (re)size the exchange buffers; the padding of a slot sorts above every |r|
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (S.buf) { HIPCHK(hipFree(S.buf)); S.buf = nullptr; }
+        const int64_t R = S.nranks;
+        const int64_t total = 2 * m_pad * (1 + R) + pc * (1 + R) + 2 * (1 + R) + 64;
+        HIPCHK(hipMalloc((void**)&S.buf, (size_t)total * 8));
+        S.abs_local = S.buf;
+        S.abs_all = S.abs_local + 2 * m_pad;
+        S.partial_local = S.abs_all + 2 * m_pad * R;
+        S.partial_all = S.partial_local + pc;
+        S.trial_local = S.partial_all + pc * R;
+        S.trial_all = S.trial_local + 2;
+        std::vector<double> inf((size_t)(2 * m_pad), INFINITY);
+        HIPCHK(hipMemcpy(S.abs_local, inf.data(), inf.size() * 8, hipMemcpyHostToDevice));
+        S.m_total = m_total; S.m_pad = m_pad; S.n = n;
+    }
+    auto gather = [&](const double* src, double* dst, int64_t count) -> int {
+        const ncclResult_t rc = S.all_gather(src, dst, (size_t)count, ncclDouble, S.comm, h->stream);
+        if (rc != ncclSuccess) return fail(VBA_EHIP, std::string("ncclAllGather failed: ") + S.error_string(rc));
+        return VBA_OK;
+    };
+    if (int rc = vba_sh_stage1(h, iter, initialize, m_total, S.abs_local)) return rc;
+    if (int rc = gather(S.abs_local, S.abs_all, 2 * m_pad)) return rc;
+    if (int rc = vba_sh_stage2(h, S.abs_all, 2 * m_pad * S.nranks, S.partial_local)) return rc;
+    if (int rc = gather(S.partial_local, S.partial_all, pc)) return rc;
+    int trials = 0;
+    for (bool first = true;; first = false) {
+        if (int rc = vba_sh_stage3(h, first ? S.partial_all : nullptr, S.nranks, S.trial_local)) return rc;
+        if (int rc = gather(S.trial_local, S.trial_all, 2)) return rc;
+        int done = 0;
+        if (int rc = vba_sh_stage4(h, S.trial_all, S.nranks, &done)) return rc;
+        ++trials;
+        if (done) break;
+        // lamda runs out after 9 trials (+ one repeat for a pivoted fallback): the device never reported an outcome
+        if (trials >= 24) return fail(VBA_ESTATE, "sharded BA call: the LM loop did not terminate within 24 trials");
+    }
+    if (n_trials) *n_trials = trials;
     return VBA_OK;
 }
 

@@ -18,6 +18,7 @@ tensors with the gloo backend in the test-suite (with a stand-in engine) and on 
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 
@@ -29,17 +30,60 @@ def shard_bounds(m_total: int, world: int):
     return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
 
 
-class HipStageEngine:
-    """Stage interface backed by libvinsat_ba.so; buffers are torch CUDA tensors, exchanged by pointer."""
+def loaded_rccl_path():
+    """The RCCL shared object this process has mapped already (torch's own copy once torch is imported), else ROCm's."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split(None, 5)[-1].strip()
+                if "librccl" in os.path.basename(path):
+                    return path
+    except OSError:
+        pass
+    return "/opt/rocm/lib/librccl.so"
 
-    def __init__(self, eng):
+
+class HipStageEngine:
+    """Stage interface backed by libvinsat_ba.so; buffers are torch CUDA tensors, exchanged by pointer.
+
+    ``attach_rccl`` hands the exchanges to the library itself (``vba_sh_comm_init`` / ``vba_sh_call``): RCCL all-gathers
+    on the handle's stream between the stage kernels, one host call per ``BA()`` call."""
+
+    native = False
+
+    def __init__(self, eng, torch_stream=True):
         import torch
         self.eng = eng
         self.lib = eng.lib
         self.torch = torch
         from ._lib import check
         self._check = check
-        check(self.lib.vba_set_stream(eng.h, torch.cuda.current_stream().cuda_stream, 1), self.lib)
+        self._torch_stream = bool(torch_stream)
+        if torch_stream:
+            check(self.lib.vba_set_stream(eng.h, torch.cuda.current_stream().cuda_stream, 1), self.lib)
+
+    def attach_rccl(self, dist, group=None, rccl_path=None):
+        """Join the library-owned communicator of this window's ranks.  ``dist`` / ``group``: any control plane that can
+        ``broadcast_object_list`` (a gloo group will do: only the 128-byte id travels over it).  Collective."""
+        import ctypes
+        path = (rccl_path or loaded_rccl_path()).encode()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            self._check(self.lib.vba_sh_unique_id(path, buf), self.lib)
+        box = [bytes(buf.raw)]
+        src = dist.get_global_rank(group, 0) if group is not None and hasattr(dist, "get_global_rank") else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        self._check(self.lib.vba_sh_comm_init(self.eng.h, path, box[0], int(world), int(rank)), self.lib)
+        self.native = True
+        self.rccl_path = path.decode()
+
+    def call(self, it, init, m_total):
+        """One BA() call through ``vba_sh_call``; returns the number of rounds of the LM loop."""
+        import ctypes
+        ntr = ctypes.c_int()
+        self._check(self.lib.vba_sh_call(self.eng.h, int(it), int(bool(init)), int(m_total), ctypes.byref(ntr)), self.lib)
+        return ntr.value
 
     def partial_count(self, n):
         return int(self.lib.vba_sh_partial_count(int(n)))
@@ -70,7 +114,10 @@ class HipStageEngine:
         return self.eng.get_states()
 
     def close(self):
-        self.lib.vba_set_stream(self.eng.h, None, 0)
+        if self.native:
+            self.lib.vba_sh_comm_destroy(self.eng.h)
+        if self._torch_stream:
+            self.lib.vba_set_stream(self.eng.h, None, 0)
         self.eng.close()
 
 
@@ -113,7 +160,10 @@ class ShardedBA:
         self.rank = dist.get_rank(group)
         self.n, self.m_local, self.m_total = int(n), int(m_local), int(m_total)
         self.m_pad = int(math.ceil(m_total / self.world))        # equal-size all-gather slots
+        self.n_trials = 0
         e = engine
+        if getattr(e, "native", False):     # the library owns the exchange buffers and issues the collectives itself
+            return
         self.abs_local = e.new_buffer(2 * self.m_pad)
         self.abs_local.fill_(float("inf"))                       # padding sorts above every |r|
         self.abs_all = e.new_buffer(2 * self.m_pad * self.world)
@@ -125,8 +175,11 @@ class ShardedBA:
         self.n_trials = 0
 
     @classmethod
-    def from_window(cls, win, device=0, group=None, collectives=None):
-        """Build the GPU-backed sharded solver for a :class:`vinsat_amd.od_pipe.Window` on this rank."""
+    def from_window(cls, win, device=0, group=None, collectives=None, native=False):
+        """Build the GPU-backed sharded solver for a :class:`vinsat_amd.od_pipe.Window` on this rank.
+
+        ``native``: the library issues the all-gathers itself (RCCL on its own stream, ``vba_sh_call``); ``group`` is then
+        only the control plane over which the communicator's id is handed out (any backend)."""
         import torch.distributed as dist
         from .engine import BAEngine
         if collectives is not None:
@@ -138,6 +191,10 @@ class ShardedBA:
         eng = BAEngine(n, max(hi - lo, 1), windows=1, device=device)
         eng.upload_observations(win.landmarks_xyz[lo:hi], win.landmarks_uv[lo:hi], win.confidences[lo:hi], win.ii[lo:hi], n)
         eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+        if native:
+            stage = HipStageEngine(eng, torch_stream=False)
+            stage.attach_rccl(dist, group)
+            return cls(stage, n, hi - lo, m, group, collectives)
         return cls(HipStageEngine(eng), n, hi - lo, m, group, collectives)
 
     def set_states(self, states, lamda):
@@ -149,6 +206,9 @@ class ShardedBA:
     def step(self, it, initialize):
         """One ``BA()`` call; returns the number of LM trials."""
         d, e = self.dist, self.engine
+        if getattr(e, "native", False):
+            self.n_trials = e.call(it, initialize, self.m_total)
+            return self.n_trials
         e.stage1(it, initialize, self.m_total, self.abs_local)
         d.all_gather_into_tensor(self.abs_all, self.abs_local, group=self.group)
         e.stage2(self.abs_all, self.partial_local)
