@@ -640,8 +640,13 @@ def run_rank(args):
             # A hung collective must neither cost the headline line nor read as success: the watchdog prints the line
             # with the error and ends this rank with a non-zero code (every rank runs its own; the launcher / torchrun
             # then ends the rest).  Nothing is retried from a process that has touched the GPU.
+            got = {}        # what has been measured so far (the caller-dispatched leg runs first)
+
             def bail():
                 hung.set()
+                if got:     # the library-issued leg hung: the line keeps the caller-dispatched rate and says so
+                    em.emit(sharded=dict(got, native_error="the library-issued leg timed out (collective hung)"))
+                    os._exit(0)
                 em.emit(sharded={"error": "sharded measurement timed out (collective hung)"})
                 os._exit(3)
 
@@ -675,22 +680,27 @@ def run_rank(args):
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     return ns / float(t.item())
 
-                # the exchanges issued by the library (RCCL on its own stream, one host call per BA call; the id of its
-                # communicator travels over the gloo control group) ...
-                sba = ShardedBA.from_window(win_s, device=device, native=True)
-                v_native = rate(sba)
-                rccl_lib = sba.engine.rccl_path
-                sba.close()
-                # ... and dispatched by the caller through torch.distributed (four stage calls + three collectives per call)
+                # dispatched by the caller through torch.distributed (four stage calls + three collectives per call) ...
                 sba = ShardedBA.from_window(win_s, device=device, group=nccl)
                 v_torch = rate(sba)
                 sba.close()
-                sharded = {"value": v_native, "unit": "BA iterations/s", "poses": cfg.n_poses,
-                           "rccl_ranks": dist.get_world_size(nccl),
-                           "observations_total": int(win_s.ii.size), "observations_per_rank": int(win_s.ii.size // world),
-                           "collectives_per_call": "3 all-gathers (|r| keys, per-pose blocks, trial sums) over RCCL",
-                           "transport": "ncclAllGather issued by libvinsat_ba.so on its stream (vba_sh_call), " + rccl_lib,
-                           "value_torch_dispatched": v_torch}
+                got.update({"value": v_torch, "unit": "BA iterations/s", "poses": cfg.n_poses,
+                            "rccl_ranks": dist.get_world_size(nccl),
+                            "observations_total": int(win_s.ii.size), "observations_per_rank": int(win_s.ii.size // world),
+                            "collectives_per_call": "3 all-gathers (|r| keys, per-pose blocks, trial sums) over RCCL",
+                            "transport": "torch.distributed all_gather_into_tensor between the stage calls",
+                            "value_torch_dispatched": v_torch})
+                sharded = dict(got)
+                # ... and issued by the library (RCCL on its own stream, one host call per BA call; the id of its
+                # communicator travels over the gloo control group).  A failure here keeps the rate above.
+                try:
+                    sba = ShardedBA.from_window(win_s, device=device, native=True)
+                    v_native = rate(sba)
+                    sharded.update(value=v_native, transport="ncclAllGather issued by libvinsat_ba.so on its stream (vba_sh_call), "
+                                   + sba.engine.rccl_path)
+                    sba.close()
+                except Exception as exc:
+                    sharded["native_error"] = repr(exc)[:300]
             except Exception as exc:      # never lose the headline line to the secondary measurement
                 sharded = {"error": repr(exc)[:300]}
             watchdog.cancel()
