@@ -250,11 +250,47 @@ __device__ __forceinline__ double bits_f64(unsigned long long b) { return __long
 // control 0x150 + K) -- no LDS crossbar round trip (ds_bpermute) and no scalar register (v_readlane serves one row only).
 template <int K>
 __device__ __forceinline__ double bcast_row16(double v) {       // lane K of this lane's row of 16
+#ifdef VBA_DPP32
     const unsigned long long b = f64_bits(v);
     // (mov_dpp: no `old` operand -- every lane is written, and update_dpp(0, ...) costs a v_mov of the zero per use)
     const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, 0x150 + K, 0xf, 0xf, false);
     const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), 0x150 + K, 0xf, 0xf, false);
     return bits_f64(((unsigned long long)hi << 32) | lo);
+#else
+    // ONE v_mov_b64_dpp (row_newbcast is the one control the 64-bit DPP moves of gfx90a and later take)
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, false);
+#endif
+}
+
+// Rank-1 update of a Gauss-Jordan pivot with the broadcast folded INTO the multiply-add: for the eight rows r != K
+//   b_r -= a_r[lane K of the row] * bk ;  a_r -= a_r[lane K of the row] * ak      (fused, the operations of fma(-f, x, y))
+// as v_fmac_f64_dpp ... row_newbcast:K -- no separate broadcast of the multiplier column (16 instead of 8 + 16 instructions
+// per pivot with 64-bit moves, 16 + 16 with 32-bit ones).  The multiplier of BOTH updates is a_r as the pivot lane holds it
+// BEFORE the pivot: the b update comes first, and the a update reads its own destination through the DPP -- an instruction
+// reads all its sources before it writes (the idiom of every DPP reduction).  One asm statement per pivot so that the order
+// inside is fixed; the s_nop covers the two wait states a DPP read needs behind a VALU write of the same register, should
+// the compiler have placed one right in front (it knows the hazard for its own instructions, not for these).
+template <int K>
+__device__ __forceinline__ void dpp_rank1_rows16(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, double& a7,
+                                                 double& b0, double& b1, double& b2, double& b3, double& b4, double& b5, double& b6, double& b7,
+                                                 double ak, double bk) {
+#define VBA_R1(A, B) "v_fmac_f64_dpp " B ", -" A ", %17 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t" \
+                     "v_fmac_f64_dpp " A ", -" A ", %16 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t" VBA_R1("%0", "%8") VBA_R1("%1", "%9") VBA_R1("%2", "%10") VBA_R1("%3", "%11") VBA_R1("%4", "%12") VBA_R1("%5", "%13")
+        VBA_R1("%6", "%14") VBA_R1("%7", "%15")
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4),
+          "+v"(b5), "+v"(b6), "+v"(b7)
+        : "v"(ak), "v"(bk), "n"(K));
+#undef VBA_R1
+}
+// the eight rows of a 9-vector that are not row K, as references
+template <int K, int I>
+__device__ __forceinline__ double& row_not(double (&v)[9]) { return v[I < K ? I : I + 1]; }
+template <int K>
+__device__ __forceinline__ void dpp_rank1_9(double (&A)[9], double (&B)[9]) {
+    dpp_rank1_rows16<K>(row_not<K, 0>(A), row_not<K, 1>(A), row_not<K, 2>(A), row_not<K, 3>(A), row_not<K, 4>(A), row_not<K, 5>(A), row_not<K, 6>(A),
+                        row_not<K, 7>(A), row_not<K, 0>(B), row_not<K, 1>(B), row_not<K, 2>(B), row_not<K, 3>(B), row_not<K, 4>(B), row_not<K, 5>(B),
+                        row_not<K, 6>(B), row_not<K, 7>(B), A[K], B[K]);
 }
 template <int K>
 __device__ __forceinline__ int bcast_row16_i32(int v) { return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, false); }

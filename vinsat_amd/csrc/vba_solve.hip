@@ -624,6 +624,7 @@ __device__ __forceinline__ void quad_pivots(const double (&baseA)[9], double (&A
             bad = bad | ((c == K) & !(A[K] > 1e-10 * baseA[K]));
             inv = bcast_row16<K>(fast_rcp(A[K]));
         }
+#ifdef VBA_QUAD_PLAIN_UPDATE
         double f[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) f[r] = (r != K) ? bcast_row16<K>(A[r]) : 0.0;
@@ -636,6 +637,11 @@ __device__ __forceinline__ void quad_pivots(const double (&baseA)[9], double (&A
                 B[r] = fma(-f[r], B[K], B[r]);
             }
         }
+#else
+        A[K] = A[K] * inv;
+        B[K] = B[K] * inv;
+        dpp_rank1_9<K>(A, B);       // a_r = fma(-a_r[pivot lane], a_K, a_r), likewise b_r: the broadcast rides in the multiply-add
+#endif
         quad_pivots<PIVOT, K + 1>(baseA, A, B, c, bad);
     }
 }
