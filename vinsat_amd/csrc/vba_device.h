@@ -283,9 +283,23 @@ __device__ __forceinline__ void dpp_rank1_rows16(double& a0, double& a1, double&
         : "v"(ak), "v"(bk), "n"(K));
 #undef VBA_R1
 }
+// ... the same for ONE column per lane: a_r -= a_r[lane K of the row] * ak for the eight rows r != K
+template <int K>
+__device__ __forceinline__ void dpp_rank1_rows8(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, double& a7, double ak) {
+#define VBA_R1(A) "v_fmac_f64_dpp " A ", -" A ", %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+    asm("s_nop 1\n\t" VBA_R1("%0") VBA_R1("%1") VBA_R1("%2") VBA_R1("%3") VBA_R1("%4") VBA_R1("%5") VBA_R1("%6") VBA_R1("%7")
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+        : "v"(ak), "n"(K));
+#undef VBA_R1
+}
 // the eight rows of a 9-vector that are not row K, as references
 template <int K, int I>
 __device__ __forceinline__ double& row_not(double (&v)[9]) { return v[I < K ? I : I + 1]; }
+template <int K>
+__device__ __forceinline__ void dpp_rank1_9(double (&A)[9]) {
+    dpp_rank1_rows8<K>(row_not<K, 0>(A), row_not<K, 1>(A), row_not<K, 2>(A), row_not<K, 3>(A), row_not<K, 4>(A), row_not<K, 5>(A), row_not<K, 6>(A),
+                       row_not<K, 7>(A), A[K]);
+}
 template <int K>
 __device__ __forceinline__ void dpp_rank1_9(double (&A)[9], double (&B)[9]) {
     dpp_rank1_rows16<K>(row_not<K, 0>(A), row_not<K, 1>(A), row_not<K, 2>(A), row_not<K, 3>(A), row_not<K, 4>(A), row_not<K, 5>(A), row_not<K, 6>(A),

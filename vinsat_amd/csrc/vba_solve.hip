@@ -1789,9 +1789,54 @@ __device__ __forceinline__ CrLanes cr_lanes(int lane) {
     return g;
 }
 
+// The unpivoted elimination with row broadcasts (DPP) instead of v_readlane: every ROW of 16 lanes holds the nine columns of
+// D in its lanes 0..8 (the same values in all rows: each row pivots its own copy) and seven of the nineteen columns of
+// [L | U | g] in lanes 9..15 (rows 0..2; row 3 idles).  A pivot is then reciprocal -> one v_mov_b64_dpp -> scale -> eight
+// v_fmac_f64_dpp (dpp_rank1_9) per lane instead of twenty v_readlane through scalar registers + nine multiply-adds -- the
+// same operations per entry in the same order as forward_step<0, 10, false, false>, so the same bits.
+template <int K = 0>
+__device__ __forceinline__ void cr_pivots_dpp(const double (&base)[9], double (&a)[9], int c, bool& bad) {
+    if constexpr (K < 9) {
+        bad = bad | ((c == K) & !(a[K] > 1e-10 * base[K]));
+        const double inv = bcast_row16<K>(fast_rcp(a[K]));
+        a[K] = a[K] * inv;
+        dpp_rank1_9<K>(a);
+        cr_pivots_dpp<K + 1>(base, a, c, bad);
+    }
+}
+__device__ __forceinline__ void cr_eliminate_dpp(double* B, int lane, bool& bad) {
+    const int row = lane >> 4, c = lane & 15;
+    const int o = row * 7 + (c - 9);                    // column of [L | U | g] of a lane with c >= 9
+    const bool isD = c < 9, isX = !isD && o < 19;
+    const int off = isD ? 81 + c : (o < 9 ? o : (o < 18 ? 162 + (o - 9) : 243));
+    const int st = (isX && o == 18) ? 1 : 9;
+    const double* p = B + ((isD || isX) ? off : 0);
+    double a[9], base[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const double v = p[r * st];
+        a[r] = (isD || isX) ? v : 0.0;
+        base[r] = a[r];
+    }
+    bool mybad = false;
+    cr_pivots_dpp<0>(base, a, c, mybad);
+    bad = bad | (isD & mybad);
+    if (isX) {
+        double* q = B + off;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) q[r * st] = a[r];
+    }
+}
+
 // A: [PL | PU | Pg] = D^{-1} [L | U | g] of block B (LDS, 252 doubles), in place; one wave.
 template <bool PIVOT>
 __device__ __forceinline__ void cr_eliminate(double* B, const CrLanes& g, int lane, bool& bad) {
+#ifndef VBA_CR_READLANE
+    if constexpr (!PIVOT) {
+        cr_eliminate_dpp(B, lane, bad);
+        return;
+    }
+#endif
     double base[9], a[9];
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
