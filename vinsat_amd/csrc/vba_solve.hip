@@ -173,6 +173,22 @@ __device__ __forceinline__ void forward_step(const double* Lmat, const double (&
     }
 }
 
+// The unpivoted elimination with row broadcasts (DPP) instead of v_readlane: every ROW of 16 lanes holds the nine columns of
+// D in its lanes 0..8 (the same values in all rows: each row pivots its own copy) and seven of the nineteen columns of
+// [L | U | g] in lanes 9..15 (rows 0..2; row 3 idles).  A pivot is then reciprocal -> one v_mov_b64_dpp -> scale -> eight
+// v_fmac_f64_dpp (dpp_rank1_9) per lane instead of twenty v_readlane through scalar registers + nine multiply-adds -- the
+// same operations per entry in the same order as forward_step<0, 10, false, false>, so the same bits.
+template <int K = 0>
+__device__ __forceinline__ void cr_pivots_dpp(const double (&base)[9], double (&a)[9], int c, bool& bad) {
+    if constexpr (K < 9) {
+        bad = bad | ((c == K) & !(a[K] > 1e-10 * base[K]));
+        const double inv = bcast_row16<K>(fast_rcp(a[K]));
+        a[K] = a[K] * inv;
+        dpp_rank1_9<K>(a);
+        cr_pivots_dpp<K + 1>(base, a, c, bad);
+    }
+}
+
 // A failed pivot check: with row pivoting it is a numerically singular block (flag 4, result kept as in the
 // reference); without it the host is asked to repeat this solve with pivoting (internal flag 8) and the window
 // stays on the pivoted kernels for the rest of the call (internal flag 16).  The choice is per window, so what one
@@ -1339,12 +1355,78 @@ __device__ __forceinline__ void chunk_eliminate_twosided(const Src& src, int n, 
             base[r] = v;
         }
     };
+    // Row layout of the unpivoted path (cr_pivots_dpp): every row of 16 lanes holds D' in lanes 0..8 (the same values in
+    // all four rows) and seven of the 28 columns [U | y V W] in lanes 9..15; a pivot broadcasts inside the row (DPP).  What
+    // the alternating lane groups of forward_step got for free -- X_{t-1}'s column c already sitting in the lane that forms
+    // D'_t's column c -- comes from Xb in LDS here (written for the outward substitution anyway).
+#ifndef VBA_CHUNK_READLANE
+    constexpr bool kRows = !PIVOT;
+#else
+    constexpr bool kRows = false;
+#endif
+    const int rrow = lane >> 4, rc = lane & 15;
+    const int ro = rrow * 7 + (rc - 9);                 // column of [U | y V W] of a lane with rc >= 9
+    const bool rD = rc < 9, rU = !rD && ro < 9, rR = !rD && ro >= 9;
+    const int rz = rR ? ro - 9 : 0;                     // column of Zb: 0 = y, 1..9 = V, 10..18 = W
+    auto rows_step = [&](const double* b, const double* Lmat, const double* Xprev, bool first) {
+        // base: this lane's column of [D + lam I | U | y | V (first block only)]
+        const bool ok = rD || rU || (rR && (rz == 0 || (first && rz < 10)));
+        const int off = rD ? 81 + rc : (rU ? 162 + ro : (rz == 0 ? 243 : rz - 1));
+        const int stride = (rR && rz == 0) ? 1 : 9;
+        const double* p = b + (ok ? off : 0);
+        double base[9], xp[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = p[r * stride];
+            v = ok ? v : 0.0;
+            if (rD && r == rc) v += lam32;
+            base[r] = v;
+        }
+        if (Lmat) {
+            // carried column: X_{t-1}[:, c] for the D lanes (from LDS), this lane's own z_{t-1} for the right-hand sides
+            const double* xs = Xprev + (rD ? rc : 0);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const double xv = xs[j * 9];
+                xp[j] = rD ? xv : (rR ? a[j] : 0.0);
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                double v = base[r];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const bool rot_r = (r >= 3 && r < 6), rot_j = (j >= 3 && j < 6);
+                    if (!SPARSE_L || rot_r == rot_j) v = fma(-Lmat[r * 9 + j], xp[j], v);
+                }
+                a[r] = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) a[r] = base[r];
+        }
+        bool mybad = false;
+        cr_pivots_dpp<0>(base, a, rc, mybad);
+        zero_pivot = zero_pivot | (rD & mybad);
+    };
     fetch(0);
     stash(0);
     wave_sync_lds();
     for (int t = 0; t < lenS; ++t) {
         const int buf = t & 1;
         if (t + 1 < lenS) fetch(t + 1);
+        if constexpr (kRows) {
+            rows_step(blk[buf], t > 0 ? blk[buf] : nullptr, Xb + (size_t)(t > 0 ? t - 1 : 0) * 81, t == 0);
+            if (rU) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) Xb[(size_t)t * 81 + r * 9 + ro] = a[r];
+            } else if (rR) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) Zb[((size_t)t * 19 + rz) * 9 + r] = a[r];
+            }
+            if (t + 1 < lenS) stash(buf ^ 1);
+            wave_sync_lds();
+            continue;
+        }
         double base[9];
         if (buf == 0) {
             load_base(blk[0], 0, t == 0, base);
@@ -1370,7 +1452,42 @@ __device__ __forceinline__ void chunk_eliminate_twosided(const Src& src, int n, 
     }
     __syncthreads();
     // block m: both neighbours folded in, then the same Gauss-Jordan step on [M | 19 right-hand sides]
-    if (side == 0) {
+    if (kRows && side == 0) {
+        const double* XL = reg0 + 512 + (size_t)(lenL - 1) * 81;
+        const double* ZL = reg0 + 512 + (size_t)hs * 81 + (size_t)(lenL - 1) * 171;
+        const double* XR = reg1 + 512 + (size_t)(lenR - 1) * 81;
+        const double* ZR = reg1 + 512 + (size_t)hs * 81 + (size_t)(lenR - 1) * 171;
+        // column of the left / right sweep's results this lane folds in (wave 1 keeps the right coupling in ITS columns 1..9)
+        const int cl = rz, cr = rz == 0 ? 0 : (rz < 10 ? rz + 9 : rz - 9);
+        const double* pl = rD ? XL + rc : ZL + (size_t)(rR ? cl : 0) * 9;
+        const double* pr = rD ? XR + rc : ZR + (size_t)(rR ? cr : 0) * 9;
+        const int st = rD ? 9 : 1;
+        double base[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            double v = 0.0;
+            const double dv = blkM[81 + r * 9 + (rD ? rc : 0)], yv = blkM[243 + r];
+            if (rD) v = dv + (r == rc ? lam32 : 0.0);
+            else if (rR && rz == 0) v = yv;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const bool rot_r = (r >= 3 && r < 6), rot_j = (j >= 3 && j < 6);
+                if (!SPARSE_L || rot_r == rot_j) {
+                    v -= blkM[r * 9 + j] * pl[j * st];
+                    v -= blkM[162 + r * 9 + j] * pr[j * st];
+                }
+            }
+            base[r] = (rD || rR) ? v : 0.0;
+            a[r] = base[r];
+        }
+        bool mybad = false;
+        cr_pivots_dpp<0>(base, a, rc, mybad);
+        zero_pivot = zero_pivot | (rD & mybad);
+        if (rR) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) xm[(size_t)rz * 9 + r] = a[r];
+        }
+    } else if (side == 0) {
         const double* XL = reg0 + 512 + (size_t)(lenL - 1) * 81;
         const double* ZL = reg0 + 512 + (size_t)hs * 81 + (size_t)(lenL - 1) * 171;
         const double* XR = reg1 + 512 + (size_t)(lenR - 1) * 81;
@@ -1789,21 +1906,7 @@ __device__ __forceinline__ CrLanes cr_lanes(int lane) {
     return g;
 }
 
-// The unpivoted elimination with row broadcasts (DPP) instead of v_readlane: every ROW of 16 lanes holds the nine columns of
-// D in its lanes 0..8 (the same values in all rows: each row pivots its own copy) and seven of the nineteen columns of
-// [L | U | g] in lanes 9..15 (rows 0..2; row 3 idles).  A pivot is then reciprocal -> one v_mov_b64_dpp -> scale -> eight
-// v_fmac_f64_dpp (dpp_rank1_9) per lane instead of twenty v_readlane through scalar registers + nine multiply-adds -- the
-// same operations per entry in the same order as forward_step<0, 10, false, false>, so the same bits.
-template <int K = 0>
-__device__ __forceinline__ void cr_pivots_dpp(const double (&base)[9], double (&a)[9], int c, bool& bad) {
-    if constexpr (K < 9) {
-        bad = bad | ((c == K) & !(a[K] > 1e-10 * base[K]));
-        const double inv = bcast_row16<K>(fast_rcp(a[K]));
-        a[K] = a[K] * inv;
-        dpp_rank1_9<K>(a);
-        cr_pivots_dpp<K + 1>(base, a, c, bad);
-    }
-}
+// (cr_pivots_dpp, above forward_step's users: D replicated per row of 16 lanes, seven other columns per row)
 __device__ __forceinline__ void cr_eliminate_dpp(double* B, int lane, bool& bad) {
     const int row = lane >> 4, c = lane & 15;
     const int o = row * 7 + (c - 9);                    // column of [L | U | g] of a lane with c >= 9
