@@ -39,6 +39,16 @@ namespace vba {
 
 typedef double vf4 __attribute__((ext_vector_type(4)));     // accumulator of v_mfma_f64_16x16x4
 
+// Diagnostic builds (-DVBA_RESIDENT_STAMPS; tools/tail_stamps.py): 100 MHz wall-clock stamps of one thread along the
+// single-window solve kernels, fetched with vba_debug_fetch(h, 0, 101, ...).
+#ifdef VBA_RESIDENT_STAMPS
+__device__ unsigned long long g_kstamps[128];
+#define VBA_KSTAMP(on, slot) do { if (on) g_kstamps[slot] = wall_clock64(); } while (0)
+void fetch_kstamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kstamps), sizeof(g_kstamps)); }
+#else
+#define VBA_KSTAMP(on, slot) do {} while (0)
+#endif
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const unsigned long long b = f64_bits(v);
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, lane);
@@ -1425,6 +1435,7 @@ __device__ __forceinline__ void chunk_eliminate_twosided(const Src& src, int n, 
             }
             if (t + 1 < lenS) stash(buf ^ 1);
             wave_sync_lds();
+            VBA_KSTAMP(tid == 0 && c == 30, 35 + t);
             continue;
         }
         double base[9];
@@ -1451,6 +1462,7 @@ __device__ __forceinline__ void chunk_eliminate_twosided(const Src& src, int n, 
         for (int q = 0; q < 4; ++q) blkM[lane + 64 * q] = mid[q];
     }
     __syncthreads();
+    VBA_KSTAMP(tid == 0 && c == 30, 40);
     // block m: both neighbours folded in, then the same Gauss-Jordan step on [M | 19 right-hand sides]
     if (kRows && side == 0) {
         const double* XL = reg0 + 512 + (size_t)(lenL - 1) * 81;
@@ -1522,6 +1534,7 @@ __device__ __forceinline__ void chunk_eliminate_twosided(const Src& src, int n, 
         }
     }
     __syncthreads();
+    VBA_KSTAMP(tid == 0 && c == 30, 41);
     // outward substitution on the matrix cores (see chunk_eliminate): x_t = Z_t - X_t x_{t+1}
     const int lr = lane & 15, lk = lane >> 4;
     auto colperm = [&](int col) { return side ? (col == 0 ? 0 : (col < 10 ? col + 9 : col - 9)) : col; };
@@ -1567,6 +1580,7 @@ __device__ __forceinline__ void chunk_eliminate_twosided(const Src& src, int n, 
         x1 = n1;
         store_cols(csol + (size_t)block_of(t) * 171, 9, 1, x0, x1);
     }
+    VBA_KSTAMP(tid == 0 && c == 30, 42);
     // x is now the solution next to this side's separator: its contribution to that row of the reduced system
     if (side == 0 ? c > 0 : has_sep) {
         vf4 p0 = {0.0, 0.0, 0.0, 0.0}, p1 = {0.0, 0.0, 0.0, 0.0};
@@ -1712,6 +1726,7 @@ __device__ __forceinline__ void chunks_ts_fused_body(const DevView& V, int s, in
     const int n = V.n[w];
     if (c * s >= n) return;
     const int tid = threadIdx.x;
+    VBA_KSTAMP(tid == 0 && c == 30, 32);
     const size_t sb = (size_t)w * V.n_max;
     const size_t rb = (size_t)w * V.p_max;
     const double lam32 = (double)(float)sc.lam[V.par];
@@ -1749,6 +1764,7 @@ __device__ __forceinline__ void chunks_ts_fused_body(const DevView& V, int s, in
         }
     }
     __syncthreads();
+    VBA_KSTAMP(tid == 0 && c == 30, 33);
     const double inv_wmax = 1.0 / bits_f64(sc.wmax_bits[V.par]);
     {
         // formation by column: a row of 16 lanes per pose row, sixteen pose rows per pass of the workgroup
@@ -1783,10 +1799,12 @@ __device__ __forceinline__ void chunks_ts_fused_body(const DevView& V, int s, in
         }
     }
     __syncthreads();
+    VBA_KSTAMP(tid == 0 && c == 30, 34);
     if (tid >= 128) return;     // the elimination is two waves' work (its barriers count the surviving waves only)
     bool bad = false;
     const LdsBlockSource src{blocks, j0};
     chunk_eliminate_twosided<PIVOT, true>(src, n, s, c, lam32, V.csol + sb * 171, V.cL + rb * 171, V.cR + rb * 171, elim, tid, bad);
+    VBA_KSTAMP(tid == 0 && c == 30, 47);
     report_pivot<PIVOT>(bad, sc, tid & 63, V.par);
 }
 
@@ -1957,6 +1975,7 @@ __device__ __forceinline__ void cr_eliminate(double* B, const CrLanes& g, int la
 // B: fold the eliminated neighbours Pm (left) and Pp (right, if has_p) into block Bj, in place; one wave.
 __device__ __forceinline__ void cr_fold(double* Bj, const double* Pm, const double* Pp, bool has_p, const CrLanes& g) {
     vf4 acc0, acc1;
+    VBA_KSTAMP(threadIdx.x == 0 && gridDim.y == 1 && blockDim.x == 1024, 79);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = g.lk + 4 * i;
@@ -1966,29 +1985,53 @@ __device__ __forceinline__ void cr_fold(double* Bj, const double* Pm, const doub
         acc0[i] = (rv && g.lr < 9) ? d0 : 0.0;
         acc1[i] = (rv && g.lr == 11) ? g0 : 0.0;      // column 27 = 16 + 11
     }
+    // every LDS operand first (15 reads in flight together), then the chain of matrix operations: left to itself the
+    // compiler reads each k-step's operands right in front of its two MFMAs -- five LDS round trips one after the other
+    double am[5], b0[5], b1[5];
 #pragma unroll
     for (int st = 0; st < 5; ++st) {
         const double a0 = Bj[g.offA[st] >= 0 ? g.offA[st] : 0];
-        const double am = g.offA[st] >= 0 ? -a0 : 0.0;
+        am[st] = g.offA[st] >= 0 ? -a0 : 0.0;
         const double* P = g.hiB[st] ? Pp : Pm;
         const bool okp = !g.hiB[st] || has_p;
         const double v0 = P[g.offB0[st] >= 0 ? g.offB0[st] : 0], v1 = P[g.offB1[st] >= 0 ? g.offB1[st] : 0];
-        const double b0 = (okp && g.offB0[st] >= 0) ? v0 : 0.0, b1 = (okp && g.offB1[st] >= 0) ? v1 : 0.0;
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, b1, acc1, 0, 0, 0);
+        b0[st] = (okp && g.offB0[st] >= 0) ? v0 : 0.0;
+        b1[st] = (okp && g.offB1[st] >= 0) ? v1 : 0.0;
     }
-    // every operand has been read (the LDS operations of a wave execute in order): replace the block
+#ifndef VBA_FOLD_INTERLEAVED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef VBA_RESIDENT_STAMPS
+    const bool fson = threadIdx.x == 0 && gridDim.y == 1 && blockDim.x == 1024;
+    VBA_KSTAMP(fson, 80);
+    if (fson) g_kstamps[81] = (unsigned long long)(am[0] + b0[0] + b1[4] + am[4] != 12345.0);   // (forces the operands)
+    VBA_KSTAMP(fson, 82);
+#endif
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[st], b0[st], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am[st], b1[st], acc1, 0, 0, 0);
+    }
+#ifdef VBA_RESIDENT_STAMPS
+    if (fson) g_kstamps[83] = (unsigned long long)(acc0[0] + acc1[3] != 12345.0);               // (forces the results)
+    VBA_KSTAMP(fson, 84);
+#endif
+    // every operand has been read (the LDS operations of a wave execute in order): replace the block.  One destination per
+    // lane and tile, decided by arithmetic -- as nested branches this tail was twenty basic blocks
+    const int c1 = 16 + g.lr;
+    const int col0 = g.lr < 9 ? 81 + g.lr : g.lr - 9;                                              // D | L columns 0..6
+    const int col1 = c1 < 18 ? c1 - 9 : (c1 < 27 ? 162 + (c1 - 18) : 243);                         // L columns 7, 8 | U | g
+    const int st1 = c1 == 27 ? 1 : 9;
+    const bool has1 = c1 <= 27;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = g.lk + 4 * i;
-        if (row < 9) {
-            Bj[g.lr < 9 ? 81 + row * 9 + g.lr : row * 9 + (g.lr - 9)] = acc0[i];                   // D | L columns 0..6
-            const int c1 = 16 + g.lr;
-            if (c1 < 18) Bj[row * 9 + (c1 - 9)] = acc1[i];                                          // L columns 7, 8
-            else if (c1 < 27) Bj[162 + row * 9 + (c1 - 18)] = acc1[i];                              // U
-            else if (c1 == 27) Bj[243 + row] = acc1[i];                                             // g
-        }
+        if (row < 9) Bj[col0 + row * 9] = acc0[i];
+        if (row < 9 && has1) Bj[col1 + row * st1] = acc1[i];
     }
+#ifdef VBA_RESIDENT_STAMPS
+    VBA_KSTAMP(fson, 85);
+#endif
 }
 
 // Blocks q0 + u * stride (u < NB) of the reduced system (see ReducedSource) into LDS at dst + u * dst_stride * 252.  A wave takes
@@ -2155,6 +2198,9 @@ __global__ __launch_bounds__(256) void k_cr_level01(DevView V, int s) {
 template <bool PIVOT, int PRE, int kCrThreads>
 __device__ __forceinline__ void reduced_cr_body(const DevView& V, int s, int w, double* smem) {
     VBA_SKIP_CALL(V, w);
+    int tsi = 0;
+    const bool tson = threadIdx.x == 0;
+    VBA_KSTAMP(tson, tsi++);
     WinScalars& sc = V.sc[w];
     if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
     const int n0 = n_separators(V.n[w], s);             // separators of the window
@@ -2187,15 +2233,17 @@ __device__ __forceinline__ void reduced_cr_body(const DevView& V, int s, int w, 
         cr_fill<kCrMax / NW>(V, w, s, n1, lam32, wave, NW, smem + (size_t)wave * 252, NW, lane, [&]() { g = cr_lanes(lane); });   // blocks wave, wave + NW, ...
     }
     __syncthreads();
+    VBA_KSTAMP(tson, tsi++);
     bool bad = false;
-    int h = 1;
-    for (;; h <<= 1) {
-        const int cnt = n1 / h;                 // active blocks of this level
+    int h = 1, lv = 0;                          // h = 1 << lv (shifts: a division by a run-time h is ~40 instructions per level)
+    for (;; h <<= 1, ++lv) {
+        const int cnt = n1 >> lv;               // active blocks of this level
         const int nel = (cnt + 1) / 2;
 #pragma nounroll
         for (int t = wave; t < nel; t += NW)    // A: eliminate the odd-ranked blocks
             cr_eliminate<PIVOT>(smem + (size_t)((2 * t + 1) * h - 1) * 252, g, lane, bad);
         __syncthreads();
+        VBA_KSTAMP(tson, tsi++);
         if (cnt <= 1) break;
         const int nk = cnt / 2;
 #pragma nounroll
@@ -2204,11 +2252,13 @@ __device__ __forceinline__ void reduced_cr_body(const DevView& V, int s, int w, 
             const bool has_p = j + h < n1;
             cr_fold(smem + (size_t)j * 252, smem + (size_t)(j - h) * 252, smem + (size_t)(has_p ? j + h : j) * 252, has_p, g);
         }
+        VBA_KSTAMP(tson, 64 + tsi);
         __syncthreads();
+        VBA_KSTAMP(tson, tsi++);
     }
     // back substitution: the level that ended the loop has a single block with no active neighbour (x = Pg)
-    for (; h >= 1; h >>= 1) {
-        const int cnt = n1 / h;
+    for (; h >= 1; h >>= 1, --lv) {
+        const int cnt = n1 >> lv;
         const int nel = (cnt + 1) / 2;
         for (int idx = tid; idx < nel * 9; idx += kCrThreads) {
             const int t = idx / 9, r = idx % 9;
@@ -2228,6 +2278,7 @@ __device__ __forceinline__ void reduced_cr_body(const DevView& V, int s, int w, 
             B[243 + r] = x;     // read only by this thread at this level (the neighbours belong to coarser levels)
         }
         __syncthreads();
+        VBA_KSTAMP(tson, tsi++);
     }
     if (PRE == 2) {
         // separators 4b+3 are the blocks solved here.  4b+1 come from the level-1 eliminations, x = Pg - PL x_{q-2} - PU x_{q+2},
@@ -2255,6 +2306,7 @@ __device__ __forceinline__ void reduced_cr_body(const DevView& V, int s, int w, 
             }
         }
         __syncthreads();
+        VBA_KSTAMP(tson, tsi++);
         for (int idx = tid; idx < n0 * 9; idx += kCrThreads) {
             const int q = idx / 9, r = idx % 9;
             double x;
@@ -2303,6 +2355,8 @@ __device__ __forceinline__ void reduced_cr_body(const DevView& V, int s, int w, 
             V.rx[rb * 9 + idx] = x;
         }
     }
+    VBA_KSTAMP(tson, tsi++);
+    (void)tsi; (void)tson;
     report_pivot<PIVOT>(bad, sc, lane, V.par);
 }
 
