@@ -1730,6 +1730,8 @@ __device__ __forceinline__ void chunks_ts_fused_body(const DevView& V, int s, in
     const size_t sb = (size_t)w * V.n_max;
     const size_t rb = (size_t)w * V.p_max;
     const double lam32 = (double)(float)sc.lam[V.par];
+    // (requested here, in front of the staging: behind the barrier below this load would be a round trip to memory of its own)
+    const unsigned long long wmax_bits = sc.wmax_bits[V.par];
     if (c == 0 && tid == 0) {
         sc.lam32 = lam32;
         if (PIVOT) atomicAnd(&sc.fl[V.par], ~8u);
@@ -1765,7 +1767,7 @@ __device__ __forceinline__ void chunks_ts_fused_body(const DevView& V, int s, in
     }
     __syncthreads();
     VBA_KSTAMP(tid == 0 && c == 30, 33);
-    const double inv_wmax = 1.0 / bits_f64(sc.wmax_bits[V.par]);
+    const double inv_wmax = 1.0 / bits_f64(wmax_bits);
     {
         // formation by column: a row of 16 lanes per pose row, sixteen pose rows per pass of the workgroup
         const int lane = tid & 63, wave = tid >> 6, row = lane >> 4, cc = lane & 15;
