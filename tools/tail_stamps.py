@@ -33,6 +33,7 @@ for it in range(13):
     print(f"   (fold done by wave 0, before the barrier):", " ".join(f"{(t[64 + i] - t[0]) * 0.01:.2f}" for i in range(k) if t[64 + i] > 0), flush=True)
     print("   (last fold of wave 0: entry, operands issued, operands there, results there, stored):",
           " ".join(f"{(t[i] - t[0]) * 0.01:.2f}" for i in (79, 80, 82, 84, 85)), flush=True)
+    print("   (chunk 30, forming: start, columns formed, stored):", " ".join(f"{(t[i] - t[32]) * 0.01:.2f}" for i in (48, 50, 51)), flush=True)
     names = ["entry", "staged", "formed", "step0", "step1", "step2", "step3", "step4", "sweeps joined", "middle", "outward", "end"]
     idx = [32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 47]
     print(f"mask {mask} call {it} chunk 30:", " ".join(f"{nm} {(t[i] - t[32]) * 0.01:.2f}" for nm, i in zip(names, idx) if t[i] >= t[32]), flush=True)

@@ -1780,24 +1780,32 @@ __device__ __forceinline__ void chunks_ts_fused_body(const DevView& V, int s, in
             double* blk = blocks + (size_t)qq * 252;
             const bool sep = have && has_sep && i == j1, last = have && i == n - 1;
             double A[9], B[9], Lc[9];
+            VBA_KSTAMP(tid == 0 && c == 30, 48);
             asm_form_columns<REG>(cl, cc, in + (size_t)(qq + 1) * kAsmIn, in + (size_t)qq * kAsmIn, true, i < n - 1, i > 0, V.prm.sigma, inv_wmax, A, B, Lc);
-            if (have && cc < 10) {
+#ifdef VBA_RESIDENT_STAMPS
+            if (tid == 0 && c == 30) g_kstamps[49] = (unsigned long long)(A[0] + A[8] + B[4] + Lc[7] != 12345.0);
+            VBA_KSTAMP(tid == 0 && c == 30, 50);
+#endif
+            {
+                // one destination and one predicate per lane and array, decided once (as nested branches inside the unrolled
+                // loop this was some forty basic blocks).  What later kernels read from memory: the right separator's
+                // diagonal block and right-hand side (reduced system), the last pose's diagonal block (last_hessian)
+                const bool isc = have && cc < 9, isr = have && cc == 9;
+                double* pA = blk + (cc < 9 ? 81 + cc : 243);
+                const int stA = cc < 9 ? 9 : 1;
+                double* gS = cc < 9 ? V.bands + (sb + i) * 243 + 81 + cc : V.rhs + (sb + i) * 9;
+                double* gL = V.lastD + (size_t)w * 81 + (cc < 9 ? cc : 0);
+                const bool wS = sep && (isc || isr), wL = last && isc;
 #pragma unroll
                 for (int a9 = 0; a9 < 9; ++a9) {
-                    if (cc < 9) {
-                        blk[a9 * 9 + cc] = Lc[a9];
-                        blk[81 + a9 * 9 + cc] = A[a9];
-                        blk[162 + a9 * 9 + cc] = B[a9];
-                        // what later kernels read from memory: the right separator's diagonal block (reduced system), the
-                        // last pose's diagonal block (last_hessian)
-                        if (sep) V.bands[(sb + i) * 243 + 81 + a9 * 9 + cc] = A[a9];
-                        if (last) V.lastD[(size_t)w * 81 + a9 * 9 + cc] = A[a9];
-                    } else {
-                        blk[243 + a9] = A[a9];
-                        if (sep) V.rhs[(sb + i) * 9 + a9] = A[a9];
-                    }
+                    if (isc) blk[a9 * 9 + cc] = Lc[a9];
+                    if (isc || isr) pA[a9 * stA] = A[a9];
+                    if (isc) blk[162 + a9 * 9 + cc] = B[a9];
+                    if (wS) gS[a9 * stA] = A[a9];
+                    if (wL) gL[a9 * 9] = A[a9];
                 }
             }
+            VBA_KSTAMP(tid == 0 && c == 30, 51);
         }
     }
     __syncthreads();
