@@ -1561,14 +1561,17 @@ __device__ __forceinline__ void chunk_eliminate_twosided(const Src& src, int n, 
         }
     };
     // the real column a value of this side's column `col` belongs to
+    // (every lane stores every time: one without an entry repeats its own first one -- row lk < 4 of the first tile always
+    // exists -- instead of opening a branch region per store)
     auto store_cols = [&](double* dst, size_t col_stride, size_t row_stride, const vf4& v0, const vf4& v1) {
+        const size_t c0 = (size_t)colperm(lr) * col_stride, c1 = (size_t)colperm(lr < 3 ? 16 + lr : 0) * col_stride;
+        const size_t home = c0 + (size_t)lk * row_stride;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = lk + 4 * i;
-            if (row < 9) {
-                dst[(size_t)colperm(lr) * col_stride + (size_t)row * row_stride] = v0[i];
-                if (lr < 3) dst[(size_t)colperm(16 + lr) * col_stride + (size_t)row * row_stride] = v1[i];
-            }
+            const bool ok0 = row < 9, ok1 = ok0 && lr < 3;
+            dst[ok0 ? c0 + (size_t)row * row_stride : home] = ok0 ? v0[i] : v0[0];
+            dst[ok1 ? c1 + (size_t)row * row_stride : home] = ok1 ? v1[i] : v0[0];
         }
     };
     vf4 x0 = load_cols(xm, 0, true), x1 = load_cols(xm, 1, true);
@@ -1796,13 +1799,27 @@ __device__ __forceinline__ void chunks_ts_fused_body(const DevView& V, int s, in
                 double* gS = cc < 9 ? V.bands + (sb + i) * 243 + 81 + cc : V.rhs + (sb + i) * 9;
                 double* gL = V.lastD + (size_t)w * 81 + (cc < 9 ? cc : 0);
                 const bool wS = sep && (isc || isr), wL = last && isc;
+                // LDS: every lane stores, the lanes without a column into a dump word of the elimination's scratch (idle until
+                // the barrier below) -- a predicated store inside the unrolled loop is a branch region of its own, and
+                // forty-five of them cost more than the formation itself (1.3 against 0.6 us)
+                double* dump = elim + (tid & 63);
+                double* pL = isc ? blk + cc : dump;
+                double* pD = (isc || isr) ? pA : dump;
+                double* pU = isc ? blk + 162 + cc : dump;
+                const int sC = isc ? 9 : 0, sD = (isc || isr) ? stA : 0;
 #pragma unroll
                 for (int a9 = 0; a9 < 9; ++a9) {
-                    if (isc) blk[a9 * 9 + cc] = Lc[a9];
-                    if (isc || isr) pA[a9 * stA] = A[a9];
-                    if (isc) blk[162 + a9 * 9 + cc] = B[a9];
-                    if (wS) gS[a9 * stA] = A[a9];
-                    if (wL) gL[a9 * 9] = A[a9];
+                    pL[a9 * sC] = Lc[a9];
+                    pD[a9 * sD] = A[a9];
+                    pU[a9 * sC] = B[a9];
+                }
+                if (wS) {
+#pragma unroll
+                    for (int a9 = 0; a9 < 9; ++a9) gS[a9 * stA] = A[a9];
+                }
+                if (wL) {
+#pragma unroll
+                    for (int a9 = 0; a9 < 9; ++a9) gL[a9 * 9] = A[a9];
                 }
             }
             VBA_KSTAMP(tid == 0 && c == 30, 51);
@@ -2033,11 +2050,15 @@ __device__ __forceinline__ void cr_fold(double* Bj, const double* Pm, const doub
     const int col1 = c1 < 18 ? c1 - 9 : (c1 < 27 ? 162 + (c1 - 18) : 243);                         // L columns 7, 8 | U | g
     const int st1 = c1 == 27 ? 1 : 9;
     const bool has1 = c1 <= 27;
+    // ... and every lane stores every time: a lane without an entry repeats its own first one (row g.lk < 4 of tile 0 always
+    // exists) -- a predicated store is a branch region of its own
+    const int home = col0 + g.lk * 9;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = g.lk + 4 * i;
-        if (row < 9) Bj[col0 + row * 9] = acc0[i];
-        if (row < 9 && has1) Bj[col1 + row * st1] = acc1[i];
+        const bool ok0 = row < 9, ok1 = ok0 && has1;
+        Bj[ok0 ? col0 + row * 9 : home] = ok0 ? acc0[i] : acc0[0];
+        Bj[ok1 ? col1 + row * st1 : home] = ok1 ? acc1[i] : acc0[0];
     }
 #ifdef VBA_RESIDENT_STAMPS
     VBA_KSTAMP(fson, 85);
