@@ -1497,6 +1497,12 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
 #ifdef VBA_RESIDENT_STAMPS
         case 100:           // diagnostic build: the wall-clock stamps of the last k_solve_resident launch (raw 64-bit words)
             return copy(V.cR2 + (size_t)window * V.res_stride * 4, (int64_t)V.res_stride * 4);
+        case 102: {         // ... and along k_trial (g_ostamps, vba_obs.hip): 64 raw words
+            if (capacity < 64) return fail(VBA_EINVAL, "debug buffer too small");
+            fetch_ostamps(reinterpret_cast<unsigned long long*>(out));
+            *count = 64;
+            return VBA_OK;
+        }
         case 101: {         // ... and of one thread along the solve kernels (g_kstamps, vba_solve.hip): 128 raw words
             if (capacity < 128) return fail(VBA_EINVAL, "debug buffer too small");
             fetch_kstamps(reinterpret_cast<unsigned long long*>(out));

@@ -27,6 +27,7 @@ void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s);
 void launch_solve(const DevView& V, int initialize, hipStream_t s);
 #ifdef VBA_RESIDENT_STAMPS
 void fetch_kstamps(unsigned long long* out);     // diagnostic builds: see vba_solve.hip
+void fetch_ostamps(unsigned long long* out);     // ... and vba_obs.hip
 #endif
 hipError_t configure_solver_device();      // per device, from vba_create
 bool solve_forms_blocks(const DevView& V);  // the chunk kernel forms its blocks itself: no k_assemble for this call

@@ -957,6 +957,15 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 // partitioned solve), 16 lanes per pose: an observation block for the poses its rows belong to (a handful), a pose-chain
 // block for 16 poses = 15 edges, which also writes states_new / dpose for everybody after this kernel; 3 = the geometry
 // of 1 / 2 with the trial states read from memory (a call of such a handle that cannot fuse: pivoted landmark-only solve).
+// Diagnostic builds (-DVBA_RESIDENT_STAMPS; tools/trial_stamps.py): 100 MHz wall-clock stamps of thread 0 of observation
+// block 100 along k_trial, fetched with vba_debug_fetch(h, 0, 102, ...).
+#ifdef VBA_RESIDENT_STAMPS
+__device__ unsigned long long g_ostamps[64];
+#define VBA_OSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x == 100 && blockIdx.y == 0) g_ostamps[slot] = wall_clock64(); } while (0)
+void fetch_ostamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ostamps), sizeof(g_ostamps)); }
+#else
+#define VBA_OSTAMP(slot) do {} while (0)
+#endif
 constexpr int kEdgesPerBlock16 = 15;
 
 // PART (many windows per launch, FUSED 0): 0 = one grid does both kinds of block; 1 = the observation blocks only, 2 = the
@@ -975,6 +984,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     if (sc.done) return;
+    VBA_OSTAMP(0);
     const int n = V.n[w], m = V.m[w];
     const StepParams& prm = V.prm;
     const int par = V.par;
@@ -1016,6 +1026,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             if (FUSED == 1 && fz) sc.lam32 = lam32;
         }
     }
+    VBA_OSTAMP(1);
     unsigned bad = 0u;
     unsigned kbin[2] = {0u, 0u}, kslot[2] = {0u, 0u};      // EMIT 2: warm bin of this thread's two keys and their place in the block's share
     double kkey[2] = {0.0, 0.0};
@@ -1044,6 +1055,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             const int slot = (int)(before + (unsigned)__popcll(lm & ((2ull << lane) - 1ull))) - 1;   // leaders up to and including me
             if (lead) lpose[slot] = pose;
             __syncthreads();
+            VBA_OSTAMP(2);
             for (unsigned base = 0; base < nlead; base += 16) {
                 const unsigned idx = base + (unsigned)grp;
                 const bool live = idx < nlead;
@@ -1056,6 +1068,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
                 }
             }
             __syncthreads();
+            VBA_OSTAMP(3);
             stp = snew + (size_t)(slot < 0 ? 0 : slot) * 10;
         }
         if (have) {
@@ -1166,6 +1179,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     }
     // bin buckets: the block reserves its share of every bin it touched with one returning atomic per bin -- requested
     // here, in flight while the block sums below are formed
+    VBA_OSTAMP(4);
     constexpr int kBinsPerThread = kSelBins / kObsBlock;
     static_assert(kSelBins % kObsBlock == 0, "bins per thread");
     unsigned bb[kBinsPerThread] = {};
@@ -1179,8 +1193,10 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             bb[q] = c ? atomicAdd(&hist[tid + q * kObsBlock], c) : 0u;
         }
     }
+    VBA_OSTAMP(5);
     const double t = block_sum<kObsBlock>(s, red);
     if (tid == 0) V.part_trial[(size_t)w * V.trial_stride + part_slot] = t;
+    VBA_OSTAMP(6);
     if (FORM && !obs_block) {
         const unsigned long long bp = __ballot(bad & 1u), bn = __ballot(bad & 2u);
         if ((tid & 63) == 0 && (bp || bn)) atomicOr(&sc.fl[par], (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
@@ -1195,6 +1211,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
 #pragma unroll
             for (int q = 0; q < kBinsPerThread; ++q) lh[tid + q * kObsBlock] = bb[q];
             __syncthreads();
+            VBA_OSTAMP(7);
             if (kvalid) {
                 double* pool = V.wbucket + ((size_t)w * 2 + (par ^ 1)) * kSelBins * (size_t)V.bucket_cap;
 #pragma unroll
@@ -1203,6 +1220,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
                     if (kbin[q] >= 1u && kbin[q] <= 2046u && slot < (unsigned)V.bucket_cap) pool[(size_t)kbin[q] * V.bucket_cap + slot] = kkey[q];
                 }
             }
+            VBA_OSTAMP(8);
         } else {
             for (int b = tid; b < kEmitBins; b += kObsBlock) {
                 const unsigned c = lh[b];
