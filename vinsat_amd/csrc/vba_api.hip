@@ -173,6 +173,13 @@ const volatile WinHead* head(vba_handle h, int w) { return h->h_head + w; }
 // The second stream of handles with many windows carries the dynamics factor beside the streaming observation kernels.
 // VBA_AUX_PRIO (diagnostic): 1 = highest priority, -1 = lowest, unset / 0 = default.
 hipError_t create_aux_stream(hipStream_t* s) {
+    // VBA_AUX_CUMASK (diagnostic): hex word repeated over the 8 x 32 compute units, e.g. 11111111 = every fourth one
+    if (const char* m = std::getenv("VBA_AUX_CUMASK")) {
+        const uint32_t word = (uint32_t)std::strtoul(m, nullptr, 16);
+        uint32_t mask[8];
+        for (auto& x : mask) x = word;
+        return hipExtStreamCreateWithCUMask(s, 8, mask);
+    }
     const char* e = std::getenv("VBA_AUX_PRIO");
     const int want = e ? std::atoi(e) : 0;
     if (want == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
