@@ -214,15 +214,91 @@ __device__ __forceinline__ unsigned* histd_of(const DevView& V, int w, int digit
 
 // ------------------------------------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, kWave); }
+// The same exchange for a mask known at compile time: partners one or two lanes apart sit in the same quad, and a quad
+// permutation is a DPP move per 32 bits (~8 cycles) where the general shuffle is a round trip through the LDS crossbar
+// (ds_bpermute).  Same partner, same value: same bits.
+template <int MASK>
+__device__ __forceinline__ double shfl_xor_f64_c(double v) {
+#ifndef VBA_SHFL_BPERMUTE
+    if constexpr (MASK == 1 || MASK == 2) {
+        constexpr int ctrl = MASK == 1 ? 0xB1 : 0x4E;       // quad_perm [1,0,3,2] / [2,3,0,1]
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, ctrl, 0xf, 0xf, false);
+        const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), ctrl, 0xf, 0xf, false);
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    if constexpr (MASK == 4 || MASK == 8) {
+        // partners four / eight lanes apart sit in the same row of 16: a row shift to the left for the lanes whose bit is
+        // clear, to the right for the others -- two DPP moves into one register, each writing its own banks of four lanes
+        constexpr int shl = 0x100 + MASK, shr = 0x110 + MASK;
+        constexpr int lo_banks = MASK == 4 ? 0x5 : 0x3, hi_banks = MASK == 4 ? 0xA : 0xC;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const int x0 = (int)(unsigned)b, x1 = (int)(unsigned)(b >> 32);
+        int r0 = __builtin_amdgcn_update_dpp(0, x0, shl, 0xf, lo_banks, false);
+        r0 = __builtin_amdgcn_update_dpp(r0, x0, shr, 0xf, hi_banks, false);
+        int r1 = __builtin_amdgcn_update_dpp(0, x1, shl, 0xf, lo_banks, false);
+        r1 = __builtin_amdgcn_update_dpp(r1, x1, shr, 0xf, hi_banks, false);
+        return __longlong_as_double((long long)(((unsigned long long)(unsigned)r1 << 32) | (unsigned)r0));
+    }
+    if constexpr (MASK == 16 || MASK == 32) {
+        // partners in another row / the other half of the wavefront: gfx950's lane-swap instructions.  With both operands
+        // the same value, v_permlane32_swap leaves (low half, low half) in the first result and (high half, high half) in
+        // the second -- a lane's partner value is in the second if it sits in the low half, in the first otherwise;
+        // v_permlane16_swap does the same with rows 0 / 2 against rows 1 / 3
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned x0 = (unsigned)b, x1 = (unsigned)(b >> 32);
+        const bool low = (__lane_id() & MASK) == 0;
+        unsigned r0, r1;
+        if constexpr (MASK == 32) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(x0, x0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(x1, x1, false, false);
+            r0 = low ? s0[1] : s0[0];
+            r1 = low ? s1[1] : s1[0];
+        } else {
+            const auto s0 = __builtin_amdgcn_permlane16_swap(x0, x0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(x1, x1, false, false);
+            r0 = low ? s0[1] : s0[0];
+            r1 = low ? s1[1] : s1[0];
+        }
+        return __longlong_as_double((long long)(((unsigned long long)r1 << 32) | r0));
+    }
+#endif
+    return __shfl_xor(v, MASK, kWave);
+}
 
-__device__ __forceinline__ double wave_sum(double v) {
+// Inclusive prefix sum over the wavefront (integers: any order is exact).  Four row shifts inside each row of 16 lanes, then
+// the last lane of a row broadcast into the next row (row_bcast15, rows 1 and 3) and lane 31 into the upper half
+// (row_bcast31): six DPP additions where the __shfl_up form is six round trips through the LDS crossbar.
+__device__ __forceinline__ unsigned wave_inclusive_scan_u32(unsigned v) {
+#ifndef VBA_SHFL_BPERMUTE
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1 (a lane without a source keeps the 0)
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast31 into rows 2 and 3
+    return v;
+#else
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += shfl_xor_f64(v, o);
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(v, o, kWave);
+        if (lane >= o) v += t;
+    }
+    return v;
+#endif
+}
+
+// (six dependent exchanges: as LDS-crossbar shuffles ~0.4 us per call of either; same partners in the same order through
+// shfl_xor_f64_c, so the same bits)
+__device__ __forceinline__ double wave_sum(double v) {
+    v += shfl_xor_f64_c<32>(v); v += shfl_xor_f64_c<16>(v); v += shfl_xor_f64_c<8>(v);
+    v += shfl_xor_f64_c<4>(v); v += shfl_xor_f64_c<2>(v); v += shfl_xor_f64_c<1>(v);
     return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, shfl_xor_f64(v, o));
+    v = fmax(v, shfl_xor_f64_c<32>(v)); v = fmax(v, shfl_xor_f64_c<16>(v)); v = fmax(v, shfl_xor_f64_c<8>(v));
+    v = fmax(v, shfl_xor_f64_c<4>(v)); v = fmax(v, shfl_xor_f64_c<2>(v)); v = fmax(v, shfl_xor_f64_c<1>(v));
     return v;
 }
 
@@ -331,12 +407,7 @@ __device__ __forceinline__ void select_resolve_loaded(const unsigned (&loc)[8], 
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += loc[j];
     // inclusive scan over 256 threads: wave scan + 4 wave totals
-    unsigned inc = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        unsigned v = __shfl_up(inc, o, kWave);
-        if ((t & 63) >= o) inc += v;
-    }
+    const unsigned inc = wave_inclusive_scan_u32(s);
     if ((t & 63) == 63) lds_u[t >> 6] = inc;
     if (t == 0) { lds_u[8] = 0; lds_u[9] = 0; lds_u[10] = 0; }
     __syncthreads();

@@ -335,12 +335,7 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
             if (have && warm_bin(f64_bits(kk[it].y), lo, V.warm_shift) == bin) mbits |= 2ull << (2 * it);
         }
         const unsigned mine = (unsigned)__popcll(mbits);
-        unsigned inc = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned v = __shfl_up(inc, o, kWave);
-            if ((t & 63) >= o) inc += v;
-        }
+        const unsigned inc = wave_inclusive_scan_u32(mine);
         __syncthreads();            // lds_u was read by the resolve above
         if ((t & 63) == 63) lds_u[t >> 6] = inc;
         __syncthreads();
@@ -422,12 +417,7 @@ __device__ __forceinline__ double select_finish_list(const DevView& V, int w, co
         }
         __syncthreads();
         const unsigned c = lh[t];
-        unsigned inc = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned v = __shfl_up(inc, o, kWave);
-            if ((t & 63) >= o) inc += v;
-        }
+        const unsigned inc = wave_inclusive_scan_u32(c);
         if ((t & 63) == 63) lds_u[t >> 6] = inc;
         __syncthreads();
         unsigned base = 0;
@@ -604,6 +594,23 @@ constexpr int kAccDepth = VBA_ACC_DEPTH;
 // whole 128-byte lines (G = 8) instead of half lines whose other half is fetched again by the next step.
 // BATCH: the variant of handles with many windows -- the median is in sc.c_obs already (k_select_finish), nothing rides in
 // the grid and nothing is selected inline, so none of that code (nor its registers: the rider alone needs ~195) is compiled in.
+// The steps of the recursive-halving reduction of k_obs_accumulate (see there), unrolled over a compile-time mask so that the
+// first two exchanges (24 of the 31 values that travel) are quad permutations instead of LDS-crossbar shuffles.
+template <int G, int CNT, int MASK>
+__device__ __forceinline__ void halving_steps(double (&acc)[32], int sub, int& own) {
+    if constexpr (MASK < G && CNT > 1) {
+        const bool up = (sub & MASK) != 0;
+        constexpr int half = CNT >> 1;
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+            const double lo = acc[j], hi = acc[half + j];
+            acc[j] = (up ? hi : lo) + shfl_xor_f64_c<MASK>(up ? lo : hi);
+        }
+        if (up) own += half;
+        halving_steps<G, (CNT >> 1), (MASK << 1)>(acc, sub, own);
+    }
+}
+
 template <int G, bool PAIR, bool BATCH>
 __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     __shared__ double wmx[4];
@@ -908,20 +915,8 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     // shuffles for the (padded) 32 values instead of 27 per butterfly step; afterwards every lane owns the totals of
     // 32 / min(G, 32) consecutive values.  The shape is fixed by G, so the sums are bit reproducible.
     int own = 0;
-#pragma unroll
-    for (int cnt = 32, mask = 1; mask < G && cnt > 1; cnt >>= 1, mask <<= 1) {
-        const bool up = (sub & mask) != 0;
-        const int half = cnt >> 1;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j < half) {
-                const double lo = acc[j], hi = acc[half + j];
-                acc[j] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, mask);
-            }
-        }
-        if (up) own += half;
-    }
-    if (G == 64) acc[0] += shfl_xor_f64(acc[0], 32);
+    halving_steps<G, 32, 1>(acc, sub, own);
+    if (G == 64) acc[0] += shfl_xor_f64_c<32>(acc[0]);
     if (i < n && sub < 32) {
         double* H = V.Hraw + pb * 21;
         double* B = V.braw + pb * 6;
