@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_select_pass(DevView V) {
                 const int leader = __ffsll((long long)mask) - 1;
                 unsigned base = 0;
                 if (lane == leader) base = atomicAdd(&V.sc[w].sel_cnt, (unsigned)__popcll(mask));
-                base = __shfl(base, leader, kWave);
+                base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);      // (leader is uniform: one v_readlane, not a crossbar shuffle)
                 if (match) {
                     const unsigned off = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
                     // the list has room for 2 m_max keys; if more match (massive ties) select_finish sees
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_select_warm(DevView V) {
             const int leader = __ffsll((long long)mask) - 1;
             unsigned base = 0;
             if (lane == leader) base = atomicAdd(&sc.sel_cnt, (unsigned)__popcll(mask));
-            base = __shfl(base, leader, kWave);
+            base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);      // (leader is uniform: one v_readlane, not a crossbar shuffle)
             if (match) V.ckeys[2 * (size_t)w * V.m_max + base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = bits_f64(key);
         }
     };
