@@ -29,4 +29,6 @@ for it in range(13):
     _lib.check(e.lib.vba_debug_fetch(e.h, 0, 102, _p(out), out.size, byref(cnt)), e.lib)
     t = out.view(np.uint64).astype(np.int64)
     print(f"call {it}:", "  ".join(f"{nm} {(t[i] - t[0]) * 0.01:.2f}" for i, nm in enumerate(names)), flush=True)
+    an = ["entry", "loads requested", "median there", "rows done", "sums rotated", "reduced + stored", "end"]
+    print(f"   accumulation, block 60:", "  ".join(f"{nm} {(t[16 + i] - t[16]) * 0.01:.2f}" for i, nm in enumerate(an)), flush=True)
 e.close()

@@ -594,6 +594,17 @@ constexpr int kAccDepth = VBA_ACC_DEPTH;
 // whole 128-byte lines (G = 8) instead of half lines whose other half is fetched again by the next step.
 // BATCH: the variant of handles with many windows -- the median is in sc.c_obs already (k_select_finish), nothing rides in
 // the grid and nothing is selected inline, so none of that code (nor its registers: the rider alone needs ~195) is compiled in.
+// Diagnostic builds (-DVBA_RESIDENT_STAMPS; tools/trial_stamps.py): 100 MHz wall-clock stamps of thread 0 of observation
+// block 100 along k_trial, fetched with vba_debug_fetch(h, 0, 102, ...).
+#ifdef VBA_RESIDENT_STAMPS
+__device__ unsigned long long g_ostamps[64];
+#define VBA_OSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x == 100 && blockIdx.y == 0) g_ostamps[slot] = wall_clock64(); } while (0)
+#define VBA_ASTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x == 60 && blockIdx.y == 0) g_ostamps[16 + (slot)] = wall_clock64(); } while (0)
+void fetch_ostamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ostamps), sizeof(g_ostamps)); }
+#else
+#define VBA_OSTAMP(slot) do {} while (0)
+#define VBA_ASTAMP(slot) do {} while (0)
+#endif
 // The steps of the recursive-halving reduction of k_obs_accumulate (see there), unrolled over a compile-time mask so that the
 // first two exchanges (24 of the 31 values that travel) are quad permutations instead of LDS-crossbar shuffles.
 template <int G, int CNT, int MASK>
@@ -677,6 +688,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     }
     const int n = V.n[w];
     if (blockIdx.x * PPB >= n) return;
+    VBA_ASTAMP(0);
     const StepParams& prm = V.prm;
     const int sub = threadIdx.x % G;
     const size_t ob = (size_t)w * V.obs_stride;
@@ -763,6 +775,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     }
 
     // Phase 2: the median (every block of the window finishes the select itself, see select_finish)
+    VBA_ASTAMP(1);
     RobustParams rp;
     if (BATCH) {
         rp.c = sc.c_obs;        // k_select_finish
@@ -794,6 +807,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             for (int b = threadIdx.x; b < kSelBins; b += 256) h0[b] = 0u;
         }
     }
+    VBA_ASTAMP(2);
     rp.inv_c = 1.0 / rp.c;
     rp.inv_c2 = 1.0 / (rp.c * rp.c);
     rp.am2 = prm.am2;
@@ -889,6 +903,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             }
         }
     }
+    VBA_ASTAMP(3);
     if (CAM) {
         // the lane's camera-frame sums into the world frame (sums are linear, so before the reduction):
         //   Htt = R M R^T, Htr = -R T, bt = -R st   (Jt = -A R^T; R[c][j] = pc.R[3 c + j])
@@ -914,6 +929,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     // values that bit s of its lane index selects and receives the partner's partial sums of that half -- 16 + 8 + 4 + 2 + 1
     // shuffles for the (padded) 32 values instead of 27 per butterfly step; afterwards every lane owns the totals of
     // 32 / min(G, 32) consecutive values.  The shape is fixed by G, so the sums are bit reproducible.
+    VBA_ASTAMP(4);
     int own = 0;
     halving_steps<G, 32, 1>(acc, sub, own);
     if (G == 64) acc[0] += shfl_xor_f64_c<32>(acc[0]);
@@ -928,6 +944,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
             else if (q < 27) B[q - 21] = acc[j];
         }
     }
+    VBA_ASTAMP(5);
     if (!BATCH) break;
     }       // groups of this block
     wmax_l = wave_max(wmax_l);
@@ -937,6 +954,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
         const double mx = fmax(fmax(wmx[0], wmx[1]), fmax(wmx[2], wmx[3]));
         atomicMax(&sc.wmax_bits[V.par], f64_bits(mx));     // positive doubles order like their bit patterns
     }
+    VBA_ASTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------- A8: trial residuals
@@ -952,15 +970,6 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 // partitioned solve), 16 lanes per pose: an observation block for the poses its rows belong to (a handful), a pose-chain
 // block for 16 poses = 15 edges, which also writes states_new / dpose for everybody after this kernel; 3 = the geometry
 // of 1 / 2 with the trial states read from memory (a call of such a handle that cannot fuse: pivoted landmark-only solve).
-// Diagnostic builds (-DVBA_RESIDENT_STAMPS; tools/trial_stamps.py): 100 MHz wall-clock stamps of thread 0 of observation
-// block 100 along k_trial, fetched with vba_debug_fetch(h, 0, 102, ...).
-#ifdef VBA_RESIDENT_STAMPS
-__device__ unsigned long long g_ostamps[64];
-#define VBA_OSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x == 100 && blockIdx.y == 0) g_ostamps[slot] = wall_clock64(); } while (0)
-void fetch_ostamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ostamps), sizeof(g_ostamps)); }
-#else
-#define VBA_OSTAMP(slot) do {} while (0)
-#endif
 constexpr int kEdgesPerBlock16 = 15;
 
 // PART (many windows per launch, FUSED 0): 0 = one grid does both kinds of block; 1 = the observation blocks only, 2 = the
