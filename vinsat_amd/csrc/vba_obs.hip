@@ -633,6 +633,16 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     const int w = blockIdx.y;
     WinScalars& sc = V.sc[w];
     if (BATCH) { V.sel_inline = 0; V.dyn_in_acc = 0; V.median_ready = 1; }
+    // The row range of this thread's pose, requested FIRST of all (its address needs the block and thread index only; the
+    // index is clamped into the window's n_max + 1 entries): the range is a dependent round trip in front of the first
+    // observation loads, and this way it runs beside the call snapshot's instead of behind it.
+    int early_beg = 0, early_end = 0;
+    if (!BATCH) {
+        const int ie = min((int)(blockIdx.x * PPB + threadIdx.x / G), V.n_max - 1);
+        const int* ptr0 = V.pose_ptr + 2 * (size_t)w * V.obs_stride;
+        early_beg = ptr0[ie];
+        early_end = ptr0[ie + 1];
+    }
     // Inline select (V.sel_inline: latency mode, carried keys in bin buckets): this kernel STARTS the call -- no select
     // kernel in front of it.  In a chained schedule its blocks evaluate the accept test of the call in front themselves
     // (warm_front) and go on only if that first trial was cleanly accepted.
@@ -747,13 +757,12 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     constexpr bool kPairDepth2 = BATCH && PAIR && VBA_ACC_PAIR_DEPTH == 2;     // two pairs in flight per lane (24 more VGPRs)
     if (i < n) {
         pose_camera(V.states + pb * 10, V.intr + pb * 4, pc);
-        const int* ptr = V.pose_ptr + 2 * ob;
         if (BATCH) {
             beg = pf_beg;
             end = pf_end;
         } else {
-            beg = ptr[i];
-            end = ptr[i + 1];
+            beg = early_beg;
+            end = early_end;
         }
         if (PAIR) {
             if (beg + 2 * sub < end) nxt = load2(beg + 2 * sub);
@@ -985,6 +994,16 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     __shared__ int lpose[FORM ? kObsBlock : 1];
     __shared__ unsigned wlead[FORM ? 4 : 1];
     const int w = blockIdx.y;
+    // The pose of this thread's row (and of the row in front of it), requested FIRST of all: the address needs the block and
+    // thread index only (clamped into the window's rows), and everything an observation block does hangs on it -- this way
+    // the round trip runs beside the one of the call counter instead of behind it.
+    int early_pose = 0, early_prev = 0;
+    if (PART != 2) {
+        const int64_t ke = min((int64_t)blockIdx.x * kObsBlock + threadIdx.x, V.m_max - 1);
+        const int* op = V.opose + 2 * (size_t)w * V.obs_stride;
+        early_pose = op[ke];
+        early_prev = op[ke > 0 ? ke - 1 : 0];
+    }
     VBA_SKIP_CALL(V, w);
     WinScalars& sc = V.sc[w];
     if (sc.done) return;
@@ -1039,12 +1058,12 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
         const int k = blockIdx.x * kObsBlock + tid;
         const size_t ob = (size_t)w * V.obs_stride, mb = (size_t)w * V.m_max;
         const bool have = k < m;
-        const int pose = have ? V.opose[2 * ob + k] : -1;
+        const int pose = have ? early_pose : -1;
         const double* stp = V.states_new + (sb + (have ? pose : 0)) * 10;
         if (FORM && fz) {
             // the poses of this block's rows (rows are pose sorted): the first row of every pose inside the block leads,
             // leaders are numbered in row order and 16 lanes form the trial state of each
-            const int prev = (have && tid > 0) ? V.opose[2 * ob + k - 1] : -2;
+            const int prev = (have && tid > 0) ? early_prev : -2;
             const bool lead = have && (tid == 0 || prev != pose);
             const unsigned long long lm = __ballot(lead);
             const int lane = tid & 63, wv = tid >> 6;
