@@ -998,7 +998,8 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     // thread index only (clamped into the window's rows), and everything an observation block does hangs on it -- this way
     // the round trip runs beside the one of the call counter instead of behind it.
     int early_pose = 0, early_prev = 0;
-    if (PART != 2) {
+    constexpr bool kEarlyPose = FUSED == 1 || FUSED == 2;      // (the streaming blocks of the batched mode keep their load where it was)
+    if (kEarlyPose && PART != 2) {
         const int64_t ke = min((int64_t)blockIdx.x * kObsBlock + threadIdx.x, V.m_max - 1);
         const int* op = V.opose + 2 * (size_t)w * V.obs_stride;
         early_pose = op[ke];
@@ -1058,7 +1059,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
         const int k = blockIdx.x * kObsBlock + tid;
         const size_t ob = (size_t)w * V.obs_stride, mb = (size_t)w * V.m_max;
         const bool have = k < m;
-        const int pose = have ? early_pose : -1;
+        const int pose = have ? (kEarlyPose ? early_pose : V.opose[2 * ob + k]) : -1;
         const double* stp = V.states_new + (sb + (have ? pose : 0)) * 10;
         if (FORM && fz) {
             // the poses of this block's rows (rows are pose sorted): the first row of every pose inside the block leads,
