@@ -73,6 +73,18 @@ int vba_device_count(int* count);
 /* Create a context on HIP device `device` able to hold `windows` windows of at most n_max poses and
  * m_max observations each.  Replaces nothing in the reference (it allocates per call). */
 int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* out);
+/* The same with the kernel set named by the caller.  A handle runs one of two kernel sets, fixed at creation because the
+ * device memory differs (bin buckets of the carried keys exist in latency mode only):
+ *   mode 1  latency mode: few kernels per call (select inside the accumulation, accept test folded into the next call, the
+ *           chunk elimination forms its own blocks, the trial kernel forms the step), 64 lanes per pose -- what a handle
+ *           whose windows cannot fill the chip by themselves wants;
+ *   mode 0  bandwidth mode: streaming kernels with few registers and many windows per launch;
+ *   mode -1 (what vba_create passes) chooses by the window count -- the switch point comes from the measured sweep over
+ *           W = 1 .. 4096 windows (bench.py "batched_sweep").
+ * Both modes give the same results to rounding (and the same bits for equal lanes per pose / solver settings). */
+int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode, vba_handle* out);
+/* *mode receives the kernel set of the handle (0 / 1 as above), *chunk the solver partition in use (0: sequential walk). */
+int vba_get_mode(vba_handle h, int* mode, int* chunk);
 int vba_destroy(vba_handle h);
 
 /* external != 0: run all work of this handle on the caller's HIP stream `hip_stream` (a hipStream_t; NULL is the

@@ -33,10 +33,10 @@ def _window(name):
     return od_pipe.prepare_window(det, orb)
 
 
-def _engine(win, windows=1, conf=None):
+def _engine(win, windows=1, conf=None, mode=-1):
     from vinsat_amd.engine import BAEngine
     n, m = win.time_idx.size, win.ii.size
-    e = BAEngine(n, m, windows=windows)
+    e = BAEngine(n, m, windows=windows, mode=mode)
     for w in range(windows):
         e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences if conf is None else conf, win.ii, n, window=w)
         e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx, window=w)
@@ -104,7 +104,7 @@ def test_batched_path_sixteen_c3_windows_stepped_vs_reference_states():
     iters, inits = [int(x) for x in g["iters"]], [bool(x) for x in g["initialize"]]
     W = 16
     conf3 = np.full_like(win.confidences, 3.0)
-    eng = _engine(win, windows=W)
+    eng = _engine(win, windows=W, mode=0)       # (the bandwidth-mode kernel set, as bench.py's 4096 windows run it)
     n = win.time_idx.size
     eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, conf3, win.ii, n, window=15)
     st_other = od_pipe.initial_guess(win, seed=7)
@@ -233,7 +233,7 @@ def test_batched_warm_select_gives_the_bits_of_the_exact_digit_passes(c2):
     W = 16
     res = {}
     for mode in ("exact", "warm-default", "warm-49", "warm-44"):
-        e = BAEngine(n, m, windows=W)
+        e = BAEngine(n, m, windows=W, mode=0)
         if mode == "exact":
             e.set_warm_select(0)
         elif mode != "warm-default":

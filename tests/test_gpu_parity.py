@@ -1317,7 +1317,7 @@ def test_batched_walk_forming_its_own_blocks_gives_the_bits_of_the_assembled_pat
     iters, inits = list(range(20)), [k < 10 for k in range(20)]
     outs, dbg = [], []
     for mask in (1, 5):
-        e = BAEngine(n, m, windows=W)
+        e = BAEngine(n, m, windows=W, mode=0)
         e.set_fusion(mask)
         e.set_solver(solver)
         for k in range(W):
@@ -1385,7 +1385,7 @@ def test_uniform_pass_assembly_gives_the_bits_of_the_per_entry_form(c2, reg, win
     n, m = inp["K"].shape[0], inp["xyz"].shape[0]
     outs = []
     for mask in (1, 9):
-        e = BAEngine(n, m, windows=windows)
+        e = BAEngine(n, m, windows=windows, mode=1 if windows == 1 else 0)
         e.set_fusion(mask)
         for k in range(windows):
             e.upload_observations(inp["xyz"], inp["uv"], inp["conf"] * (1.0 + 0.01 * k), inp["ii"], n, window=k)

@@ -13,10 +13,18 @@ det, orb = synth.make_sequence("C3")
 win = od_pipe.prepare_window(det, orb)
 st0 = od_pipe.initial_guess(win)
 n, m = win.time_idx.size, win.ii.size
-e = BAEngine(n, m, windows=W)
+# VBA_MODE: lat / bw force the kernel set (default: the handle's own choice); VBA_SOLVER: part / seq force the solver
+mode = {"lat": 1, "bw": 0}.get(os.environ.get("VBA_MODE", ""), -1)
+e = BAEngine(n, m, windows=W, mode=mode)
+if os.environ.get("VBA_SOLVER") == "part":
+    e.set_solver(8, -1)
+elif os.environ.get("VBA_SOLVER") == "seq":
+    e.set_solver(0)
 for w in range(W):
     e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n, window=w)
     e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx, window=w)
+if os.environ.get("VBA_FUSION"):
+    e.set_fusion(int(os.environ["VBA_FUSION"]))
 iters, inits = list(range(20)), [k < 10 for k in range(20)]
 e.set_states(st0, 1e-4, window=-1)
 e.run_schedule(iters, inits)

@@ -22,6 +22,8 @@ SIGNATURES = {
     "vba_last_error": (c_char_p, []),
     "vba_device_count": (c_int, [POINTER(c_int)]),
     "vba_create": (c_int, [c_int, c_int, c_int, c_int64, POINTER(c_void_p)]),
+    "vba_create_mode": (c_int, [c_int, c_int, c_int, c_int64, c_int, POINTER(c_void_p)]),
+    "vba_get_mode": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "vba_destroy": (c_int, [c_void_p]),
     "vba_set_stream": (c_int, [c_void_p, c_void_p, c_int]),
     "vba_set_solver": (c_int, [c_void_p, c_int]),

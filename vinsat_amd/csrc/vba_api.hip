@@ -240,9 +240,45 @@ int vba_device_count(int* count) {
     return VBA_OK;
 }
 
+// Where the mode switches of a handle lie, chosen from the round-4 sweeps over W = 1 .. 4096 windows with the kernel set and the
+// solver forced (tools/mode_sweep.py; DESIGN.md section 7, bench.py "batched_sweep").  C3 windows (500 poses / 50 000 rows),
+// thousands of BA calls per second:
+//   W            1    2    4    8   12   16   22   28   32   48   64  128  256  512 1024 2048 4096
+//   latency     22   40   71  114  144  168  187  201  204    .  184  189  202  204    .    .    .   (best fusion mask, below)
+//   bandwidth    .   23   38   64  112  139  167  194  212  245  273  314  342  361  367    .  369   (partitioned solve)
+//   ... walk     .    2    4    9    .   17   23    .   34    .   63  114  187  277  366  435  479   (four windows per wavefront)
+// and C2 windows (100 poses / 5 000 rows): latency 107 / 379 / 606 / 943 / 1230 / 1446 / 1541 at W = 4 / 16 / 32 / 64 / 128 / 256 /
+// 512 against bandwidth 51 / 199 / 360 / 662 / 1145 / 1649 / 1931; walk against partitioned solve 954 : 1649 at 256 windows,
+// 2183 : 2071 at 1024, 3227 : 2259 at 4096.
+// * Kernel set: what fills the chip is ROWS, not windows -- the latency-mode kernels win up to ~1.6 million observation rows
+//   per launch (31 C3 windows, ~180 C2 windows; until round 4 the switch was at 16 windows whatever their size).
+// * Solver: the sequential walk is a latency chain per window (~2.2 ms at 500 poses whatever the window count) and pays only
+//   once ~1000 windows share it; below that the chains are cut into chunks (until round 4 the walk took over at 128 windows:
+//   3.3 ms per step at 256 windows where the partitioned solve needs 0.75).
+// * Inside latency mode the fusions that trade instructions for launches hold only while launches are what a call costs:
+//   up to 175 000 rows mask 15 (the trial kernel forms the step, the chunk elimination its blocks); up to 450 000 rows 14 (the
+//   trial kernel reads a step that a launch of its own formed: every observation block re-forming the steps of its poses costs
+//   more than that launch as soon as a few windows share the chip); beyond 12 (the assembly is a launch of its own as well).
+constexpr double kLatRowsMax = 1.6e6;
+constexpr int kLatWindowsCap = 192;             // (33 MB of bin buckets per C3 window; per-window prologues)
+constexpr int kPartitionedWindowsMax = 1023;
+static bool default_latency_mode(int windows, int64_t m_max) {
+    return windows == 1 || (windows <= kLatWindowsCap && (double)windows * (double)m_max <= kLatRowsMax);
+}
+static int default_fusion(bool lat, int windows, int64_t m_max) {
+    const double rows = (double)windows * (double)m_max;
+    return (!lat || windows == 1) ? 15 : rows <= 175e3 ? 15 : rows <= 450e3 ? 14 : 12;      // (one window: as measured in rounds 2 and 3; the pipelined BA() loop needs bit 0)
+}
+
 int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* out) {
+    return vba_create_mode(device, windows, n_max, m_max, -1, out);
+}
+
+int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode, vba_handle* out) {
     if (!out) return fail(VBA_EINVAL, "null out");
     *out = nullptr;
+    if (mode < -1 || mode > 1) return fail(VBA_EINVAL, "mode must be -1 (automatic), 0 (bandwidth-mode kernels) or 1 (latency-mode kernels)");
+    const bool lat = mode == -1 ? default_latency_mode(windows, m_max) : mode == 1;
     if (windows < 1 || n_max < 2 || m_max < 1) return fail(VBA_EINVAL, "need windows >= 1, n_max >= 2, m_max >= 1");
     if (m_max > (int64_t)1 << 30) return fail(VBA_EINVAL, "m_max too large");
     int cnt = 0;
@@ -280,9 +316,9 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     // histogram costs a global atomic per bin it touched, coarser bins contend in LDS and lengthen the list the single pass
     // (k_select_warm) compacts and k_select_finish ranks -- about half a per cent of the keys here.  Swept 44 .. 51 at
     // 4096 x C3: 10.53 / 9.94 / 9.85 / 9.87 / 9.90 / 9.94 / 10.03 ms per step for 44 .. 50 (exact two-pass select: 10.12)
-    const int warm_shift = windows >= 16 ? 46 : (2 * m_max <= 300000 ? 44 : 43);
+    const int warm_shift = !lat ? 46 : (2 * m_max <= 300000 ? 44 : 43);
     int bucket_cap = 0;
-    if (windows < 16) {
+    if (lat) {
         const double expect = 2.0 * (double)m_max * (warm_shift == 44 ? 0.0013 : 0.00065) * 6.0;
         bucket_cap = 256;
         while (bucket_cap < expect && bucket_cap < 4096) bucket_cap *= 2;
@@ -357,7 +393,7 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
     V.hop = 0; V.pivot = 0; V.call = -1; V.emit = 0; V.carry = 0; V.dyn_in_acc = 0;
     V.par = 0; V.fold = 0; V.redo = 0; V.fused_trial = 0; V.pending_only = 0; V.warm_force_miss = 0;
-    V.lat = windows < 16 ? 1 : 0;       // latency mode: few windows cannot fill the chip, the kernel COUNT of a call is what costs
+    V.lat = lat ? 1 : 0;       // latency mode: few windows cannot fill the chip, the kernel COUNT of a call is what costs
     // warm bins: 2^44 bit patterns (1/256 of a binade, range [c/16, c*8)) while a bin of the median's density stays short,
     // 2^43 (1/512, [c/4, c*2)) for the big windows
     V.warm_shift = warm_shift;
@@ -381,11 +417,12 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     // to share them with
     for (int k = 0; k < 64; ++k) h->pred_iter[k] = h->pred_init[k] = -1;
     h->V.host_states = nullptr;
+    h->fusion = default_fusion(lat, windows, m_max);
     if ((windows == 1 && (hipEventCreateWithFlags(&h->ev_first, hipEventDisableTiming) != hipSuccess ||
                           hipHostMalloc((void**)&h->h_states_map, (size_t)2 * n_max * 10 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
                           hipHostGetDevicePointer((void**)&h->V.host_states, h->h_states_map, 0) != hipSuccess)) ||
         hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        (windows >= 16 && create_aux_stream(&h->aux_stream) != hipSuccess) ||
+        (!lat && create_aux_stream(&h->aux_stream) != hipSuccess) ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
@@ -410,8 +447,16 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
     // warm select everywhere; the accept test is folded into the next call's first kernel only in latency mode (with many
     // windows the decide launch is 20 us of a 10 ms step, and every block of the select would repeat the test)
     h->warm_enabled = 1;
-    h->fold_enabled = windows < 16;
+    h->fold_enabled = lat;
+    if (const char* e = std::getenv("VBA_X_FOLD")) h->fold_enabled = std::atoi(e) != 0;     // (experiment knob)
     *out = h;
+    return VBA_OK;
+}
+
+int vba_get_mode(vba_handle h, int* mode, int* chunk) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (mode) *mode = h->V.lat;
+    if (chunk) *chunk = h->V.chunk;
     return VBA_OK;
 }
 
@@ -462,7 +507,7 @@ int vba_set_solver(vba_handle h, int chunk) {
     if (chunk == -1) {      // default: many windows supply their own parallelism (one wave walks each chain);
         h->no_pack = 0;     // otherwise the chain is cut into chunks and the reduced system over the (at most 64)
                             // separators is solved by cyclic reduction in one workgroup; very long chains: two levels
-        if (h->W >= 128 || h->n_max < 8) { h->V.chunk = 0; return VBA_OK; }
+        if (h->W > kPartitionedWindowsMax || h->n_max < 8) { h->V.chunk = 0; return VBA_OK; }
         // <= 64 separators while that keeps the chunks at <= 8 poses, else up to 128 (their first reduction level runs
         // on its own CUs either way, see k_cr_level0)
         const int c64 = (h->n_max + 64) / 65, c128 = (h->n_max + 128) / 129;
@@ -894,7 +939,7 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     V.chunk_waves = h->chunk_waves;
     V.asm_rows = (h->fusion & 8) ? 1 : 0;
     V.cr_levels = (h->fusion & 16) ? 1 : 2;
-    V.fuse_walk = ((h->fusion & 4) && h->W >= 16) ? 1 : 0;
+    V.fuse_walk = ((h->fusion & 4) && !V.lat) ? 1 : 0;
 }
 
 // the kernels in front of the first LM trial; ev (profiled variant): events that bracket the kernel classes
@@ -906,7 +951,7 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
     V.sel_inline = 0;       // (a repeat of the front after a missed warm select takes the exact digits and the plain prologue)
     // the dynamics factor depends only on the states: with few windows its blocks ride in the accumulation's grid (no
     // second stream, no cross-stream join), with many it runs beside the observation kernels on a second stream
-    const bool ride = !init && !c.prof && h->W < 16;
+    const bool ride = !init && !c.prof && V.lat;
     V.dyn_in_acc = ride ? 1 : 0;
     static const bool no_overlap = std::getenv("VBA_NO_OVERLAP") != nullptr;     // diagnostic: dynamics in line on the main stream
     const bool overlap = !init && !c.prof && !ride && !no_overlap;
@@ -941,7 +986,7 @@ int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat
         launch_select(V, true, s);
     }
     if (fork_late) { if (int rc = fork_dynamics()) return rc; }
-    V.median_ready = (!V.sel_inline && h->W >= 16) ? 1 : 0;
+    V.median_ready = (!V.sel_inline && !V.lat) ? 1 : 0;
     if (V.median_ready) launch_select_finish(V, s);
     mark(3);
     launch_obs_accumulate(V, s);

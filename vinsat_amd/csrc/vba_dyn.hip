@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_assemble_rows(DevView V) {
 }
 
 void launch_dynamics(const DevView& V, hipStream_t s) {
-    if (V.W >= 16) {
+    if (!V.lat) {
         hipLaunchKernelGGL(k_dynamics_pair, dim3((V.n_max + 127) / 128, V.W), dim3(256), 0, s, V);
         return;
     }
@@ -309,12 +309,12 @@ void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s) {
 #define VBA_ASM_BATCHED 16
 #endif
     const bool reg = V.reg && !V.prm.initialize;
-    if (fuse_init_solve && V.W >= 16) {     // (few windows: the 16-lanes-per-pose form below, latency)
+    if (fuse_init_solve && !V.lat) {     // (few windows: the 16-lanes-per-pose form below, latency)
         hipLaunchKernelGGL(k_init_step, dim3((V.n_max + 255) / 256, V.W), dim3(256), 0, s, V);
         return;
     }
     const bool rows = !V.prm.initialize && !fuse_init_solve && V.asm_rows;     // full phase: the uniform-pass form
-    if (V.W >= 16) {
+    if (!V.lat) {
         constexpr int P = VBA_ASM_BATCHED;
         const dim3 g((V.n_max + P - 1) / P, V.W);
         if (rows) {

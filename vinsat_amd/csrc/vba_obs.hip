@@ -21,6 +21,7 @@
 // All of these stream the observation arrays once, coalesced (SoA, 8 B per lane per array); the pose state
 // is gathered through L1/L2 (observations are pose sorted, so a wave touches one or two poses).
 #include "vba_decide.h"
+#include <cstdlib>
 #include "vba_device.h"
 #include "vba_dyn_body.h"
 #include "vba_launch.h"
@@ -1340,7 +1341,7 @@ void launch_obs_residual(const DevView& V, double* abs_out, hipStream_t s) {
 void launch_select(const DevView& V, bool with_digit0, hipStream_t s) {
     const int64_t count = V.abs_all ? V.abs_all_count : 2 * V.m_max;
     const dim3 b(256);
-    if (V.W >= 16) {
+    if (!V.lat) {
         const int nb = (int)((count + 256 * 32 - 1) / (256 * 32));
         const dim3 g(nb > 0 ? nb : 1, V.W);
         if (with_digit0) hipLaunchKernelGGL((k_select_pass<0, false, 32>), g, b, 0, s, V);
@@ -1358,7 +1359,7 @@ void launch_select(const DevView& V, bool with_digit0, hipStream_t s) {
 // warm select on carried keys: one pass (plus, V.fold, the accept test of the call in front)
 void launch_select_warm(const DevView& V, hipStream_t s) {
     const int64_t count = 2 * V.m_max;
-    if (V.W >= 16) {
+    if (!V.lat) {
 #ifndef VBA_SELW_ITEMS
 #define VBA_SELW_ITEMS 32
 #endif
@@ -1388,7 +1389,13 @@ void launch_obs_accumulate(const DevView& V, hipStream_t s) {
 #ifndef VBA_ACC_GROUPS
 #define VBA_ACC_GROUPS 4
 #endif
-        const dim3 gb((nb + VBA_ACC_GROUPS - 1) / VBA_ACC_GROUPS, V.W);    // a block walks VBA_ACC_GROUPS groups of poses
+        // a block walks up to VBA_ACC_GROUPS groups of poses (its grid stride) -- fewer when the windows of the handle would
+        // otherwise leave compute units without a block (the chip holds 512 of these blocks at once)
+        static const int groups_env = std::getenv("VBA_X_ACCGROUPS") ? std::atoi(std::getenv("VBA_X_ACCGROUPS")) : 0;
+        int groups = VBA_ACC_GROUPS;
+        while (groups > 1 && (int64_t)V.W * ((nb + groups - 1) / groups) < 2048) groups >>= 1;
+        if (groups_env > 0) groups = groups_env;
+        const dim3 gb((nb + groups - 1) / groups, V.W);
         if (G == 8) hipLaunchKernelGGL((k_obs_accumulate<8, kPair, true>), gb, b, 0, s, V);
         else hipLaunchKernelGGL((k_obs_accumulate<16, false, true>), gb, b, 0, s, V);
         return;
@@ -1406,7 +1413,7 @@ template <int EMIT>
 static void launch_trial_emit(const DevView& V, hipStream_t s) {
     const dim3 g(V.nblk_obs + V.nblk_dyn, V.W), b(kObsBlock);
     const int f = V.fused_trial;        // 0..3, see k_trial; V.nblk_dyn is the pose-chain block count of that geometry
-    if (f == 0 && V.W >= 16 && !V.wbucket) {        // many windows: the two kinds of block as two launches
+    if (f == 0 && !V.lat && !V.wbucket) {        // many windows: the two kinds of block as two launches
         hipLaunchKernelGGL((k_trial<EMIT, 0, 2>), dim3(V.nblk_dyn, V.W), b, 0, s, V);
         hipLaunchKernelGGL((k_trial<EMIT, 0, 1>), dim3(V.nblk_obs, V.W), b, 0, s, V);
         return;

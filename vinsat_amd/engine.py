@@ -27,10 +27,12 @@ def _p(a):
 class BAEngine:
     """Device-resident bundle-adjustment context holding ``windows`` independent windows."""
 
-    def __init__(self, n_max, m_max, windows=1, device=0):
+    def __init__(self, n_max, m_max, windows=1, device=0, mode=-1):
+        """``mode``: -1 = kernel set chosen by the window count, 0 = bandwidth-mode kernels, 1 = latency-mode kernels
+        (``vba_create_mode``)."""
         self.lib = _lib.load()
         self.h = c_void_p()
-        _lib.check(self.lib.vba_create(device, windows, int(n_max), int(m_max), byref(self.h)), self.lib)
+        _lib.check(self.lib.vba_create_mode(device, windows, int(n_max), int(m_max), int(mode), byref(self.h)), self.lib)
         self.windows = windows
         self.n = [0] * windows
         self.m = [0] * windows
@@ -48,6 +50,12 @@ class BAEngine:
             self.close()
         except Exception:
             pass
+
+    def mode(self):
+        """(kernel set: 1 latency / 0 bandwidth, chunk size of the solver partition: 0 = sequential walk)."""
+        a, b = c_int(), c_int()
+        _lib.check(self.lib.vba_get_mode(self.h, byref(a), byref(b)), self.lib)
+        return a.value, b.value
 
     def set_solver(self, chunk, chunk2=None):
         """0 = sequential chain, 2..60 = partitioned with that chunk size (chunk2: second-level chunk size, or -1 =
