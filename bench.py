@@ -26,7 +26,9 @@ timings on the library's stream; "whole_call" = SURVEY's algorithmic bytes of a 
 matrix-core counters of the solve kernels from the committed PMC pass), "cpu_baseline" (the NumPy oracle on ALL host
 cores of this box, one single-threaded worker process per core over independent windows, bounded sample),
 "python_BA_call" (the drop-in vinsat_amd.ba.BA in the reference's loop shape), "host_roundtrip" (vba_iterate),
-"batched" (W windows per launch: the HBM-bound regime), "kernels_ms" (per-kernel-class averages).
+"batched" (4096 windows per launch: the HBM-bound regime), "batched_sweep" (W = 1 .. 4096 windows per handle, kernel set and
+solver chosen by the handle), "python_BA_batch" (22 windows through BA / BA_window on lists), "configs" (C2, C4, C5 and the
+two-pass window with either integrator), "chain_classes_ms" / "phase_ms" (class and phase times of the chained schedule).
 """
 from __future__ import annotations
 
@@ -89,7 +91,10 @@ def parse():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--windows", type=int, default=4096, help="windows per launch of the batched series (0 = skip)")
     ap.add_argument("--batched-steps", type=int, default=40)
-    ap.add_argument("--profile-tag", default="r03", help="profiles/<tag>_w1_traffic.json / _mfma.json supply roofline.traffic / .mfma")
+    ap.add_argument("--sweep", default="1,2,4,8,15,16,22,32,64,128,256,1024", help="window counts of the batched_sweep series (the "
+                    "--windows handle joins it); empty = skip")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config series (C2, C4, C5, gap window)")
+    ap.add_argument("--profile-tag", default="r04", help="profiles/<tag>_w1_traffic.json / _mfma.json supply roofline.traffic / .mfma")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = every core of this box)")
     ap.add_argument("--no-sharded", action="store_true")
@@ -118,6 +123,83 @@ def run_steps(eng, st0, nsteps, windows=1):
         calls = [schedule(j) for j in range(cnt)]
         eng.run_schedule([c[0] for c in calls], [c[1] for c in calls])
         k += cnt
+
+
+def load_windows(eng, win, n, W):
+    for w in range(W):
+        eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n, window=w)
+        eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx, window=w)
+
+
+def sweep_point(BAEngine, win, st0, n, m, W, device, sync):
+    """W independent C3 windows on ONE handle with the handle's own choice of kernel set and solver: the chained 20-call
+    schedule, warmed once, then timed."""
+    e = BAEngine(n, m, windows=W, device=device)
+    load_windows(e, win, n, W)
+    run_steps(e, st0, 20, windows=W)
+    reps = 3 if W <= 256 else 1
+    sync()
+    t0 = time.perf_counter()
+    run_steps(e, st0, 20 * reps, windows=W)
+    sync()
+    dt = time.perf_counter() - t0
+    lat, chunk = e.mode()
+    e.close()
+    return {"windows": W, "value": 20 * reps * W / dt, "ms_per_step": 1e3 * dt / (20 * reps),
+            "kernel_set": "latency" if lat else "bandwidth", "solver": f"chunks of {chunk} + cyclic reduction" if chunk else "sequential walk, four windows per wavefront",
+            "whole_step_frac_survey_bytes": survey_bytes_per_call(n, m) * W / (dt / (20 * reps)) / 1e9 / HBM_PEAK_GBS}
+
+
+def config_series(BAEngine, od_pipe, synth, device, sync):
+    """The other BASELINE configs on one GPU (same function, other sizes: BA_filtering.py:4-98): one warmed chained 20-call
+    schedule each, plus the two-pass window whose dynamics factor spans a ~945 s gap with either integrator."""
+    out = {}
+    for name in ("C2", "C4", "C5"):
+        det, orb = synth.make_sequence(name)
+        win = od_pipe.prepare_window(det, orb)
+        st0 = od_pipe.initial_guess(win)
+        n, m = win.time_idx.size, win.ii.size
+        e = BAEngine(n, m, device=device)
+        load_windows(e, win, n, 1)
+        run_steps(e, st0, 20)
+        reps = 3
+        sync()
+        t0 = time.perf_counter()
+        run_steps(e, st0, 20 * reps)
+        sync()
+        ms = 1e3 * (time.perf_counter() - t0) / (20 * reps)
+        e.set_chain_profile(True)
+        run_steps(e, st0, 20)
+        cls = e.chain_profile()
+        e.close()
+        whole = survey_bytes_per_call(n, m)
+        out[name] = {"poses": int(n), "observations": int(m), "value": 1e3 / ms, "unit": "BA iterations/s", "ms_per_step": ms,
+                     "whole_call_bytes": whole, "whole_call_frac": whole / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "kernels_per_call": {"landmark_only": 2, "full": 5},
+                     "chain_classes_ms": {k: v[0] for k, v in cls.items()}}
+    # second batch of the two-pass sequence: 25 poses, one gap of ~945 s -- the RK4 chain of the dynamics factor IS the call
+    win = od_pipe.prepare_window(*synth.make_two_pass_sequence())
+    gap_states = od_pipe.initial_guess(win)
+    n, m = win.time_idx.size, win.ii.size
+    gap = {"poses": int(n), "observations": int(m), "longest_gap_s": int(np.diff(win.time_idx).max())}
+    for hop in (False, True):
+        e = BAEngine(n, m, device=device)
+        e.set_integrator(hop)
+        load_windows(e, win, n, 1)
+        iters, inits = list(range(20)), [False] * 20
+        e.set_states(gap_states, 1e-4)
+        e.run_schedule(iters, inits)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            e.set_states(gap_states, 1e-4)
+            e.run_schedule(iters, inits)
+        sync()
+        ms = 1e3 * (time.perf_counter() - t0) / 60
+        e.close()
+        gap["hop (predict_gpu, the reference's GPU default)" if hop else "rk4 (predict, the parity target)"] = {"value": 1e3 / ms, "ms_per_step": ms}
+    out["GAP"] = gap
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ launcher (N > 1)
@@ -393,32 +475,34 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt200 = float(t.item())
 
-    # ---- per-kernel-class timing with HIP events on the library's stream (same steps, right after the timed region).
-    # NOTE: this is the SERIALISED schedule of vba_step_profiled (an event record between classes, the dynamics factor
-    # as its own launch instead of riding in the accumulation's grid, one host call per BA call), not the chained
-    # schedule the headline value is timed on; rocprofv3 --kernel-trace of this same command (profiles/<tag>_w1_*)
-    # gives the kernels of the chained run.
-    kern = {k: [] for k in BAEngine.KERNELS}
+    # ---- class times of the CHAINED schedule (the one `value` is timed on), HIP events on the library's stream at the class
+    # boundaries of every call (vba_set_chain_profile): accumulate (select and the previous call's accept test folded in),
+    # solve (chunk elimination + cyclic reduction), trial.  The markers cost ~1 us each, so this pass follows the timed one.
+    eng.set_chain_profile(True)
+    eng.chain_profile(reset=True)
+    run_steps(eng, st0, max(40, min(args.steps, 200) // 20 * 20))
+    torch.cuda.synchronize()
+    cls = eng.chain_profile(reset=True)
+    eng.set_chain_profile(False)
+    classes_ms = {k: v[0] for k, v in cls.items()}
+    class_calls = {k: v[1] for k, v in cls.items()}
+    # ... and the two phases of the schedule, each chained and timed by the wall clock around its ten calls
     phase = {"landmark_only": [], "full": []}
-    nprof = min(args.steps, 40)
-    for k in range(nprof):
-        it, init = schedule(k)
-        if it == 0:
-            eng.set_states(st0, 1e-4)
-        ms = eng.step_profiled(it, init)
-        for name, v in ms.items():
-            if v > 0:
-                kern[name].append(v)
-        phase["landmark_only" if init else "full"].append(sum(ms.values()))
-    kernels_ms = {k: (float(np.mean(v)) if v else 0.0) for k, v in kern.items()}
-    # the dominant class is chosen among the kernels the TIMED (chained) schedule consists of: there the dynamics factor
-    # rides in the accumulation's grid and residual / select / accept test are folded into their neighbours -- as classes
-    # of their own they exist in this serialised schedule only (where the dynamics launch, forked onto a second stream
-    # between two events, reads as 35-50 us for a 10 us kernel)
-    share = {k: kernels_ms[k] * len(kern[k]) for k in ("accumulate", "solve", "trial")}
+    for _ in range(5):
+        eng.set_states(st0, 1e-4)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        eng.run_schedule(list(range(10)), [True] * 10)
+        tb = time.perf_counter()
+        eng.run_schedule(list(range(10, 20)), [False] * 10)
+        tc = time.perf_counter()
+        phase["landmark_only"].append(1e3 * (tb - ta) / 10)
+        phase["full"].append(1e3 * (tc - tb) / 10)
+    # the dominant class by total time in the schedule
+    share = {k: classes_ms[k] * class_calls[k] for k in classes_ms}
     dom = max(share, key=share.get)
     alg = float(ALG_BYTES[dom](n, m))
-    achieved = alg / (kernels_ms[dom] * 1e-3) / 1e9
+    achieved = alg / (classes_ms[dom] * 1e-3) / 1e9
     # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_pmc.sh + tools/summarize_pmc.py:
     # 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md); a kernel class sums its kernels
     traffic = None
@@ -446,8 +530,8 @@ def run_rank(args):
     roofline = {"kernel": "solve class (chunk elimination + cyclic reduction of the separators + recovery)" if dom == "solve" else "k_" + dom,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
-                "avg_launch_ms": kernels_ms[dom], "launches_timed": len(kern[dom]),
-                "timing_source": "vba_step_profiled (serialised schedule, HIP events on the library's stream)",
+                "avg_launch_ms": classes_ms[dom], "launches_timed": class_calls[dom],
+                "timing_source": "HIP events on the library's stream at the class boundaries of the chained schedule (vba_set_chain_profile)",
                 "whole_call": {"bytes": whole, "achieved": whole / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                                "frac": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "note": "SURVEY 8(d) B_alg = 208 m + 5000 n over the timed (chained) ms_per_step"},
@@ -502,9 +586,7 @@ def run_rank(args):
     if args.windows > 0 and rank == 0 and world == 1 and not force_dist:
         W = args.windows
         be = BAEngine(n, m, windows=W, device=device)
-        for w in range(W):
-            be.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n, window=w)
-            be.upload_window(win.intrinsics, win.cumrot_last, win.time_idx, window=w)
+        load_windows(be, win, n, W)
         run_steps(be, st0, 20, windows=W)
         torch.cuda.synchronize()
         tb = time.perf_counter()
@@ -533,7 +615,10 @@ def run_rank(args):
         # (chained) ms per call -- not over the sum of the serialised per-class times
         step_bytes = sum(sum(v) for v in bbytes.values()) / 20.0 * W
         bms_step = 1e3 * dtb / args.batched_steps
+        blat, bchunk = be.mode()
         batched = {"windows": W, "value": W * args.batched_steps / dtb, "unit": "BA iterations/s", "steps": args.batched_steps,
+                   "kernel_set": "latency" if blat else "bandwidth",
+                   "solver": f"chunks of {bchunk} + cyclic reduction" if bchunk else "sequential walk, four windows per wavefront",
                    "ms_per_step": bms_step, "dominant_kernel": "k_" + bdom,
                    "roofline": {"kernel": "k_" + bdom, "bound": "hbm", "achieved": per_kernel[bdom]["GBps"], "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": per_kernel[bdom]["GBps"] / HBM_PEAK_GBS},
@@ -562,6 +647,66 @@ def run_rank(args):
             except Exception:
                 pass
         be.close()
+
+    # ---- the regime between one window and 4096: W windows per handle, the handle choosing kernel set and solver itself
+    sync = torch.cuda.synchronize
+    batched_sweep = configs = python_batch = None
+    if rank == 0 and world == 1 and not force_dist and args.sweep:
+        pts = []
+        for W in sorted({int(x) for x in args.sweep.split(",") if x}):
+            if W == 1:
+                pts.append({"windows": 1, "value": value, "ms_per_step": ms_per_step, "kernel_set": "latency",
+                            "solver": f"chunks of {eng.mode()[1]} + cyclic reduction",
+                            "whole_step_frac_survey_bytes": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS})
+            else:
+                pts.append(sweep_point(BAEngine, win, st0, n, m, W, device, sync))
+        if batched is not None and batched["windows"] not in [q["windows"] for q in pts]:
+            pts.append({"windows": batched["windows"], "value": batched["value"], "ms_per_step": batched["ms_per_step"],
+                        "kernel_set": batched["kernel_set"], "solver": batched["solver"],
+                        "whole_step_frac_survey_bytes": batched["whole_step_frac_survey_bytes"]})
+        pts.sort(key=lambda q: q["windows"])
+        vals = [q["value"] for q in pts]
+        batched_sweep = {"unit": "BA iterations/s", "workload": "W independent C3 windows on one handle, chained 20-call schedule",
+                         "points": pts, "monotone": all(b >= 0.97 * a for a, b in zip(vals, vals[1:])),
+                         "note": "kernel set and solver are the handle's own choice (vba_create_mode -1): latency-mode kernels up to "
+                                 "1.6M rows per launch, partitioned solve up to 1023 windows, see DESIGN.md section 7"}
+        # the same batch behind the reference's call surface: BA_window on lists of 22 windows (the reference's 22 sequences,
+        # od_pipe.py:1069-1077), arguments as the driver holds them
+        from vinsat_amd import ba as ba_mod
+        B = 22
+        imu1 = torch.zeros((1, n, 1, 10), dtype=torch.float64)
+        imu1[0, :, 0, 6:10] = torch.from_numpy(win.cumrot_last)
+        one = dict(states=torch.from_numpy(st0)[None], vel=torch.from_numpy(win.velocities)[None], imu=imu1,
+                   uv=torch.from_numpy(win.landmarks_uv)[None], xyz=torch.from_numpy(win.landmarks_xyz)[None],
+                   intr=torch.from_numpy(win.intrinsics)[None], conf=torch.from_numpy(win.confidences))
+        rep = lambda key: [one[key]] * B
+        sched_i, sched_b = list(range(20)), [k < 10 for k in range(20)]
+
+        def window_call():
+            return ba_mod.BA_window(sched_i, sched_b, rep("states"), rep("vel"), rep("imu"), rep("uv"), rep("xyz"), [win.ii] * B,
+                                    [win.time_idx] * B, rep("intr"), rep("conf"), [1e-4] * B, device=device)
+        window_call()
+        tq = time.perf_counter()
+        for _ in range(3):
+            window_call()
+        dq = (time.perf_counter() - tq) / 3
+        st_l, lam_l = rep("states"), [1e-4] * B
+        tq2 = time.perf_counter()
+        for it in range(20):
+            st_l, _, lam_l, _ = ba_mod.BA(it, st_l, rep("vel"), rep("imu"), rep("uv"), rep("xyz"), [win.ii] * B, [win.time_idx] * B,
+                                          rep("intr"), rep("conf"), 1e-3, 1e-3, lam_l, None, initialize=it < 10, device=device)
+        dq2 = time.perf_counter() - tq2
+        ba_mod.release()
+        python_batch = {"windows": B, "BA_window": {"value": 20 * B / dq, "unit": "BA iterations/s", "ms_per_schedule": 1e3 * dq},
+                        "BA_per_call": {"value": 20 * B / dq2, "unit": "BA iterations/s", "ms_per_call": 1e3 * dq2 / 20},
+                        "note": "vinsat_amd.ba.BA / BA_window on lists of 22 windows (ragged batch, one handle); BA_window = the "
+                                "20-call loop as one chained device call incl. upload check, states up and results back; BA per call "
+                                "= states fed back stay on the device, every ndarray argument compared with its uploaded copy per call"}
+    if rank == 0 and world == 1 and not force_dist and not args.no_configs:
+        try:
+            configs = config_series(BAEngine, od_pipe, synth, device, sync)
+        except Exception as exc:
+            configs = {"error": repr(exc)[:300]}
 
     # ---- accuracy: the 20-call schedule once more from the initial guess, against the reference's final states
     accuracy = None
@@ -622,15 +767,19 @@ def run_rank(args):
                                + (f", {world} independent windows (one per rank)" if world > 1 else ""),
                    "poses": n, "observations": m, "windows_per_gpu": 1, "parallelism": f"replicas{world}",
                    "devices_visible": ndev, "ranks_per_device": (world + ndev - 1) // ndev},
-        "phase_ms": {k: float(np.mean(v)) if v else None for k, v in phase.items()},
-        "kernels_ms": kernels_ms,
-        "kernels_ms_source": "vba_step_profiled: serialised schedule, see roofline.timing_source",
+        "phase_ms": {k: float(np.median(v)) if v else None for k, v in phase.items()},
+        "phase_ms_source": "ten chained calls of the phase (vba_run_schedule), wall clock; their mean is ms_per_step plus one host synchronisation per ten calls",
+        "chain_classes_ms": classes_ms,
+        "chain_classes_source": "HIP events at the class boundaries of the chained schedule; the dynamics factor rides in the accumulation's grid, select and accept test are folded into it",
         "roofline": roofline,
         "host_roundtrip": host_roundtrip,
         "python_BA_call": python_ba,
         "accuracy": accuracy,
         "cpu_baseline": cpu,
         "batched": batched,
+        "batched_sweep": batched_sweep,
+        "python_BA_batch": python_batch,
+        "configs": configs,
         "schur_addon": schur,
     }
 
@@ -648,11 +797,11 @@ def run_rank(args):
 
             def bail():
                 hung.set()
-                if got:     # the library-issued leg hung: the line keeps the caller-dispatched rate and says so
+                if got:     # the library-issued leg hung: the line keeps the caller-dispatched rate and says so ...
                     em.emit(sharded=dict(got, native_error="the library-issued leg timed out (collective hung)"))
-                    os._exit(0)
-                em.emit(sharded={"error": "sharded measurement timed out (collective hung)"})
-                os._exit(3)
+                else:
+                    em.emit(sharded={"error": "sharded measurement timed out (collective hung)"})
+                os._exit(3)     # ... and the run FAILS either way: a hung collective is a defect, never a result
 
             watchdog = threading.Timer(240.0, bail)
             watchdog.daemon = True
@@ -697,14 +846,25 @@ def run_rank(args):
                 sharded = dict(got)
                 # ... and issued by the library (RCCL on its own stream, one host call per BA call; the id of its
                 # communicator travels over the gloo control group).  A failure here keeps the rate above.
+                # `value` stays the caller-dispatched rate: the library-issued path has been compared with it bit for bit at
+                # one rank and on the test double of tests/fake_rccl only, not yet on two real devices.  Whether the leg runs is
+                # decided by ALL ranks together (a rank that could not join must not leave the others inside a collective).
+                sba, ok = None, 1.0
                 try:
                     sba = ShardedBA.from_window(win_s, device=device, native=True)
-                    v_native = rate(sba)
-                    sharded.update(value=v_native, transport="ncclAllGather issued by libvinsat_ba.so on its stream (vba_sh_call), "
-                                   + sba.engine.rccl_path)
-                    sba.close()
                 except Exception as exc:
+                    ok = 0.0
                     sharded["native_error"] = repr(exc)[:300]
+                agree = torch.tensor([ok], dtype=torch.float64)
+                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+                if float(agree.item()) > 0.5:
+                    v_native = rate(sba)
+                    sharded.update(value_library_issued=v_native,
+                                   transport_library_issued="ncclAllGather issued by libvinsat_ba.so on its stream (vba_sh_call), " + sba.engine.rccl_path)
+                elif "native_error" not in sharded:
+                    sharded["native_error"] = "another rank could not join the library's communicator"
+                if sba is not None:
+                    sba.close()
             except Exception as exc:      # never lose the headline line to the secondary measurement
                 sharded = {"error": repr(exc)[:300]}
             watchdog.cancel()

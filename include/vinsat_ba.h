@@ -226,6 +226,12 @@ int vba_set_states(vba_handle h, int window, const double* states, double lamda)
 int vba_get_states(vba_handle h, int window, double* states, double* lamda, double* last_hessian /*[81] or NULL*/,
                    int* n_trials /*or NULL*/, unsigned* flags /*or NULL*/);
 
+/* The same for every window of the handle at once -- the batch dimension of BA()'s `states [bsz, n, 10]` (BA_filtering.py:14):
+ * states [W][n_max][10] (rows beyond a window's pose count are ignored / left untouched), lamda [W], last_hessian [W][81],
+ * n_trials [W], flags [W] (each of the last three may be NULL).  One copy each way instead of W. */
+int vba_set_states_all(vba_handle h, const double* states, const double* lamda);
+int vba_get_states_all(vba_handle h, double* states, double* lamda, double* last_hessian, int* n_trials, unsigned* flags);
+
 /* One BA() call (BA_filtering.py:4-98) on EVERY window of the handle, states and lamda device resident:
  * states <- states_new, lamda <- lamda_out.  `iter` selects alpha and Sigma (BA_filtering.py:22,26);
  * `initialize` != 0 is the landmark-only phase (BA_utils.py:463-466).  Synchronous. */
@@ -259,7 +265,7 @@ int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_
 int vba_set_pipeline(vba_handle h, int on);
 /* Host buffers of the caller whose content was uploaded (e.g. the ndarray arguments ii / time_idx of BA()) and that the caller
  * might edit in place: every vba_iterate_resident compares `live` with the reference `copy` (bytes each, both must stay valid;
- * 4 slots, live == NULL clears one) while the device works and reports a difference as VBA_FLAG_HOST_CHANGED. */
+ * 8 slots -- one per array argument of BA() --, live == NULL clears one) while the device works and reports a difference as VBA_FLAG_HOST_CHANGED. */
 int vba_set_host_watch(vba_handle h, int slot, const void* live, const void* copy, int64_t bytes);
 int vba_pipeline_stats(vba_handle h, int* hits, int* discards);
 
@@ -278,6 +284,17 @@ int vba_last_step_ms(vba_handle h, float* ms);
 enum { VBA_K_BEGIN = 0, VBA_K_RESIDUAL, VBA_K_SELECT, VBA_K_ACCUMULATE, VBA_K_DYNAMICS, VBA_K_ASSEMBLE, VBA_K_SOLVE,
        VBA_K_TRIAL, VBA_K_DECIDE, VBA_NKERNELS };
 int vba_step_profiled(vba_handle h, int iter, int initialize, float* ms);
+
+/* Class times of the CHAINED schedule (what vba_run_schedule really runs, as opposed to vba_step_profiled's serialised one).
+ * on != 0: every vba_run_schedule records HIP events on the handle's stream at three boundaries of each call -- in front of
+ * the call's first kernel, behind its accumulation (+ assembly, where that is a launch), behind its solve kernels, behind its
+ * trial kernel -- and, if every call of the schedule was accepted at its first trial, adds the three intervals to the sums.
+ * vba_chain_profile: ms[3] = summed milliseconds of the classes {accumulate (with the select / accept test folded into it, or
+ * launched in front of it), solve, trial}, launches[3] = how many intervals each sum holds (a landmark-only call whose step the
+ * trial kernel forms has no solve interval); reset != 0 clears the sums.  The markers cost ~1 us each on the chain: use a
+ * profiled schedule for class times, an unprofiled one for throughput. */
+int vba_set_chain_profile(vba_handle h, int on);
+int vba_chain_profile(vba_handle h, double* ms, int64_t* launches, int reset);
 
 /* ---- observation-sharded multi-GPU operation (one rank per GPU, window 0 only) -------------------------
  * Each rank uploads its slice of the observation rows and the full per-pose constants.  One BA() call is

@@ -48,6 +48,8 @@ SIGNATURES = {
     "vba_upload_window": (c_int, [c_void_p, c_int, c_int, PD, PD, PI64]),
     "vba_set_states": (c_int, [c_void_p, c_int, PD, c_double]),
     "vba_get_states": (c_int, [c_void_p, c_int, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
+    "vba_set_states_all": (c_int, [c_void_p, PD, PD]),
+    "vba_get_states_all": (c_int, [c_void_p, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
     "vba_step": (c_int, [c_void_p, c_int, c_int]),
     "vba_run_schedule": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "vba_iterate": (c_int, [c_void_p, c_int, c_int, c_double, PD, PD, PD, PD, POINTER(c_int), POINTER(c_uint)]),
@@ -56,6 +58,8 @@ SIGNATURES = {
     "vba_debug_fetch": (c_int, [c_void_p, c_int, c_int, PD, c_int64, PI64]),
     "vba_last_step_ms": (c_int, [c_void_p, POINTER(c_float)]),
     "vba_step_profiled": (c_int, [c_void_p, c_int, c_int, POINTER(c_float)]),
+    "vba_set_chain_profile": (c_int, [c_void_p, c_int]),
+    "vba_chain_profile": (c_int, [c_void_p, PD, PI64, c_int]),
     "vba_sh_partial_count": (c_int64, [c_int]),
     "vba_sh_stage1": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p]),
     "vba_sh_stage2": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

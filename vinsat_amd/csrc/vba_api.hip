@@ -128,7 +128,14 @@ struct vba_context {
     int pipeline = 1;                       // vba_set_pipeline
     bool last_pipelined = false;            // the last call went through iterate_pipelined: a speculated call has reused its scratch
     int spec_hits = 0, spec_discards = 0;   // diagnostics (vba_pipeline_stats)
-    struct Watch { const void* live = nullptr; const void* copy = nullptr; size_t bytes = 0; } watch[4];   // vba_set_host_watch
+    struct Watch { const void* live = nullptr; const void* copy = nullptr; size_t bytes = 0; } watch[8];   // vba_set_host_watch
+    // vba_set_chain_profile: HIP events at the class boundaries (accumulate | solve | trial) of every call of a chained schedule
+    struct ChainProf {
+        bool on = false;
+        std::vector<hipEvent_t> ev;         // 4 per call: before / behind the accumulation, behind the solve, behind the trial
+        double ms[3] = {0.0, 0.0, 0.0};
+        int64_t launches[3] = {0, 0, 0};
+    } cprof;
     double* h_states_map = nullptr;         // [2][n_max][10] mapped pinned host memory (DevView::host_states), one-window handles
     hipEvent_t ev_first = nullptr;
 };
@@ -259,7 +266,7 @@ int vba_device_count(int* count) {
 //   up to 175 000 rows mask 15 (the trial kernel forms the step, the chunk elimination its blocks); up to 450 000 rows 14 (the
 //   trial kernel reads a step that a launch of its own formed: every observation block re-forming the steps of its poses costs
 //   more than that launch as soon as a few windows share the chip); beyond 12 (the assembly is a launch of its own as well).
-constexpr double kLatRowsMax = 1.6e6;
+constexpr double kLatRowsMax = 1.55e6;
 constexpr int kLatWindowsCap = 192;             // (33 MB of bin buckets per C3 window; per-window prologues)
 constexpr int kPartitionedWindowsMax = 1023;
 static bool default_latency_mode(int windows, int64_t m_max) {
@@ -467,6 +474,7 @@ int vba_destroy(vba_handle h) {
     (void)vba_sh_comm_destroy(h);
     if (h->own_stream) { hipStreamSynchronize(h->own_stream); hipStreamDestroy(h->own_stream); }
     if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); }
+    for (hipEvent_t e : h->cprof.ev) if (e) hipEventDestroy(e);
     if (h->ev_first) hipEventDestroy(h->ev_first);
     if (h->h_states_map) hipHostFree(h->h_states_map);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -614,7 +622,7 @@ int vba_set_bucket_cap(vba_handle h, int cap) {
 }
 
 int vba_set_host_watch(vba_handle h, int slot, const void* live, const void* copy, int64_t bytes) {
-    if (!h || slot < 0 || slot >= 4) return fail(VBA_EINVAL, "bad argument (4 watch slots)");
+    if (!h || slot < 0 || slot >= 8) return fail(VBA_EINVAL, "bad argument (8 watch slots)");
     if (live && (!copy || bytes < 1)) return fail(VBA_EINVAL, "a watched buffer needs its reference copy and a size");
     h->watch[slot].live = live;
     h->watch[slot].copy = live ? copy : nullptr;
@@ -846,6 +854,42 @@ int vba_get_states(vba_handle h, int window, double* states, double* lamda, doub
     return VBA_OK;
 }
 
+int vba_set_states_all(vba_handle h, const double* states, const double* lamda) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h, true)) return rc_settle;
+    if (!states || !lamda) return fail(VBA_EINVAL, "null states / lamda");
+    for (int w = 0; w < h->W; ++w)
+        if (!h->have_obs[w] && !h->have_win[w]) return fail(VBA_ESTATE, "upload the windows before their states");
+    HIPCHK(hipSetDevice(h->device));
+    h->carry_ok = 0;
+    const size_t per = (size_t)h->n_max * 10;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->S[h->par], states, (size_t)h->W * per * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<WinScalars> sc((size_t)h->W);
+    HIPCHK(hipMemcpy(sc.data(), h->V.sc, sc.size() * sizeof(WinScalars), hipMemcpyDeviceToHost));
+    for (int w = 0; w < h->W; ++w) sc[w].lam[h->par] = lamda[w];
+    HIPCHK(hipMemcpy(h->V.sc, sc.data(), sc.size() * sizeof(WinScalars), hipMemcpyHostToDevice));
+    for (int w = 0; w < h->W; ++w) h->have_state[w] = 1;
+    return VBA_OK;
+}
+
+int vba_get_states_all(vba_handle h, double* states, double* lamda, double* last_hessian, int* n_trials, unsigned* flags) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
+    for (int w = 0; w < h->W; ++w)
+        if (!h->have_state[w]) return fail(VBA_ESTATE, "no states uploaded");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t per = (size_t)h->n_max * 10;
+    if (states) HIPCHK(hipMemcpy(states, h->S[h->par], (size_t)h->W * per * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<WinScalars> sc((size_t)h->W);
+    HIPCHK(hipMemcpy(sc.data(), h->V.sc, sc.size() * sizeof(WinScalars), hipMemcpyDeviceToHost));
+    for (int w = 0; w < h->W; ++w)
+        unpack_scalars(&sc[w], h->par, lamda ? lamda + w : nullptr, last_hessian ? last_hessian + (size_t)w * 81 : nullptr,
+                       n_trials ? n_trials + w : nullptr, flags ? flags + w : nullptr);
+    return VBA_OK;
+}
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------- one BA() call
@@ -946,7 +990,7 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
 int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat, hipEvent_t* ev) {
     DevView& V = C.V;
     hipStream_t s = h->stream;
-    auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], s); };
+    auto mark = [&](int k) { if (ev && ev[k]) (void)hipEventRecord(ev[k], s); };
     const bool init = c.initialize != 0;
     V.sel_inline = 0;       // (a repeat of the front after a missed warm select takes the exact digits and the plain prologue)
     // the dynamics factor depends only on the states: with few windows its blocks ride in the accumulation's grid (no
@@ -1266,6 +1310,14 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     long trials = 0;
     int next = 0;
     bool complete = false;
+    const bool prof_pass = h->cprof.on;
+    if (prof_pass) {
+        while ((int)h->cprof.ev.size() < 4 * ncalls) {
+            hipEvent_t e = nullptr;
+            HIPCHK(hipEventCreate(&e));
+            h->cprof.ev.push_back(e);
+        }
+    }
     for (int guard = 0; guard <= ncalls; ++guard) {
         // speculative part: calls next .. ncalls-1, one trial each
         for (int c = next; c < ncalls; ++c) {
@@ -1274,8 +1326,19 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             CallCtx C;
             view_for_call(h, C.V, q);
             if (fold) fill_params(C.V.prev, iters[c - 1], inits[c - 1]);
-            if (int rc = enqueue_front(h, C, q, false, nullptr)) return rc;
-            enqueue_trial(h, C, q, true);
+            // chain profile (first pass only): events in front of / behind the accumulation (what runs in front of it --
+            // select kernels of the bandwidth mode -- counts as accumulate class: the first event is moved there), behind
+            // the solve and behind the trial
+            hipEvent_t marks[VBA_NKERNELS + 1] = {};
+            hipEvent_t* pe = nullptr;
+            if (prof_pass && guard == 0) {
+                pe = h->cprof.ev.data() + (size_t)4 * c;
+                marks[1] = pe[0];
+                marks[6] = pe[1];
+            }
+            if (int rc = enqueue_front(h, C, q, false, pe ? marks : nullptr)) return rc;
+            enqueue_trial(h, C, q, true, pe ? pe[2] : nullptr);
+            if (pe) HIPCHK(hipEventRecord(pe[3], s));
             const bool next_folds = c + 1 < ncalls && emit_kind == 2 && h->fold_enabled;
             if (!next_folds) launch_decide(C.V, nullptr, 0, s);
         }
@@ -1290,6 +1353,19 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             const int c = (int)head(h, w)->call_idx;
             stall_at[w] = c;        // a window that the loop below moves on INTO a later stalled call has not run that call's front: it waits for the re-issue
             if (c < ncalls && std::find(stalled.begin(), stalled.end(), c) == stalled.end()) stalled.push_back(c);
+        }
+        if (prof_pass && guard == 0 && stalled.empty()) {       // every call ran once, in order: its three intervals count
+            for (int c = 0; c < ncalls; ++c) {
+                const hipEvent_t* pe = h->cprof.ev.data() + (size_t)4 * c;
+                for (int k = 0; k < 3; ++k) {
+                    float ms = 0.f;
+                    if (k == 1 && inits[c]) continue;       // landmark-only call: the step is formed in front of or inside the trial kernel, no solve launch
+                    if (hipEventElapsedTime(&ms, pe[k], pe[k + 1]) == hipSuccess) {
+                        h->cprof.ms[k] += ms;
+                        h->cprof.launches[k]++;
+                    }
+                }
+            }
         }
         if (stalled.empty()) { complete = true; break; }
         std::sort(stalled.begin(), stalled.end());
@@ -1319,6 +1395,23 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     h->last_pipelined = false;
     h->last_iter = iters[ncalls - 1];
     h->last_init = inits[ncalls - 1];
+    return VBA_OK;
+}
+
+int vba_set_chain_profile(vba_handle h, int on) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc = settle(h)) return rc;
+    h->cprof.on = on != 0;
+    return VBA_OK;
+}
+
+int vba_chain_profile(vba_handle h, double* ms, int64_t* launches, int reset) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    for (int k = 0; k < 3; ++k) {
+        if (ms) ms[k] = h->cprof.ms[k];
+        if (launches) launches[k] = h->cprof.launches[k];
+        if (reset) { h->cprof.ms[k] = 0.0; h->cprof.launches[k] = 0; }
+    }
     return VBA_OK;
 }
 

@@ -34,6 +34,7 @@ class BAEngine:
         self.h = c_void_p()
         _lib.check(self.lib.vba_create_mode(device, windows, int(n_max), int(m_max), int(mode), byref(self.h)), self.lib)
         self.windows = windows
+        self.n_max, self.m_max, self.device = int(n_max), int(m_max), device
         self.n = [0] * windows
         self.m = [0] * windows
         # out-parameters of the per-call entry points, made once: lamda, n_trials, flags and their addresses
@@ -167,6 +168,22 @@ class BAEngine:
         _lib.check(self.lib.vba_get_states(self.h, window, _p(s), byref(lam), _p(hess), byref(nt), byref(fl)), self.lib)
         return s, lam.value, hess, nt.value, fl.value
 
+    def set_states_all(self, states, lamdas):
+        """Every window at once: ``states`` [W, n_max, 10] (rows beyond a window's pose count ignored), ``lamdas`` [W]."""
+        s, lam = _f64(states), _f64(lamdas).reshape(-1)
+        if s.shape != (self.windows, self.n_max, 10) or lam.shape[0] != self.windows:
+            raise ValueError("states must be [windows, n_max, 10] and lamdas [windows]")
+        _lib.check(self.lib.vba_set_states_all(self.h, _p(s), _p(lam)), self.lib)
+
+    def get_states_all(self):
+        """(states [W, n_max, 10], lamda [W], last_hessian [W, 9, 9], n_trials [W], flags [W]) of every window, one copy."""
+        W = self.windows
+        s = np.empty((W, self.n_max, 10))
+        lam, hess = np.empty(W), np.empty((W, 9, 9))
+        nt, fl = (c_int * W)(), (c_uint * W)()
+        _lib.check(self.lib.vba_get_states_all(self.h, _p(s), _p(lam), _p(hess), nt, fl), self.lib)
+        return s, lam, hess, np.array(nt[:], dtype=np.int64), np.array(fl[:], dtype=np.int64)
+
     # ------------------------------------------------------------------ compute
     def step(self, it, initialize):
         _lib.check(self.lib.vba_step(self.h, int(it), int(bool(initialize))), self.lib)
@@ -217,6 +234,19 @@ class BAEngine:
         ms = (c_float * len(self.KERNELS))()
         _lib.check(self.lib.vba_step_profiled(self.h, int(it), int(bool(initialize)), ms), self.lib)
         return dict(zip(self.KERNELS, [float(x) for x in ms]))
+
+    CHAIN_CLASSES = ("accumulate", "solve", "trial")
+
+    def set_chain_profile(self, on):
+        """HIP events at the class boundaries of every call of the following ``run_schedule`` calls (``vba_set_chain_profile``)."""
+        _lib.check(self.lib.vba_set_chain_profile(self.h, int(bool(on))), self.lib)
+
+    def chain_profile(self, reset=True):
+        """{class: (average ms per interval, intervals)} of the chained schedules run since the last reset."""
+        ms = (c_double * 3)()
+        cnt = (c_int64 * 3)()
+        _lib.check(self.lib.vba_chain_profile(self.h, ms, cnt, int(bool(reset))), self.lib)
+        return {k: ((ms[i] / cnt[i]) if cnt[i] else 0.0, int(cnt[i])) for i, k in enumerate(self.CHAIN_CLASSES)}
 
     def last_step_ms(self):
         ms = c_float()

@@ -33,17 +33,31 @@ def time_to_error(errors, times, threshold_km=5.0):
     return np.array(out)
 
 
-def run_folder(folder, ba=None):
-    """Process every ``*_all_detections.npy`` / ``*_orbit_eci_zyxvecs.npy`` pair under ``folder`` (the layout of
-    od_pipe.py:1064-1075: ``tmp_dets/`` and ``tmp_pose/``) and save errors.npy / times.npy next to them."""
-    from .od_pipe import streaming_version
-    errors, times = [], []
+def _pairs(folder):
     for det in sorted(glob.glob(os.path.join(folder, "tmp_dets", "*_all_detections.npy"))):
         sid = os.path.basename(det).split("_")[0]
         orb = os.path.join(folder, "tmp_pose", f"{sid}_orbit_eci_zyxvecs.npy")
-        if not os.path.exists(orb):
-            continue
-        e, _, t = streaming_version(detections_file_name=det, orbit_file_name=orb, ba=ba)
+        if os.path.exists(orb):
+            yield det, orb
+
+
+def run_folder(folder, ba=None, batched=False):
+    """Process every ``*_all_detections.npy`` / ``*_orbit_eci_zyxvecs.npy`` pair under ``folder`` (the layout of
+    od_pipe.py:1064-1075: ``tmp_dets/`` and ``tmp_pose/``) and save errors.npy / times.npy next to them.
+
+    ``batched=True``: the sequences are the batch dimension of ``BA`` -- every sequence's current batch is a window of ONE
+    ragged handle and each kernel launch covers all of them (:func:`vinsat_amd.od_pipe.streaming_batched`) -- instead of
+    one sequence after the other as the reference's loop (od_pipe.py:1069-1077) runs them."""
+    from .od_pipe import streaming_batched, streaming_version
+    errors, times = [], []
+    if batched:
+        if ba is not None:
+            raise ValueError("batched=True drives vinsat_amd.ba.BA_window itself")
+        seqs = [(np.load(det, allow_pickle=True), np.load(orb, allow_pickle=True)) for det, orb in _pairs(folder)]
+        results = streaming_batched(seqs)
+    else:
+        results = [streaming_version(detections_file_name=det, orbit_file_name=orb, ba=ba) for det, orb in _pairs(folder)]
+    for e, _, t in results:
         errors.append(e.detach().cpu().numpy())
         times.append(np.concatenate([np.atleast_1d(np.asarray(x)) for x in t]))
     save_results(folder, errors, times)
@@ -54,8 +68,9 @@ def main():
     ap = argparse.ArgumentParser(description="run the OD driver over a folder of simulated sequences")
     ap.add_argument("folder")
     ap.add_argument("--threshold-km", type=float, default=5.0)
+    ap.add_argument("--batched", action="store_true", help="all sequences as windows of one device handle")
     a = ap.parse_args()
-    errors, times = run_folder(a.folder)
+    errors, times = run_folder(a.folder, batched=a.batched)
     tt = time_to_error(errors, times, a.threshold_km)
     print(f"{len(errors)} sequences; time to <{a.threshold_km} km: median {np.nanmedian(tt):.0f} s, "
           f"{int(np.isnan(tt).sum())} never")

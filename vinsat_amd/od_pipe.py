@@ -188,6 +188,97 @@ def propagate_between_batches(state, velocity, omega, tdiff, duration, rk4_step)
     return np.stack(out)
 
 
+class SequenceRun:
+    """One sequence of the reference's ``streaming_version`` (od_pipe.py:911-1062), cut at its ``BA`` loops: ``next_patch``
+    does what the driver does in front of the 20 calls of a batch (batch cut, dead reckoning across the gap, error
+    bookkeeping) and returns their arguments, ``finish_patch`` takes their result.  The sequential driver and the batched
+    one (:func:`streaming_batched`: the patches of many sequences as windows of ONE handle) share this code."""
+
+    def __init__(self, detections, orbit_np):
+        import torch
+        win = self.win = prepare_window(detections, orbit_np)
+        states = initial_guess(win, seed=0)
+        self.time_idx, self.ii = win.time_idx, win.ii
+        T = self.T = len(self.time_idx)
+        # the reference hands BA an imu tensor [1,T,N,10] of which only [..., -1, 6:10] is read
+        self.imu = torch.zeros((1, T, 1, 10), dtype=torch.float64)
+        self.imu[0, :, 0, 6:10] = torch.from_numpy(win.cumrot_last)
+        self.uv = torch.from_numpy(win.landmarks_uv)[None]
+        self.xyz = torch.from_numpy(win.landmarks_xyz)[None]
+        self.intr = torch.from_numpy(win.intrinsics)[None]
+        self.conf = torch.from_numpy(win.confidences)
+        self.poses_gt = torch.from_numpy(win.poses_gt)
+        self.vel_all = torch.from_numpy(win.velocities)[None]
+        self.states_all = torch.from_numpy(states)[None]
+        self.t = self.i = 0
+        self.seq_end = False
+        self.patch = 0
+        self.errors, self.times = [], []
+        self.first_detection = None
+        self.states_t = self.vel_t = None
+
+    def next_patch(self):
+        """Arguments of the next batch's BA calls, or None when the sequence has ended."""
+        import torch
+        from .synth import rk4_step
+        if self.seq_end:
+            return None
+        win, time_idx, ii = self.win, self.time_idx, self.ii
+        t_init = self.t
+        self.t, self.i, self.seq_end = next_batch(ii, time_idx, self.i)
+        t, i = self.t, self.i
+        if self.patch == 0:
+            self.states_t = self.states_all[:, :t]
+            self.vel_t = self.vel_all[:, :t]
+            self.first_detection = time_idx[:t][-1]
+        else:
+            omega = win.omega_gt[time_idx[t_init - 1]:time_idx[t - 1]]
+            tdiff = int(time_idx[t_init] - time_idx[t_init - 1])
+            duration = int(time_idx[t - 1] - time_idx[t_init])
+            prop = propagate_between_batches(self.states_t[0, -1].numpy(), self.vel_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
+            sel = time_idx[t_init:t] - time_idx[t_init]
+            prop = torch.from_numpy(prop[sel])[None]
+            self.states_t = torch.cat([self.states_t, prop], dim=1)
+            self.vel_t = torch.cat([self.vel_t, prop[..., 7:]], dim=1)
+            err_prop = (prop[0, :, :3] - self.poses_gt[t - prop.shape[1]:t, :3]).norm(dim=-1)[:-1]
+            self.times.append(time_idx[t - prop.shape[1]:t][:-1])
+            self.errors.append(err_prop)
+        return dict(first=self.patch == 0, states=self.states_t, velocities=self.vel_t, imu=self.imu[:, :t], uv=self.uv[:, :i],
+                    xyz=self.xyz[:, :i], ii=ii[:i], time_idx=time_idx[:t], intr=self.intr[:, :t], conf=self.conf[:i],
+                    poses_gt=self.poses_gt[:t], lam=1e-4)
+
+    def finish_patch(self, states_t, vel_t):
+        """The estimate after the batch's BA calls: bookkeeping behind the loop (od_pipe.py:1041-1060)."""
+        import torch
+        from .synth import rk4_step
+        win, time_idx, t, T = self.win, self.time_idx, self.t, self.T
+        self.states_t, self.vel_t = states_t, vel_t
+        self.patch += 1
+        self.errors.append((states_t[0, -1:, :3] - self.poses_gt[t - 1:t, :3]).norm(dim=-1))
+        self.times.append(time_idx[t - 1:t])
+        if self.seq_end and t < T:
+            t_init, t = t, T
+            omega = win.omega_gt[time_idx[t_init - 1]:time_idx[t - 1]]
+            tdiff = int(time_idx[t_init] - time_idx[t_init - 1])
+            duration = int(time_idx[t - 1] - time_idx[t_init])
+            prop = propagate_between_batches(states_t[0, -1].numpy(), vel_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
+            prop = torch.from_numpy(prop[time_idx[t_init:t] - time_idx[t_init]])
+            self.errors.append((prop[:, :3] - self.poses_gt[t_init:t, :3]).norm(dim=-1))
+            self.times.append(time_idx[-prop.shape[0]:])
+
+    def result(self):
+        import torch
+        return torch.cat(self.errors), self.first_detection, self.times
+
+
+def _load_sequence(detections, orbit_np, orbit_file_name, detections_file_name):
+    if detections is None:
+        detections = np.load(detections_file_name, allow_pickle=True)
+    if orbit_np is None:
+        orbit_np = np.load(orbit_file_name, allow_pickle=True)
+    return detections, orbit_np
+
+
 def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, detections_file_name=None,
                       ba=None, num_iters=NUM_ITERS, record=None):
     """Drop-in for the reference's ``streaming_version`` (od_pipe.py:911-1062).
@@ -196,79 +287,68 @@ def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, dete
     callable with the reference signature.  With the default ``ba`` and no ``record`` list the ``num_iters`` calls
     of a batch are issued as one chained device call (:func:`vinsat_amd.ba.BA_window`, same bits).
     """
-    import torch
-    from .synth import rk4_step
     ba_window = None
     if ba is None:
         from .ba import BA as ba
         if record is None:
             from .ba import BA_window as ba_window
-    if detections is None:
-        detections = np.load(detections_file_name, allow_pickle=True)
-    if orbit_np is None:
-        orbit_np = np.load(orbit_file_name, allow_pickle=True)
-    win = prepare_window(detections, orbit_np)
-    states = initial_guess(win, seed=0)
-    time_idx, ii = win.time_idx, win.ii
-    T = len(time_idx)
-    # the reference hands BA an imu tensor [1,T,N,10] of which only [..., -1, 6:10] is read
-    imu = torch.zeros((1, T, 1, 10), dtype=torch.float64)
-    imu[0, :, 0, 6:10] = torch.from_numpy(win.cumrot_last)
-    uv = torch.from_numpy(win.landmarks_uv)[None]
-    xyz = torch.from_numpy(win.landmarks_xyz)[None]
-    intr = torch.from_numpy(win.intrinsics)[None]
-    conf = torch.from_numpy(win.confidences)
-    poses_gt = torch.from_numpy(win.poses_gt)
-    vel_all = torch.from_numpy(win.velocities)[None]
-    states_all = torch.from_numpy(states)[None]
-
-    t = i = 0
-    seq_end = False
-    patch = 0
-    errors, times = [], []
-    first_detection = None
-    states_t = vel_t = None
-    while not seq_end:
-        t_init = t
-        t, i, seq_end = next_batch(ii, time_idx, i)
-        if patch == 0:
-            states_t = states_all[:, :t]
-            vel_t = vel_all[:, :t]
-            first_detection = time_idx[:t][-1]
-        else:
-            omega = win.omega_gt[time_idx[t_init - 1]:time_idx[t - 1]]
-            tdiff = int(time_idx[t_init] - time_idx[t_init - 1])
-            duration = int(time_idx[t - 1] - time_idx[t_init])
-            prop = propagate_between_batches(states_t[0, -1].numpy(), vel_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
-            sel = time_idx[t_init:t] - time_idx[t_init]
-            prop = torch.from_numpy(prop[sel])[None]
-            states_t = torch.cat([states_t, prop], dim=1)
-            vel_t = torch.cat([vel_t, prop[..., 7:]], dim=1)
-            err_prop = (prop[0, :, :3] - poses_gt[t - prop.shape[1]:t, :3]).norm(dim=-1)[:-1]
-            times.append(time_idx[t - prop.shape[1]:t][:-1])
-            errors.append(err_prop)
-        lam = 1e-4
+    run = SequenceRun(*_load_sequence(detections, orbit_np, orbit_file_name, detections_file_name))
+    while True:
+        p = run.next_patch()
+        if p is None:
+            break
+        states_t, vel_t, lam = p["states"], p["velocities"], p["lam"]
+        inits = [(it < 10) if p["first"] else False for it in range(num_iters)]
         if ba_window is not None:
-            inits = [(it < 10) if patch == 0 else False for it in range(num_iters)]
-            states_t, vel_t, lam, last_h = ba_window(range(num_iters), inits, states_t, vel_t, imu[:, :t], uv[:, :i], xyz[:, :i],
-                                                     ii[:i], time_idx[:t], intr[:, :t], conf[:i], lam)
+            states_t, vel_t, lam, last_h = ba_window(range(num_iters), inits, states_t, vel_t, p["imu"], p["uv"], p["xyz"],
+                                                     p["ii"], p["time_idx"], p["intr"], p["conf"], lam)
         for it in range(num_iters if ba_window is None else 0):
-            init = (it < 10) if patch == 0 else False
-            states_t, vel_t, lam, last_h = ba(it, states_t, vel_t, imu[:, :t], uv[:, :i], xyz[:, :i], ii[:i],
-                                              time_idx[:t], intr[:, :t], conf[:i], 1e-3, 1e-3, lam,
-                                              poses_gt[:t], initialize=init)
+            states_t, vel_t, lam, last_h = ba(it, states_t, vel_t, p["imu"], p["uv"], p["xyz"], p["ii"],
+                                              p["time_idx"], p["intr"], p["conf"], 1e-3, 1e-3, lam,
+                                              p["poses_gt"], initialize=inits[it])
             if record is not None:
-                record.append(dict(patch=patch, iter=it, states=states_t.clone(), lamda=lam))
-        patch += 1
-        errors.append((states_t[0, -1:, :3] - poses_gt[t - 1:t, :3]).norm(dim=-1))
-        times.append(time_idx[t - 1:t])
-        if seq_end and t < T:
-            t_init, t = t, T
-            omega = win.omega_gt[time_idx[t_init - 1]:time_idx[t - 1]]
-            tdiff = int(time_idx[t_init] - time_idx[t_init - 1])
-            duration = int(time_idx[t - 1] - time_idx[t_init])
-            prop = propagate_between_batches(states_t[0, -1].numpy(), vel_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
-            prop = torch.from_numpy(prop[time_idx[t_init:t] - time_idx[t_init]])
-            errors.append((prop[:, :3] - poses_gt[t_init:t, :3]).norm(dim=-1))
-            times.append(time_idx[-prop.shape[0]:])
-    return torch.cat(errors), first_detection, times
+                record.append(dict(patch=run.patch, iter=it, states=states_t.clone(), lamda=lam))
+        run.finish_patch(states_t, vel_t)
+    return run.result()
+
+
+def streaming_batched(sequences, num_iters=NUM_ITERS, ba_window=None, record=None):
+    """Many sequences at once -- the reference's outer loop over sequence files (od_pipe.py:1069-1077) turned into the batch
+    dimension of ``BA``: round r runs batch r of EVERY sequence that still has one as the windows of ONE ragged handle
+    (:func:`vinsat_amd.ba.BA_window` on lists: every kernel launch covers all of them), sequences that have ended drop out.
+
+    ``sequences``: list of ``(detections, orbit_np)`` pairs.  Returns the list of ``streaming_version`` results.  With equal
+    handle settings (``vinsat_amd.ba.configure``) every sequence gets the bits of its own ``streaming_version`` run.
+    ``record`` (a list) receives ``dict(round, sequence, states, lamda)`` after every round.
+    """
+    if ba_window is None:
+        from .ba import BA_window as ba_window
+    runs = [SequenceRun(det, orb) for det, orb in sequences]
+    rnd = 0
+    while True:
+        live = [(k, r, r.next_patch()) for k, r in enumerate(runs)]
+        live = [(k, r, p) for k, r, p in live if p is not None]
+        if not live:
+            break
+        # batch 0 of a sequence is the only one with landmark-only calls (od_pipe.py:1038): all sequences are in the same
+        # round, so `initialize` is one value per call as in the reference
+        first = live[0][2]["first"]
+        assert all(p["first"] == first for _, _, p in live)
+        inits = [(it < 10) if first else False for it in range(num_iters)]
+        ps = [p for _, _, p in live]
+        if len(ps) == 1:        # a single window left: the one-window path (pipelined, latency mode)
+            p = ps[0]
+            st, vel, lam, _ = ba_window(range(num_iters), inits, p["states"], p["velocities"], p["imu"], p["uv"], p["xyz"], p["ii"],
+                                        p["time_idx"], p["intr"], p["conf"], p["lam"])
+            st, lam = [st], [lam]
+        else:
+            st, _, lam, _ = ba_window(range(num_iters), inits, [p["states"] for p in ps], [p["velocities"] for p in ps],
+                                      [p["imu"] for p in ps], [p["uv"] for p in ps], [p["xyz"] for p in ps], [p["ii"] for p in ps],
+                                      [p["time_idx"] for p in ps], [p["intr"] for p in ps], [p["conf"] for p in ps],
+                                      [p["lam"] for p in ps])
+        for (k, r, p), s_new, l_new in zip(live, st, lam):
+            if record is not None:
+                record.append(dict(round=rnd, sequence=k, states=s_new.clone(), lamda=l_new))
+            r.finish_patch(s_new, p["velocities"])
+        rnd += 1
+    return [r.result() for r in runs]
