@@ -441,6 +441,84 @@ def test_BA_sees_in_place_edits_of_its_numpy_arguments(c2):
     ba_mod.release()
 
 
+@pytest.mark.parametrize("which", ["time_idx", "intrinsics", "confidences", "confidences-strided"])
+def test_BA_sees_in_place_edits_of_any_of_seven_numpy_arguments_between_resident_calls(c2, which):
+    """An all-NumPy caller: imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences are seven ndarrays.  Every
+    one of them is watched by the library during the RESIDENT calls of the loop ``states = BA(iter, states, ...)`` (eight watch
+    slots; round 3 had four, so the 5th .. 7th array could be edited unseen); an array that cannot be watched (a strided view) is
+    compared on the Python side before every call.  The call after an in-place edit must run on the edited window."""
+    from conftest import golden_inputs
+    from vinsat_amd import ba as ba_mod
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    imu = np.zeros((1, n, 1, 10))
+    imu[0, :, 0, 6:] = inp["cumrot"]
+    conf_store = np.zeros((m, 2))
+    conf_store[:, 0] = inp["conf"]
+    a = dict(imu=imu, uv=inp["uv"][None].copy(), xyz=inp["xyz"][None].copy(), ii=inp["ii"].copy(), t=inp["time_idx"].copy(),
+             K=inp["K"][None].copy(), conf=conf_store[:, 0] if which.endswith("strided") else inp["conf"].copy())
+    assert all(isinstance(v, np.ndarray) for v in a.values()) and a["conf"].flags.c_contiguous != which.endswith("strided")
+
+    sched = [(0, True), (1, True), (10, False), (11, False)]       # (the edit comes in front of a full-phase call: time_idx matters there)
+
+    def loop(args, edit_before=None):
+        ba_mod.release()
+        st, lam = g["states0"].copy(), 1e-4
+        outs = []
+        for k, (it, init) in enumerate(sched):
+            if k == edit_before:
+                edit(args)
+            st, _, lam, _ = ba_mod.BA(it, st, None, args["imu"], args["uv"], args["xyz"], args["ii"], args["t"], args["K"], args["conf"],
+                                      1e-3, 1e-3, lam, None, initialize=init)
+            outs.append(st.numpy().copy())
+        return outs
+
+    def edit(args):
+        if which == "time_idx":
+            args["t"][-1] += 3                      # the last gap grows: another dynamics factor
+        elif which == "intrinsics":
+            args["K"][0, :, 0] *= 1.001
+        else:
+            args["conf"][::2] *= 0.5
+
+    orig = {k: np.array(v) for k, v in a.items()}
+    base = loop(a)
+    edited = loop(a, edit_before=2)                 # calls 0, 1 resident on the old window, the edit, calls 2, 3
+    assert np.array_equal(edited[1], base[1]) and not np.array_equal(edited[2], base[2])
+    # what a caller gets who never edits in place: calls 0, 1 on the original arrays, call 2 on fresh copies of the edited ones
+    fresh = {k: np.array(v) for k, v in a.items()}
+    ba_mod.release()
+    st, lam = g["states0"].copy(), 1e-4
+    for k, (it, init) in enumerate(sched[:3]):
+        w = orig if k < 2 else fresh
+        st, _, lam, _ = ba_mod.BA(it, st, None, w["imu"], w["uv"], w["xyz"], w["ii"], w["t"], w["K"], w["conf"], 1e-3, 1e-3, lam, None,
+                                  initialize=init)
+    assert rel_err(edited[2], st.numpy()) < 1e-12
+    ba_mod.release()
+
+
+def test_pipeline_predictor_does_not_learn_across_window_boundaries(c2):
+    """Six windows in a row through the driver's loop (call 0 with uploaded states, calls 1 .. 19 resident): the speculated calls
+    that are dropped stay at one per boundary at most (the call guessed behind iter 19) plus the one wrong guess at the first
+    phase switch -- round 3 learnt "iter 1 follows iter 19" from the boundary and wasted a call every second window."""
+    from conftest import golden_inputs
+    from vinsat_amd.engine import BAEngine
+    g, inp = c2, golden_inputs(c2)
+    n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+    e = BAEngine(n, m)
+    e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
+    e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+    windows = 6
+    for w in range(windows):
+        st, lam, _, _, _ = e.iterate(0, True, 1e-4, g["states0"][0])
+        for k in range(1, 20):
+            st, lam, _, _, _ = e.iterate_resident(k, k < 10)
+        assert rel_err(st, g["states_out_19"][0]) < 1e-7
+    hits, discards = e.pipeline_stats()
+    assert hits >= windows * 17 and discards <= windows + 1, (hits, discards)
+    e.close()
+
+
 def test_pipelined_calls_survive_whatever_happens_between_them(c2):
     """The speculated call is an implementation detail: reading the states, fetching intermediates, toggling a switch,
     uploading the window again or running a plain step between two resident calls must neither change a result nor leave the

@@ -104,6 +104,7 @@ struct vba_context {
         double* buf = nullptr;              // one allocation: abs_local | abs_all | partial_local | partial_all | trial_local | trial_all
         int64_t m_total = 0, m_pad = 0;     // what buf was sized for
         int n = 0;
+        int m_local = -1;                   // rows of this rank the +inf padding of abs_local was laid out for
         double *abs_local = nullptr, *abs_all = nullptr, *partial_local = nullptr, *partial_all = nullptr, *trial_local = nullptr, *trial_all = nullptr;
     } shc;
     int pack_min = 1 << 30;                 // windows from which three chains share a wavefront: never by default (measured at 1024 / 2048 / 4096
@@ -201,7 +202,13 @@ hipError_t create_aux_stream(hipStream_t* s) {
 // parity), its trial states and everything keyed to them are dropped.  `boundary`: the caller left the resident loop
 // (uploads, new states): remember not to speculate behind a call with that iter again.
 int settle(vba_handle h, bool boundary = false) {
-    if (!h || !h->spec.valid) return VBA_OK;
+    if (!h) return VBA_OK;
+    if (!h->spec.valid) {
+        // the caller left the resident loop behind a call that had speculated nothing: what it does next is not "what follows
+        // that iter" (learning across a window boundary made every second window waste a speculated call)
+        if (boundary) h->prev_res_iter = -1;
+        return VBA_OK;
+    }
     HIPCHK(hipSetDevice(h->device));
     launch_reset_calls(h->V, h->stream);            // (also clears a missed warm select the dropped call may have recorded)
     HIPCHK(hipGetLastError());
@@ -1194,6 +1201,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     h->carry_ok = c.emit;           // (the kind of histogram that came with the keys)
     h->stepped = true;
     h->last_pipelined = false;
+    h->prev_res_iter = -1;          // (not a link of the resident loop: nothing to learn from what follows it)
     h->last_iter = iter;
     h->last_init = initialize;
     return VBA_OK;
@@ -1971,9 +1979,15 @@ int vba_sh_call(vba_handle h, int iter, int initialize, int64_t m_total, int* n_
         S.partial_all = S.partial_local + pc;
         S.trial_local = S.partial_all + pc * R;
         S.trial_all = S.trial_local + 2;
+        S.m_total = m_total; S.m_pad = m_pad; S.n = n;
+        S.m_local = -1;
+    }
+    if (S.m_local != h->m[0]) {     // stage 1 writes 2 * m_local keys: everything behind them must sort above every |r| -- also after
+                                    // a re-upload with FEWER rows of this rank than before (the old shard's keys would enter the median)
+        HIPCHK(hipStreamSynchronize(h->stream));
         std::vector<double> inf((size_t)(2 * m_pad), INFINITY);
         HIPCHK(hipMemcpy(S.abs_local, inf.data(), inf.size() * 8, hipMemcpyHostToDevice));
-        S.m_total = m_total; S.m_pad = m_pad; S.n = n;
+        S.m_local = h->m[0];
     }
     auto gather = [&](const double* src, double* dst, int64_t count) -> int {
         const ncclResult_t rc = S.all_gather(src, dst, (size_t)count, ncclDouble, S.comm, h->stream);

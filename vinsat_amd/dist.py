@@ -175,11 +175,12 @@ class ShardedBA:
         self.n_trials = 0
 
     @classmethod
-    def from_window(cls, win, device=0, group=None, collectives=None, native=False):
+    def from_window(cls, win, device=0, group=None, collectives=None, native=False, rccl_path=None):
         """Build the GPU-backed sharded solver for a :class:`vinsat_amd.od_pipe.Window` on this rank.
 
         ``native``: the library issues the all-gathers itself (RCCL on its own stream, ``vba_sh_call``); ``group`` is then
-        only the control plane over which the communicator's id is handed out (any backend)."""
+        only the control plane over which the communicator's id is handed out (any backend); ``rccl_path`` names the library
+        that provides the collectives (default: the RCCL this process has loaded)."""
         import torch.distributed as dist
         from .engine import BAEngine
         if collectives is not None:
@@ -193,7 +194,7 @@ class ShardedBA:
         eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
         if native:
             stage = HipStageEngine(eng, torch_stream=False)
-            stage.attach_rccl(dist, group)
+            stage.attach_rccl(dist, group, rccl_path)
             return cls(stage, n, hi - lo, m, group, collectives)
         return cls(HipStageEngine(eng), n, hi - lo, m, group, collectives)
 
