@@ -67,6 +67,11 @@ enum {
 
 /* library / device */
 int vba_version(void);
+/* 1 if the library was built with -DVBA_VARIANTS (make VARIANTS=1 -> libvinsat_ba_variants.so): the solver variants that were
+ * measured slower and are kept for comparison only -- three windows per wavefront (vba_set_solver -3), one window per wavefront
+ * forming its own blocks, one cyclic-reduction level in front (vba_set_fusion bit 4), the solve as one grid of waiting blocks
+ * (bits 5, 6).  The default build does not carry them: those settings return VBA_EINVAL. */
+int vba_has_variants(void);
 const char* vba_last_error(void);
 int vba_device_count(int* count);
 

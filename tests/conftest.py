@@ -13,6 +13,26 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "variants: needs the comparison build of the library (make VARIANTS=1; deselected otherwise)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests of the comparison-only solver variants (marker ``variants``) run against a library built with them
+    (make VARIANTS=1, VBA_LIB=...); against the default library they are deselected."""
+    has = False
+    try:
+        from vinsat_amd import _lib
+        has = bool(_lib.load().vba_has_variants())
+    except Exception:
+        has = False
+    if has:
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("variants") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def pytest_sessionstart(session):

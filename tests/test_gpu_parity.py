@@ -711,41 +711,6 @@ def test_plain_BA_with_rejected_trials_vs_reference(solver):
     eng.close()
 
 
-@pytest.mark.parametrize("pivot", [False, True], ids=["unpivoted", "pivoted"])
-def test_packed_sequential_solve_three_windows_per_wave(pivot):
-    """Sequential driver with equal pose counts: three windows share a wavefront (k_solve_packed).  Five windows
-    (3 + a partial group of 2) with different data must reproduce the one-window-per-wave results bit for bit."""
-    from vinsat_amd.engine import BAEngine
-    from vinsat_amd import od_pipe, synth
-    cfg = synth.WindowConfig("pk", 48, 25, 5)
-    wins = [od_pipe.prepare_window(*synth.make_sequence(cfg, seed=s)) for s in range(5)]
-    n, m = wins[0].time_idx.size, wins[0].ii.size
-    sched = [(0, True), (1, True), (10, False), (11, False), (12, False)]
-
-    def run(solver, W):
-        outs = []
-        groups = [list(enumerate(wins))] if W == 5 else [[(k, w)] for k, w in enumerate(wins)]
-        for grp in groups:
-            e = BAEngine(n, m, windows=len(grp))
-            e.set_solver(solver)
-            e.set_pivoting(pivot)
-            e.set_accumulate_lanes(8)
-            for k, (seed, w) in enumerate(grp):
-                e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, n, window=k)
-                e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx, window=k)
-                e.set_states(od_pipe.initial_guess(w, seed=seed), 1e-4, window=k)
-            for it, init in sched:
-                e.step(it, init)
-            outs += [e.get_states(window=k) for k in range(len(grp))]
-            e.close()
-        return outs
-
-    packed = run(-3, 5)         # 5 windows, sequential with packing forced -> k_solve_packed
-    single = run(-2, 1)         # one window per handle, one window per wavefront
-    for a, b in zip(packed, single):
-        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[3] == b[3]
-
-
 def test_run_schedule_equals_step_by_step(c2):
     """vba_run_schedule chains the 20 calls on the device; it must give the same bits as 20 vba_step calls --
     also when some windows need several LM trials (confidence 3 -> lamda exhaustion) or the pivoted fallback
@@ -1297,7 +1262,7 @@ def test_torch_cuda_initialises_after_the_library_has_used_the_gpu():
     assert out.stdout.strip().splitlines()[-1] == "0"
 
 
-@pytest.mark.parametrize("solver", [0, -2], ids=["four-per-wave", "one-per-wave"])
+@pytest.mark.parametrize("solver", [0], ids=["four-per-wave"])
 @pytest.mark.parametrize("reg", [False, True])
 def test_batched_walk_forming_its_own_blocks_gives_the_bits_of_the_assembled_path(c2, reg, solver):
     """vba_set_fusion bit 2 (default for 16 windows and more, sequential driver -- itself the default from 128 windows on):
@@ -1405,87 +1370,3 @@ def test_uniform_pass_assembly_gives_the_bits_of_the_per_entry_form(c2, reg, win
     assert np.abs(a[0]).max() > 0 and np.abs(a[0][:, 0]).max() > 0 and np.abs(a[0][:, 2]).max() > 0     # off-diagonal bands are populated
 
 
-@pytest.mark.parametrize("chunk", [4, 5, 6, 7, 8, 13])
-def test_two_cyclic_reduction_levels_in_front_give_the_bits_of_one(chunk):
-    """The reduced system's first TWO cyclic-reduction levels on their own CUs (k_cr_level01, default) against one level in
-    front (k_cr_level0; vba_set_fusion bit 4): the same eliminations and folds in another place, so the same bits -- for
-    separator counts of every residue mod 4 (a 300-pose window cut into chunks of 4 .. 13: 74, 59, 49, 42, 37, 23 separators,
-    the last one below the size from which the levels are split off at all), unpivoted and pivoted."""
-    from vinsat_amd.engine import BAEngine
-    from vinsat_amd import od_pipe, synth
-    cfg = synth.WindowConfig("cr2", 300, 20, 5)
-    win = od_pipe.prepare_window(*synth.make_sequence(cfg, seed=11))
-    n, m = win.time_idx.size, win.ii.size
-    st0 = od_pipe.initial_guess(win, seed=11)
-    iters, inits = [9, 10, 11, 12, 13], [True, False, False, False, False]
-    for pivot in (False, True):
-        outs = []
-        for mask in (9, 25):
-            e = BAEngine(n, m)
-            e.set_solver(chunk, -1)
-            e.set_pivoting(pivot)
-            e.set_fusion(mask)
-            e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
-            e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
-            e.set_states(st0, 1e-4)
-            e.run_schedule(iters, inits)
-            outs.append((e.get_states(), e.debug("dpose")))
-            e.close()
-        a, b = outs
-        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0][0], b[0][0]) and a[0][1] == b[0][1] and a[0][3] == b[0][3], (chunk, pivot)
-        assert np.isfinite(a[1]).all() and np.abs(a[1]).max() > 0
-
-
-@pytest.mark.parametrize("chunk", [4, 6, 8])
-def test_resident_solve_gives_the_bits_of_three_launches(chunk):
-    """vba_set_fusion bits 5 / 6 (k_solve_resident): chunk elimination, the two split-off cyclic-reduction levels and -- bit 6
-    -- the one-workgroup tail as ONE grid whose consumer blocks wait for their producers on flags.  The same bodies run, so
-    the bits are those of the three launches, unpivoted and pivoted; and every block publishes its flag whatever it did, so a
-    handle whose windows differ in length (one of them below the size from which the levels are split off at all, one
-    that finishes its schedule early... none may leave a consumer waiting) comes back with the same bits too.  Not the
-    default: a hop over a flag measured slower than a kernel boundary."""
-    from vinsat_amd.engine import BAEngine
-    from vinsat_amd import od_pipe, synth
-    cfg = synth.WindowConfig("res", 300, 20, 5)
-    win = od_pipe.prepare_window(*synth.make_sequence(cfg, seed=11))
-    n, m = win.time_idx.size, win.ii.size
-    st0 = od_pipe.initial_guess(win, seed=11)
-    iters, inits = [9, 10, 11, 12, 13], [True, False, False, False, False]
-    for pivot in (False, True):
-        outs = []
-        for mask in (15, 15 + 32, 15 + 64):
-            e = BAEngine(n, m)
-            e.set_solver(chunk, -1)
-            e.set_pivoting(pivot)
-            e.set_fusion(mask)
-            e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
-            e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
-            e.set_states(st0, 1e-4)
-            e.run_schedule(iters, inits)
-            outs.append((e.get_states(), e.debug("dpose")))
-            e.close()
-        for b in outs[1:]:
-            a = outs[0]
-            assert np.array_equal(a[1], b[1]) and np.array_equal(a[0][0], b[0][0]) and a[0][1] == b[0][1] and a[0][3] == b[0][3], (chunk, pivot)
-        assert np.isfinite(outs[0][1]).all() and np.abs(outs[0][1]).max() > 0
-    if chunk != 8:
-        return
-    # windows of 300, 120 (14 separators: the one-workgroup variant) and 260 poses in one handle
-    cfgs = [synth.WindowConfig("r0", 300, 20, 5), synth.WindowConfig("r1", 120, 20, 5), synth.WindowConfig("r2", 260, 20, 5)]
-    wins = [od_pipe.prepare_window(*synth.make_sequence(c, seed=20 + k)) for k, c in enumerate(cfgs)]
-    n_max, m_max = max(w.time_idx.size for w in wins), max(w.ii.size for w in wins)
-    iters, inits = list(range(6, 16)), [k < 10 for k in range(6, 16)]
-    got = []
-    for mask in (15, 15 + 32, 15 + 64):
-        e = BAEngine(n_max, m_max, windows=3)
-        e.set_fusion(mask)
-        for k, w in enumerate(wins):
-            e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, w.time_idx.size, window=k)
-            e.upload_window(w.intrinsics, w.cumrot_last, w.time_idx, window=k)
-            e.set_states(od_pipe.initial_guess(w, seed=k), 1e-4, window=k)
-        e.run_schedule(iters, inits)
-        got.append([e.get_states(window=k) for k in range(3)])
-        e.close()
-    for b in got[1:]:
-        for k in range(3):
-            assert np.array_equal(got[0][k][0], b[k][0]) and got[0][k][1] == b[k][1] and got[0][k][3] == b[k][3], k

@@ -19,6 +19,7 @@ PI64 = POINTER(c_int64)
 # name -> (restype, argtypes); mirrors include/vinsat_ba.h one to one
 SIGNATURES = {
     "vba_version": (c_int, []),
+    "vba_has_variants": (c_int, []),
     "vba_last_error": (c_char_p, []),
     "vba_device_count": (c_int, [POINTER(c_int)]),
     "vba_create": (c_int, [c_int, c_int, c_int, c_int64, POINTER(c_void_p)]),

@@ -467,6 +467,14 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     return VBA_OK;
 }
 
+int vba_has_variants(void) {
+#ifdef VBA_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int vba_get_mode(vba_handle h, int* mode, int* chunk) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (mode) *mode = h->V.lat;
@@ -542,6 +550,9 @@ int vba_set_solver(vba_handle h, int chunk) {
         h->no_pack = 1;
         return VBA_OK;
     }
+#ifndef VBA_VARIANTS
+    if (chunk == -3) return fail(VBA_EINVAL, "three windows per wavefront (k_solve_packed) is a comparison variant that this build does not carry (make VARIANTS=1)");
+#endif
     if (chunk == -3) {      // sequential, three windows per wavefront whenever the pose counts allow it
         h->V.chunk = 0;
         h->no_pack = 0;
@@ -589,6 +600,9 @@ int vba_set_fusion(vba_handle h, int mask) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     if (mask < 0 || mask > 127) return fail(VBA_EINVAL, "mask must be in [0, 127]");
+#ifndef VBA_VARIANTS
+    if (mask & (16 | 32 | 64)) return fail(VBA_EINVAL, "mask bits 4 .. 6 select comparison variants that this build does not carry (make VARIANTS=1)");
+#endif
     h->fusion = mask;
     return VBA_OK;
 }

@@ -380,6 +380,7 @@ __global__ __launch_bounds__(64) void k_solve(DevView V) {
     if (lane == 0 && anybad) atomicOr(&sc.fl[V.par], 2u);
 }
 
+#ifdef VBA_VARIANTS   // measured dead ends kept for comparison builds (make VARIANTS=1): k_solve_forming, k_solve_packed
 // Batched windows, full phase (vba_set_fusion bit 2): the walk forms the blocks itself.  The assembly kernel wrote 2 kB
 // per pose that this kernel read straight back -- 8 GB per call at 4096 windows of 500 poses; here the wave keeps the
 // inputs of three consecutive poses (141 doubles each, BA_reg 183) in an LDS ring, loads the next pose's while it
@@ -591,6 +592,8 @@ __global__ __launch_bounds__(64) void k_solve_packed(DevView V) {
         if (lane == 0 && anybad) atomicOr(&s3.fl[V.par], 2u);
     }
 }
+
+#endif  // VBA_VARIANTS
 
 // ---------------------------------------------------------------------------------------------- quad
 // Many batched windows: FOUR chains per wavefront, one per row of 16 lanes.  The walk of one window per wave is bound by
@@ -2120,6 +2123,7 @@ __device__ __forceinline__ void cr_fill(const DevView& V, int w, int s, int n1, 
     }
 }
 
+#ifdef VBA_VARIANTS   // one cyclic-reduction level in front instead of two (vba_set_fusion bit 4): 0.9 us per call slower, comparison builds
 // First level of the cyclic reduction as its own kernel, one wave (one CU) per pair of separators: wave t builds the
 // blocks 2t, 2t+1, 2t+2, eliminates the two even ones (each even block is eliminated by both of its odd neighbours'
 // waves: redundant work instead of communication), folds them into block 2t+1 and leaves
@@ -2159,6 +2163,8 @@ __global__ __launch_bounds__(128) void k_cr_level0(DevView V, int s) {
     }
     report_pivot<PIVOT>(bad, sc, lane, V.par);
 }
+
+#endif  // VBA_VARIANTS
 
 // The first TWO levels on their own CUs: four waves per group of four separators.  Group t builds the seven blocks
 // 4t .. 4t+6, eliminates the even ones (four waves side by side), folds them into 4t+1, 4t+3, 4t+5, eliminates 4t+1 and
@@ -2397,6 +2403,7 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
     reduced_cr_body<PIVOT, PRE, kCrThreads>(V, s, blockIdx.x, smem);
 }
 
+#ifdef VBA_VARIANTS   // the solve as ONE grid of producer and waiting consumer blocks (vba_set_fusion bits 5, 6): measured slower, comparison builds
 // ------------------------------------------------------------------------------------------------ resident solve
 // The three launches of the latency-mode solve (chunk elimination -> cyclic-reduction levels 0 + 1 -> the remaining levels
 // in one workgroup) as ONE grid whose consumer blocks are resident from the start and wait for their producers on flags
@@ -2480,6 +2487,8 @@ __global__ __launch_bounds__(TAIL ? 512 : 256) void k_solve_resident(DevView V, 
     VBA_RSTAMP(3);
 #undef VBA_RSTAMP
 }
+
+#endif  // VBA_VARIANTS
 
 // Recovery of a partitioned chain: x_i = yhat_i - Vhat_i x_left - What_i x_right for interior blocks, separators
 // copied from the reduced solution.
@@ -2708,12 +2717,18 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
 // latency mode with a partitioned chain whose chunk (blocks + staged inputs + elimination scratch) fits the LDS of a CU:
 // the chunk kernel forms its blocks itself and k_assemble is not launched (vba_api.hip asks the same question)
 // ... and the sequential walk of the batched mode forms them pose by pose (vba_set_fusion bit 2)
+#ifdef VBA_VARIANTS
 static bool walk_forms_blocks(const DevView& V) { return !V.lat && V.fuse_walk && !V.prm.initialize && V.chunk <= 0 && V.pack != 1; }
+#else   // (one window per wavefront forming its own blocks -- k_solve_forming -- is a comparison variant)
+static bool walk_forms_blocks(const DevView& V) { return !V.lat && V.fuse_walk && !V.prm.initialize && V.chunk <= 0 && V.pack == 2; }
+#endif
 bool solve_forms_blocks(const DevView& V) {
     return walk_forms_blocks(V) || (V.lat && V.fuse_blocks && !V.prm.initialize && V.chunk >= 2 && V.chunk <= kFusedChunkMax);
 }
 
+#ifdef VBA_VARIANTS
 static std::atomic<unsigned> g_resident_epoch{0u};    // flags of k_solve_resident: one value per launch, process wide
+#endif
 
 template <bool PIVOT>
 static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s) {
@@ -2729,16 +2744,20 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
             else if (V.reg) hipLaunchKernelGGL((k_solve_quad<PIVOT, true, true>), g, b, 0, s, V);
             else hipLaunchKernelGGL((k_solve_quad<PIVOT, true, false>), g, b, 0, s, V);
         }
+#ifdef VBA_VARIANTS
         else if (V.pack) hipLaunchKernelGGL(k_solve_packed<PIVOT>, dim3((V.W + kPack - 1) / kPack), dim3(64), 0, s, V);   // equal pose counts: three windows per wavefront
         else if (walk_forms_blocks(V)) {     // (V.pack == 0: one window per wavefront)
             if (V.reg) hipLaunchKernelGGL((k_solve_forming<PIVOT, true>), dim3(V.W), dim3(64), 0, s, V);
             else hipLaunchKernelGGL((k_solve_forming<PIVOT, false>), dim3(V.W), dim3(64), 0, s, V);
-        } else hipLaunchKernelGGL(k_solve<PIVOT>, dim3(V.W), dim3(64), 0, s, V);
+        }
+#endif
+        else hipLaunchKernelGGL(k_solve<PIVOT>, dim3(V.W), dim3(64), 0, s, V);      // one window per wavefront
         return;
     }
     const int cs = V.chunk, cs2 = V.chunk2;
     const int P = (V.n_max + cs - 1) / cs;
     const size_t lds = (512 + (size_t)cs * 252 + 162) * sizeof(double);
+#ifdef VBA_VARIANTS
     const int n0_all = P - 1;
     const bool resident = V.resident && solve_forms_blocks(V) && V.chunk_waves == 2 && cs >= 4 && cs2 < 0 && V.cr_levels == 2 &&
                           n0_all >= kCrSplitMin && n0_all <= 4 * kCrMax;
@@ -2766,6 +2785,7 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
             hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, 0>), dim3(V.W), dim3(kCrThreads), (size_t)(kCrSplitMin - 1) * 252 * sizeof(double), s, V, cs);
         return;
     }
+#endif
     if (solve_forms_blocks(V) && V.chunk_waves == 2 && cs >= 4) {
         const bool reg = V.reg != 0;
         const size_t ldsf = (size_t)twosided_fused_lds_doubles(cs, reg) * sizeof(double);
@@ -2789,14 +2809,20 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
     if (cs2 < 0) {      // one level, the reduced system by cyclic reduction (every window picks its variant by its own size)
         const int n0_max = P - 1, n0_min = (V.n_min + cs - 1) / cs - 1;
         if (n0_max >= kCrSplitMin) {    // first level(s) on their own CUs, the rest in one workgroup
-            if (V.cr_levels == 2) {
+#ifdef VBA_VARIANTS
+            if (V.cr_levels == 2)
+#endif
+            {
                 hipLaunchKernelGGL(k_cr_level01<PIVOT>, dim3((n0_max + 3) / 4, V.W), dim3(256), 0, s, V, cs);
                 hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, 2>), dim3(V.W), dim3(kCrThreads),
                                    ((size_t)(n0_max / 4) * 252 + (size_t)((n0_max + 3) / 4) * 9) * sizeof(double), s, V, cs);
-            } else {
+            }
+#ifdef VBA_VARIANTS
+            else {
                 hipLaunchKernelGGL(k_cr_level0<PIVOT>, dim3((n0_max + 1) / 2, V.W), dim3(128), 0, s, V, cs);
                 hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, 1>), dim3(V.W), dim3(kCrThreads), (size_t)(n0_max / 2) * 252 * sizeof(double), s, V, cs);
             }
+#endif
         }
         if (n0_min < kCrSplitMin && n0_max > 0) {
             const int nb = n0_max < kCrSplitMin ? n0_max : kCrSplitMin - 1;
@@ -2813,8 +2839,10 @@ hipError_t configure_solver_device() {
     const int cap = (int)((512 + 60 * 252 + 162) * sizeof(double));     // chunks above ~30 poses exceed the default 64 KiB
     const int cap_cr = kCrMax * 252 * (int)sizeof(double);
     const int cap_f = (int)((512 + kFusedChunkMax * 252 + 162 + (kFusedChunkMax + 1) * 252 + (kFusedChunkMax + 2) * (kAsmBase + kAsmPrior)) * sizeof(double));
+#ifdef VBA_VARIANTS
     const int cap_ts = twosided_fused_lds_doubles(kFusedChunkMax, true) * 8;
     const int cap_res = cap_ts > cap_cr + 65 * 9 * 8 ? cap_ts : cap_cr + 65 * 9 * 8;
+#endif
     const struct { const void* fn; int bytes; } set[] = {
         {reinterpret_cast<const void*>(k_solve_chunks_fused<false, false>), cap_f}, {reinterpret_cast<const void*>(k_solve_chunks_fused<true, false>), cap_f},
         {reinterpret_cast<const void*>(k_solve_chunks_fused<false, true>), cap_f}, {reinterpret_cast<const void*>(k_solve_chunks_fused<true, true>), cap_f},
@@ -2826,12 +2854,14 @@ hipError_t configure_solver_device() {
         {reinterpret_cast<const void*>(k_solve_chunks_ts<false>), twosided_lds_doubles(60) * 8}, {reinterpret_cast<const void*>(k_solve_chunks_ts<true>), twosided_lds_doubles(60) * 8},
         {reinterpret_cast<const void*>(k_solve_chunks2<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks2<true>), cap},
         {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 0>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 0>), cap_cr},
+#ifdef VBA_VARIANTS
         {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 1>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 1>), cap_cr},
-        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 2>), cap_cr + 65 * 9 * 8}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 2>), cap_cr + 65 * 9 * 8},
         {reinterpret_cast<const void*>(k_solve_resident<false, false, false>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, false, false>), cap_res},
         {reinterpret_cast<const void*>(k_solve_resident<false, true, false>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, true, false>), cap_res},
         {reinterpret_cast<const void*>(k_solve_resident<false, false, true>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, false, true>), cap_res},
-        {reinterpret_cast<const void*>(k_solve_resident<false, true, true>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, true, true>), cap_res}};
+        {reinterpret_cast<const void*>(k_solve_resident<false, true, true>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, true, true>), cap_res},
+#endif
+        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 2>), cap_cr + 65 * 9 * 8}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 2>), cap_cr + 65 * 9 * 8}};
     for (const auto& e : set) {
         const hipError_t rc = hipFuncSetAttribute(e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, e.bytes);
         if (rc != hipSuccess) return rc;
