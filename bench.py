@@ -815,19 +815,26 @@ def run_rank(args):
                 st_s = od_pipe.initial_guess(win_s)
                 ns = min(args.steps, 100)
 
+                def run(sba, count):
+                    """`count` BA() calls walking the 20-call schedule: one chained device call per schedule where the library
+                    issues the exchanges (vba_sh_run_schedule), call by call through torch.distributed otherwise."""
+                    k = 0
+                    while k < count:
+                        cnt = min(20, count - k)
+                        sba.set_states(st_s, 1e-4)
+                        calls = [schedule(j) for j in range(cnt)]
+                        if getattr(sba.engine, "native", False):
+                            sba.run_schedule([c[0] for c in calls], [c[1] for c in calls])
+                        else:
+                            for it, init in calls:
+                                sba.step(it, init)
+                        k += cnt
+
                 def rate(sba):
-                    for k in range(20):
-                        it, init = schedule(k)
-                        if it == 0:
-                            sba.set_states(st_s, 1e-4)
-                        sba.step(it, init)
+                    run(sba, 20)
                     barrier()
                     ts = time.perf_counter()
-                    for k in range(ns):
-                        it, init = schedule(k)
-                        if it == 0:
-                            sba.set_states(st_s, 1e-4)
-                        sba.step(it, init)
+                    run(sba, ns)
                     barrier()
                     t = torch.tensor([time.perf_counter() - ts], dtype=torch.float64)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -859,7 +866,11 @@ def run_rank(args):
                 dist.all_reduce(agree, op=dist.ReduceOp.MIN)
                 if float(agree.item()) > 0.5:
                     v_native = rate(sba)
-                    sharded.update(value_library_issued=v_native,
+                    first_b, n_miss, n_lm = sba.engine.stats()
+                    sharded.update(value_library_issued=v_native, value_library_issued_vs_unsharded=v_native / value * world,
+                                   protocol="carried keys: all-gather of [warm histogram | block sums], of the median bin's bucket, of the "
+                                            "per-pose normal equations; calls chained on the device (vba_sh_run_schedule)",
+                                   first_exchange_bytes_per_rank=first_b, calls_repeated_after_a_missed_select=n_miss, calls_finished_by_the_lm_loop=n_lm,
                                    transport_library_issued="ncclAllGather issued by libvinsat_ba.so on its stream (vba_sh_call), " + sba.engine.rccl_path)
                 elif "native_error" not in sharded:
                     sharded["native_error"] = "another rank could not join the library's communicator"

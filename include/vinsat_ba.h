@@ -330,13 +330,30 @@ int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done)
  * not link it.
  *   vba_sh_unique_id: rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means;
  *   vba_sh_comm_init: every rank of the window joins (ncclCommInitRank: collective, returns when all have);
- *   vba_sh_call:      one BA() call (BA_filtering.py:4-98) on the sharded window: stage1 .. stage4 with the all-gathers of
- *                     |r| keys (+inf padded slots of ceil(m_total / ranks) rows), partial normal equations and trial sums
- *                     in between; this rank's rows (vba_upload_observations) must number at most ceil(m_total / ranks);
- *   vba_sh_comm_destroy: leaves the communicator (vba_destroy does it as well). */
+ *   vba_sh_call:      one BA() call (BA_filtering.py:4-98) on the sharded window (protocol below); this rank's rows
+ *                     (vba_upload_observations) must number at most ceil(m_total / ranks);
+ *   vba_sh_comm_destroy: leaves the communicator (vba_destroy does it as well).
+ * Protocol of the library-issued form (vba_sh_set_protocol; default 1):
+ *   1  carried keys.  An accepted trial is evaluated at the states the next call starts from, so the trial kernel of every rank
+ *      leaves the |r| keys of ITS rows behind in per-bin buckets, with their warm histogram (vba_set_warm_select) and block sums,
+ *      written straight into the exchange buffer.  Per call: all-gather A [histogram | block sums] (~12 kB per rank at 500 / 50k;
+ *      the next call's first kernel evaluates the accept test on it and resolves the bin of the global median from the summed
+ *      histograms), all-gather B [this rank's bucket of that bin] (<= 8 kB), all-gather C [per-pose normal equations, written
+ *      by the accumulation in place].  No pass over all keys, no glue launches; the calls of a schedule are chained on the device
+ *      and every rank enqueues the same collectives whether a call runs or skips, one host synchronisation per schedule.  A call
+ *      whose select misses (median outside the binned range, a bucket overflowed) is repeated with protocol 0's front; a trial
+ *      that is not cleanly accepted is finished by the ordinary LM loop with the trial sums gathered per round.  All decisions
+ *      are taken on gathered data: every rank takes the same.  Needs a latency-mode handle with its default kernel fusion.
+ *   0  the round-3 protocol: every call recomputes its keys and gathers all of them (16 B per observation). */
 int vba_sh_unique_id(const char* rccl_path, void* id128);
 int vba_sh_comm_init(vba_handle h, const char* rccl_path, const void* id128, int nranks, int rank);
 int vba_sh_call(vba_handle h, int iter, int initialize, int64_t m_total, int* n_trials);
+/* ncalls consecutive BA() calls on the sharded window as one host call (the driver's loop od_pipe.py:1036-1040), chained on the
+ * device in protocol 1; *trials_total: LM rounds issued.  vba_sh_call is the schedule of one call. */
+int vba_sh_run_schedule(vba_handle h, int ncalls, const int* iters, const int* inits, int64_t m_total, int* trials_total);
+int vba_sh_set_protocol(vba_handle h, int carried_keys);
+/* bytes this rank contributes to the first exchange of a call; calls repeated after a missed select; calls finished by the LM loop */
+int vba_sh_stats(vba_handle h, int64_t* bytes_first_exchange, int64_t* fallbacks_miss, int64_t* fallbacks_lm);
 int vba_sh_comm_destroy(vba_handle h);
 
 /* ---- free-landmark Schur-complement BA: ADD-ON, PARITY UNPINNED ------------------------------------------

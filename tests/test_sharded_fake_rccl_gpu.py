@@ -96,6 +96,33 @@ def _worker(rank, world, port, tmp):
             ref2, lam2, _, ntr2 = O.ba_iteration(it, ref2, inp["cumrot"], uv, xyz, ii, inp["time_idx"], inp["K"], conf, lam2, initialize=init)
             assert sa[3] == ntr2 and sa[1] == lam2 and np.abs(sa[0] - ref2).max() / np.abs(ref2).max() < 1e-7, it
         rounds.append(-1)
+        # the 20-call schedule chained on the device (one host synchronisation) with two ranks, and with every carried select
+        # forced to miss (both ranks fall back alike: the decision is taken on gathered data): the bits of call-by-call stepping
+        iters, inits = list(range(20)), [k < 10 for k in range(20)]
+        finals = []
+        for miss, chained in ((False, False), (False, True), (True, True)):
+            e = engine(lo2, hi2)
+            if miss:
+                e.set_warm_select(2)
+            stg = HipStageEngine(e, torch_stream=False)
+            stg.attach_rccl(dist, None, FAKE)
+            sb = ShardedBA(stg, n, hi2 - lo2, m)
+            sb.set_states(st, lam)
+            if chained:
+                sb.run_schedule(iters, inits)
+            else:
+                for it, init in zip(iters, inits):
+                    sb.step(it, init)
+            finals.append(sb.get_states())
+            first, misses, lm = stg.stats()
+            assert first <= 16 * 1024 and (misses >= 18) == miss and lm > 0, (first, misses, lm)
+            sb.close()
+        for f in finals[1:]:
+            assert np.array_equal(f[0], finals[0][0]) and f[1] == finals[0][1] and f[3] == finals[0][3]
+        ref3, lam3 = st.copy(), lam
+        for it, init in zip(iters, inits):
+            ref3, lam3, _, _ = O.ba_iteration(it, ref3, inp["cumrot"], uv, xyz, ii, inp["time_idx"], inp["K"], conf, lam3, initialize=init)
+        assert finals[0][1] == lam3 and np.abs(finals[0][0] - ref3).max() / np.abs(ref3).max() < 1e-6
         if rank == 0:
             np.save(os.path.join(tmp, "rounds.npy"), np.array(rounds))
             single.close()

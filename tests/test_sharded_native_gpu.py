@@ -81,6 +81,84 @@ def _worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
+def _worker_protocols(rank, world, port, tmp):
+    """Carried-keys protocol (default) against the round-3 protocol and the unsharded engine: call by call, the 20-call schedule
+    chained on the device (vba_sh_run_schedule), every carried select forced to miss (fallback: exact select over all keys)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from conftest import golden_inputs, load_golden
+    from vinsat_amd.dist import HipStageEngine, ShardedBA
+    from vinsat_amd.engine import BAEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        g = load_golden("c2")
+        inp = golden_inputs(g)
+        n, m = inp["K"].shape[0], inp["xyz"].shape[0]
+        iters, inits = list(range(20)), [k < 10 for k in range(20)]
+        out = {}
+        for confname, conf in (("golden", inp["conf"]), ("rejecting", np.full(m, 3.0))):
+            def make(proto, force_miss=False):
+                eng = BAEngine(n, m)
+                eng.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
+                eng.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+                if force_miss:
+                    eng.set_warm_select(2)
+                stage = HipStageEngine(eng, torch_stream=False)
+                stage.attach_rccl(dist)
+                stage.set_protocol(proto)
+                return ShardedBA(stage, n, m, m)
+
+            res = {}
+            for name, proto, miss, chained in (("carried", 1, False, False), ("carried-chained", 1, False, True), ("round3", 0, False, False),
+                                               ("carried-missing", 1, True, True)):
+                sb = make(proto, miss)
+                sb.set_states(g["states0"][0], 1e-4)
+                if chained:
+                    sb.run_schedule(iters[:7], inits[:7])          # two schedules: the second starts from carried keys
+                    sb.run_schedule(iters[7:], inits[7:])
+                else:
+                    for it, init in zip(iters, inits):
+                        sb.step(it, init)
+                res[name] = sb.get_states()
+                first, misses, lm = sb.engine.stats()
+                if proto == 1:
+                    assert first <= 16 * 1024, first                # the first exchange of a call: histogram + block sums, not 16 B per row
+                    assert (misses >= 18) == miss, (name, misses)   # forced misses: every carried call fell back (the first has no carried keys)
+                    assert (lm > 0) == (confname == "rejecting"), (name, lm)
+                else:
+                    assert first == 16 * m
+                sb.close()
+            single = BAEngine(n, m)
+            single.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
+            single.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
+            single.set_states(g["states0"][0], 1e-4)
+            single.run_schedule(iters, inits)
+            ref = single.get_states()
+            single.close()
+            base = res["carried"]
+            for name, r in res.items():
+                assert np.array_equal(r[0], base[0]) and r[1] == base[1] and r[3] == base[3], (confname, name)     # one set of bits
+            assert base[1] == ref[1] and base[3] == ref[3] and np.abs(base[0] - ref[0]).max() / np.abs(ref[0]).max() < 1e-9, confname
+            if confname == "golden":
+                assert np.abs(base[0] - g["states_out_19"][0]).max() / np.abs(g["states_out_19"][0]).max() < 1e-6
+            out[confname] = base[3]
+        np.save(os.path.join(tmp, "ntr.npy"), np.array([out["golden"], out["rejecting"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_carried_keys_protocol_chained_stepped_and_falling_back_gives_one_set_of_bits(tmp_path):
+    port = 29100 + (os.getpid() % 200)
+    mp.spawn(_worker_protocols, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert np.load(tmp_path / "ntr.npy").shape == (2,)
+
+
 def test_library_issued_rccl_exchanges_match_the_caller_dispatched_protocol(tmp_path):
     port = 29500 + (os.getpid() % 200)
     mp.spawn(_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)

@@ -69,6 +69,9 @@ SIGNATURES = {
     "vba_sh_unique_id": (c_int, [c_char_p, c_void_p]),
     "vba_sh_comm_init": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int]),
     "vba_sh_call": (c_int, [c_void_p, c_int, c_int, c_int64, POINTER(c_int)]),
+    "vba_sh_run_schedule": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), c_int64, POINTER(c_int)]),
+    "vba_sh_set_protocol": (c_int, [c_void_p, c_int]),
+    "vba_sh_stats": (c_int, [c_void_p, PI64, PI64, PI64]),
     "vba_sh_comm_destroy": (c_int, [c_void_p]),
     # free-landmark Schur add-on (parity unpinned: no counterpart in the reference)
     "vba_schur_last_error": (c_char_p, []),

@@ -105,6 +105,16 @@ struct vba_context {
         int64_t m_total = 0, m_pad = 0;     // what buf was sized for
         int n = 0;
         int m_local = -1;                   // rows of this rank the +inf padding of abs_local was laid out for
+        // carried-keys protocol (vba_sh_run_schedule): exchange buffers that the kernels write in place
+        int protocol = 1;                   // 1 = carried keys (default), 0 = the round-3 protocol (every call gathers all keys)
+        ncclResult_t (*group_start)() = nullptr;
+        ncclResult_t (*group_end)() = nullptr;
+        double* buf2 = nullptr;             // sendA[2] | recvA | sendB | recvB
+        int lenA = 0, lenB = 0, n2 = 0, nbo2 = 0, nbd2 = 0, cap2 = 0;
+        double *sendA[2] = {nullptr, nullptr}, *recvA = nullptr, *sendB = nullptr, *recvB = nullptr;
+        bool carried = false;               // recvA holds the exchange of the trial that produced the resident states: the next call may start from it
+        int carried_par = 0;                // ... whose parity (the parity of the call that will read it)
+        long fallbacks_miss = 0, fallbacks_lm = 0;
         double *abs_local = nullptr, *abs_all = nullptr, *partial_local = nullptr, *partial_all = nullptr, *trial_local = nullptr, *trial_all = nullptr;
     } shc;
     int pack_min = 1 << 30;                 // windows from which three chains share a wavefront: never by default (measured at 1024 / 2048 / 4096
@@ -1966,25 +1976,25 @@ int vba_sh_comm_destroy(vba_handle h) {
     hipStreamSynchronize(h->stream);
     if (S.comm) S.comm_destroy(S.comm);
     if (S.buf) hipFree(S.buf);
+    if (S.buf2) hipFree(S.buf2);
     if (S.dl) dlclose(S.dl);
     S = {};
     return VBA_OK;
 }
 
-int vba_sh_call(vba_handle h, int iter, int initialize, int64_t m_total, int* n_trials) {
-    if (!h || m_total < 1) return fail(VBA_EINVAL, "bad argument");
+namespace {
+
+// exchange buffers of a sharded window (both protocols); m_total rows over all ranks
+int sh_ensure_buffers(vba_handle h, int64_t m_total) {
     auto& S = h->shc;
-    if (!S.comm) return fail(VBA_ESTATE, "vba_sh_comm_init has not run");
-    if (int rc = ready(h)) return rc;
-    HIPCHK(hipSetDevice(h->device));
     const int n = h->n[0];
     const int64_t m_pad = (m_total + S.nranks - 1) / S.nranks;     // equal all-gather slots
     if (h->m[0] > m_pad) return fail(VBA_EINVAL, "this rank holds more rows than ceil(m_total / ranks)");
     const int64_t pc = vba_sh_partial_count(n);
+    const int64_t R = S.nranks;
     if (S.m_total != m_total || S.n != n) {       // (re)size the exchange buffers; the padding of a slot sorts above every |r|
         HIPCHK(hipStreamSynchronize(h->stream));
         if (S.buf) { HIPCHK(hipFree(S.buf)); S.buf = nullptr; }
-        const int64_t R = S.nranks;
         const int64_t total = 2 * m_pad * (1 + R) + pc * (1 + R) + 2 * (1 + R) + 64;
         HIPCHK(hipMalloc((void**)&S.buf, (size_t)total * 8));
         S.abs_local = S.buf;
@@ -1995,6 +2005,7 @@ int vba_sh_call(vba_handle h, int iter, int initialize, int64_t m_total, int* n_
         S.trial_all = S.trial_local + 2;
         S.m_total = m_total; S.m_pad = m_pad; S.n = n;
         S.m_local = -1;
+        S.carried = false;
     }
     if (S.m_local != h->m[0]) {     // stage 1 writes 2 * m_local keys: everything behind them must sort above every |r| -- also after
                                     // a re-upload with FEWER rows of this rank than before (the old shard's keys would enter the median)
@@ -2002,20 +2013,49 @@ int vba_sh_call(vba_handle h, int iter, int initialize, int64_t m_total, int* n_
         std::vector<double> inf((size_t)(2 * m_pad), INFINITY);
         HIPCHK(hipMemcpy(S.abs_local, inf.data(), inf.size() * 8, hipMemcpyHostToDevice));
         S.m_local = h->m[0];
+        S.carried = false;
     }
-    auto gather = [&](const double* src, double* dst, int64_t count) -> int {
-        const ncclResult_t rc = S.all_gather(src, dst, (size_t)count, ncclDouble, S.comm, h->stream);
-        if (rc != ncclSuccess) return fail(VBA_EHIP, std::string("ncclAllGather failed: ") + S.error_string(rc));
-        return VBA_OK;
-    };
+    // carried-keys protocol: [hist 1024 | part_next nblk_obs | part_trial trial_stride] per call parity, the gathered copy, the
+    // bucket slots [count | keys bucket_cap]
+    const int nbo = h->V.nblk_obs, cap = h->V.bucket_cap;
+    const int lenA = 1024 + nbo + h->V.trial_stride, lenB = cap + 1;
+    if (S.protocol == 1 && cap > 0 && (S.lenA != lenA || S.lenB != lenB || !S.buf2)) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (S.buf2) { HIPCHK(hipFree(S.buf2)); S.buf2 = nullptr; }
+        const size_t total = (size_t)lenA * (2 + R) + (size_t)lenB * (1 + R) + 64;
+        HIPCHK(hipMalloc((void**)&S.buf2, total * 8));
+        HIPCHK(hipMemset(S.buf2, 0, total * 8));
+        S.sendA[0] = S.buf2;
+        S.sendA[1] = S.sendA[0] + lenA;
+        S.recvA = S.sendA[1] + lenA;
+        S.sendB = S.recvA + (size_t)lenA * R;
+        S.recvB = S.sendB + lenB;
+        S.lenA = lenA; S.lenB = lenB;
+        S.carried = false;
+    }
+    return VBA_OK;
+}
+
+int sh_gather(vba_handle h, const double* src, double* dst, int64_t count) {
+    auto& S = h->shc;
+    const ncclResult_t rc = S.all_gather(src, dst, (size_t)count, ncclDouble, S.comm, h->stream);
+    if (rc != ncclSuccess) return fail(VBA_EHIP, std::string("ncclAllGather failed: ") + S.error_string(rc));
+    return VBA_OK;
+}
+
+// ---- round-3 protocol: every call gathers all |r| keys (kept for comparison, vba_sh_set_protocol(h, 0))
+int sh_call_classic(vba_handle h, int iter, int initialize, int64_t m_total, int* n_trials) {
+    auto& S = h->shc;
+    const int n = h->n[0];
+    const int64_t pc = vba_sh_partial_count(n);
     if (int rc = vba_sh_stage1(h, iter, initialize, m_total, S.abs_local)) return rc;
-    if (int rc = gather(S.abs_local, S.abs_all, 2 * m_pad)) return rc;
-    if (int rc = vba_sh_stage2(h, S.abs_all, 2 * m_pad * S.nranks, S.partial_local)) return rc;
-    if (int rc = gather(S.partial_local, S.partial_all, pc)) return rc;
+    if (int rc = sh_gather(h, S.abs_local, S.abs_all, 2 * S.m_pad)) return rc;
+    if (int rc = vba_sh_stage2(h, S.abs_all, 2 * S.m_pad * S.nranks, S.partial_local)) return rc;
+    if (int rc = sh_gather(h, S.partial_local, S.partial_all, pc)) return rc;
     int trials = 0;
     for (bool first = true;; first = false) {
         if (int rc = vba_sh_stage3(h, first ? S.partial_all : nullptr, S.nranks, S.trial_local)) return rc;
-        if (int rc = gather(S.trial_local, S.trial_all, 2)) return rc;
+        if (int rc = sh_gather(h, S.trial_local, S.trial_all, 2)) return rc;
         int done = 0;
         if (int rc = vba_sh_stage4(h, S.trial_all, S.nranks, &done)) return rc;
         ++trials;
@@ -2025,6 +2065,251 @@ int vba_sh_call(vba_handle h, int iter, int initialize, int64_t m_total, int* n_
     }
     if (n_trials) *n_trials = trials;
     return VBA_OK;
+}
+
+// ---- carried-keys protocol.  One BA() call of a rank, first trial (everything asynchronous on the handle's stream):
+//   front, carried   k_sh_front   [accept test of the call in front on the gathered block sums] + the R warm histograms added up,
+//                                 the bin of the global median resolved, this rank's bucket of it -> sendB
+//                    all-gather B buckets of that bin (<= 8 kB per rank)
+//                    k_obs_accumulate  ranks the gathered buckets in its prologue (exact median), weights, local per-pose sums
+//                                 straight into the exchange buffer; the dynamics factor rides in its grid
+//   front, classic   (first call on new states; a call whose carried select missed)  residual pass -> all-gather of all keys
+//                                 -> exact select -> accumulation -> pack
+//                    all-gather C per-pose normal equations (27 n + 2 doubles) [-> rank-ordered reduce; one rank: used in place]
+//   solve            the handle's latency-mode kernels (every rank redundantly: bit-identical systems)
+//   trial            k_trial: trial residuals of the local rows + next call's keys in bin buckets, warm histogram and block sums,
+//                                 the latter two written straight into sendA
+//                    all-gather A [histogram | block sums] (~12 kB per rank) -- decided by the NEXT call's k_sh_front
+// Every rank enqueues the same collectives whether its window runs a call or skips it (a window that stalls at a call --
+// trial not cleanly accepted, select missed -- leaves the rest of the chain untouched on EVERY rank alike, the decisions being
+// taken on gathered data), and the host synchronises once per schedule.
+struct Sh2 {
+    vba_handle h;
+    int R;
+    const int *iters, *inits;
+    int ncalls, par0;
+
+    CallSpec spec(int c, bool carried, bool fold) const {
+        CallSpec q;
+        q.iter = iters[c]; q.initialize = inits[c]; q.call = c; q.par = (par0 + c) & 1;
+        q.carry = carried ? 2 : 0;
+        q.emit = 2;
+        q.fold = fold;
+        return q;
+    }
+    // the view of call q: exchange buffers where the kernels write anyway
+    void view(DevView& V, const CallSpec& q) const {
+        auto& S = h->shc;
+        view_for_call(h, V, q);
+        V.fuse_walk = 0;
+        V.m_total = S.m_total;
+        V.hist0_ext[0] = reinterpret_cast<unsigned*>(S.sendA[0]);
+        V.hist0_ext[1] = reinterpret_cast<unsigned*>(S.sendA[1]);
+        V.part_next = S.sendA[q.par ^ 1] + 1024;                     // the trial of this call writes the next call's slot
+        V.part_trial = V.part_next + V.nblk_obs;
+        V.sel_inline = 0;
+        V.pivot = h->sh_pivot;
+    }
+
+    int enqueue_call(int c, bool carried, bool fold) {
+        auto& S = h->shc;
+        hipStream_t s = h->stream;
+        const CallSpec q = spec(c, carried, fold);
+        const int n = h->n[0];
+        const int64_t pc = vba_sh_partial_count(n);
+        const bool init = q.initialize != 0;
+        CallCtx C;
+        view(C.V, q);
+        DevView& V = C.V;
+        h->sh_pivot = h->pivot_mode;
+        V.pivot = h->sh_pivot;
+        V.dyn_in_acc = (!init && V.lat) ? 1 : 0;
+        if (carried) {
+            if (fold) fill_params(V.prev, iters[c - 1], inits[c - 1]);
+            if (R > 1) V.wmax_ext = reinterpret_cast<unsigned long long*>(S.partial_local + (size_t)27 * n);     // (the front clears it)
+            launch_sh_front(V, S.recvA, R, S.lenA, S.sendB, fold ? 1 : 0, 1, s);
+            if (int rc = sh_gather(h, S.sendB, S.recvB, S.lenB)) return rc;
+            DevView Va = V;             // the accumulation: gathered buckets in, sums straight into the exchange buffer
+            Va.sel_slots = S.recvB; Va.sel_nslots = R; Va.sel_slot_stride = S.lenB;
+            Va.Hraw = S.partial_local; Va.braw = S.partial_local + (size_t)21 * n;
+            launch_obs_accumulate(Va, s);
+            if (int rc = sh_gather(h, S.partial_local, S.partial_all, pc)) return rc;
+            if (R > 1) launch_shard_reduce(V, S.partial_all, R, s, 0);
+            else { V.Hraw = S.partial_all; V.braw = S.partial_all + (size_t)21 * n; }      // one rank: the gathered copy IS the sum
+        } else {
+            // no carried keys: residual pass, all keys gathered, exact select
+            DevView Q = V;
+            for (int p = 0; p < 2; ++p) { Q.par = p; launch_clear_hist(Q, 1, s); }
+            V.redo = 2;                 // (a window repeating a call whose carried select missed takes part)
+            launch_sh_clear_miss(V, s);
+            launch_obs_residual(V, S.abs_local, s);
+            if (int rc = sh_gather(h, S.abs_local, S.abs_all, 2 * S.m_pad)) return rc;
+            DevView Vs = V;
+            Vs.abs_all = S.abs_all; Vs.abs_all_count = 2 * S.m_pad * R;
+            launch_select(Vs, true, s);
+            launch_obs_accumulate(Vs, s);
+            launch_shard_pack(V, S.partial_local, s);
+            if (int rc = sh_gather(h, S.partial_local, S.partial_all, pc)) return rc;
+            launch_shard_reduce(V, S.partial_all, R, s, 1);
+        }
+        if (!init && !V.dyn_in_acc) launch_dynamics(V, s);
+        const bool need_bands = init ? V.fused_trial != 1 : !solve_forms_blocks(V);
+        if (need_bands) launch_assemble(V, 0, s);
+        C.fuse_assemble = false;
+        C.assembled = C.bands_ready = need_bands;
+        enqueue_trial(h, C, q, true);
+        if (int rc = sh_gather(h, S.sendA[q.par ^ 1], S.recvA, S.lenA)) return rc;
+        return VBA_OK;
+    }
+
+    // call c stalled at its first trial (rejected, pivot check failed): the ordinary LM loop, the trial sums gathered per round
+    int finish_stalled(int c, bool carried, long& trials) {
+        auto& S = h->shc;
+        hipStream_t s = h->stream;
+        const CallSpec q = spec(c, carried, false);
+        CallCtx C;
+        view(C.V, q);
+        DevView& V = C.V;
+        const int n = h->n[0];
+        if (R == 1 && carried) { V.Hraw = S.partial_all; V.braw = S.partial_all + (size_t)21 * n; }    // (where the call's sums live, see enqueue_call)
+        V.redo = 2;
+        const bool init = q.initialize != 0;
+        C.fuse_assemble = false;
+        C.assembled = C.bands_ready = init ? V.fused_trial != 1 : !solve_forms_blocks(V);
+        for (int round = 0; round <= 24; ++round) {
+            launch_shard_trial_sum(V, S.trial_local, s);
+            if (int rc = sh_gather(h, S.trial_local, S.trial_all, 2)) return rc;
+            launch_decide(V, S.trial_all, R, s);
+            HIPCHK(hipGetLastError());
+            if (int rc = read_heads(h)) return rc;
+            if (head(h, 0)->done) {
+                // the last trial left the next call's keys, histogram and block sums: exchange them as every trial's are
+                if (int rc = sh_gather(h, S.sendA[q.par ^ 1], S.recvA, S.lenA)) return rc;
+                S.fallbacks_lm++;
+                return VBA_OK;
+            }
+            if (round == 24) break;
+            if ((head(h, 0)->flags & 8u) && h->sh_pivot == 0) { h->sh_pivot = 2; h->fallbacks++; }
+            V.pivot = h->sh_pivot;
+            enqueue_trial(h, C, q, false);
+            ++trials;
+        }
+        return fail(VBA_ESTATE, "sharded BA call: the LM loop did not terminate within 24 rounds");
+    }
+};
+
+}  // namespace
+
+int vba_sh_set_protocol(vba_handle h, int carried_keys) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc = settle(h)) return rc;
+    h->shc.protocol = carried_keys ? 1 : 0;
+    h->shc.carried = false;
+    return VBA_OK;
+}
+
+int vba_sh_stats(vba_handle h, int64_t* bytes_first_exchange, int64_t* fallbacks_miss, int64_t* fallbacks_lm) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    auto& S = h->shc;
+    if (bytes_first_exchange) *bytes_first_exchange = (S.protocol == 1 && S.lenA) ? (int64_t)S.lenA * 8 : 16 * S.m_pad;
+    if (fallbacks_miss) *fallbacks_miss = S.fallbacks_miss;
+    if (fallbacks_lm) *fallbacks_lm = S.fallbacks_lm;
+    return VBA_OK;
+}
+
+int vba_sh_run_schedule(vba_handle h, int ncalls, const int* iters, const int* inits, int64_t m_total, int* trials_total) {
+    if (!h || !iters || !inits || ncalls < 1 || m_total < 1) return fail(VBA_EINVAL, "bad argument");
+    auto& S = h->shc;
+    if (!S.comm) return fail(VBA_ESTATE, "vba_sh_comm_init has not run");
+    if (int rc_settle = settle(h)) return rc_settle;
+    if (h->W != 1) return fail(VBA_EINVAL, "sharded mode uses a single window per handle");
+    if (h->reg) return fail(VBA_EINVAL, "sharded mode does not take a prior (vba_set_prior)");
+    if (int rc = ready(h)) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    if (int rc = sh_ensure_buffers(h, m_total)) return rc;
+    if (S.protocol == 0 || !h->V.wbucket || !h->V.lat || !(h->fusion & 1) || h->V.chunk <= 0) {
+        // the round-3 protocol, call by call
+        long total = 0;
+        for (int c = 0; c < ncalls; ++c) {
+            int t = 0;
+            if (int rc = sh_call_classic(h, iters[c], inits[c], m_total, &t)) return rc;
+            total += t;
+        }
+        S.carried = false;
+        if (trials_total) *trials_total = (int)total;
+        return VBA_OK;
+    }
+    hipStream_t s = h->stream;
+    h->V.m_total = m_total;
+    Sh2 P{h, S.nranks, iters, inits, ncalls, h->par};
+    bool carried0 = S.carried && h->carry_ok == 2 && S.carried_par == h->par;
+    h->carry_ok = 0;
+    S.carried = false;
+    struct Abandon {
+        vba_handle h; bool armed = true;
+        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = 0; h->V.m_total = 0; } }
+    } abandon{h};
+    {
+        DevView V0;
+        P.view(V0, P.spec(0, false, false));
+        launch_reset_calls(V0, s);
+    }
+    h->h_head[0].call_idx = 0; h->h_head[0].done = 0; h->h_head[0].flags = 0;
+    long trials = 0;
+    int next = 0;
+    bool first_carried = carried0;
+    for (int guard = 0; guard <= 2 * ncalls + 2; ++guard) {
+        for (int c = next; c < ncalls; ++c) {
+            const bool carried = c == next ? first_carried : true;
+            const bool fold = carried && c > next;
+            if (int rc = P.enqueue_call(c, carried, fold)) return rc;
+            // a call without carried keys in front of it is decided by a launch of its own (nothing folds it) when the NEXT
+            // call's front does not: the next call is always carried, so only the last call of the schedule is left over
+        }
+        {   // the accept test of the last call: the front kernel with nothing to resolve
+            CallSpec q = P.spec(ncalls - 1, true, true);
+            q.call = ncalls; q.par = (P.par0 + ncalls) & 1;
+            DevView V;
+            P.view(V, q);
+            fill_params(V.prev, iters[ncalls - 1], inits[ncalls - 1]);
+            launch_sh_front(V, S.recvA, P.R, S.lenA, S.sendB, 1, 0, s);
+        }
+        HIPCHK(hipGetLastError());
+        if (int rc = read_heads(h)) return rc;
+        const int at = (int)head(h, 0)->call_idx;
+        if (at >= ncalls) { trials += (long)(ncalls - next); break; }
+        if (head(h, 0)->flags & 32u) {          // the carried select of call `at` missed: that call again, exact select over all keys
+            trials += (long)(at - next);
+            S.fallbacks_miss++;
+            h->warm_misses++;
+            h->h_head[0].flags = 0;
+            next = at;
+            first_carried = false;
+            continue;
+        }
+        trials += (long)(at - next + 1);        // (the stalled call's first trial has run)
+        if (int rc = P.finish_stalled(at, at == next ? first_carried : true, trials)) return rc;
+        next = at + 1;
+        first_carried = true;
+        if (next >= ncalls) break;
+    }
+    if ((int)head(h, 0)->call_idx < ncalls) return fail(VBA_ESTATE, "sharded schedule did not complete (the window never reached its last call)");
+    abandon.armed = false;
+    h->par = (P.par0 + ncalls) & 1;
+    h->carry_ok = 2;
+    S.carried = true;
+    S.carried_par = h->par;
+    h->V.m_total = 0;
+    h->stepped = true;
+    h->last_pipelined = false;
+    h->last_iter = iters[ncalls - 1];
+    h->last_init = inits[ncalls - 1];
+    if (trials_total) *trials_total = (int)trials;
+    return VBA_OK;
+}
+
+int vba_sh_call(vba_handle h, int iter, int initialize, int64_t m_total, int* n_trials) {
+    return vba_sh_run_schedule(h, 1, &iter, &initialize, m_total, n_trials);
 }
 
 }  // extern "C"

@@ -199,6 +199,11 @@ struct DevView {
     int64_t m_total;
     const double* abs_all;          // gathered |r| of all ranks or nullptr
     int64_t abs_all_count;
+    // sharded mode, carried-keys protocol (vba_sh_run_schedule): what a rank exchanges lives where the kernels write it anyway
+    unsigned* hist0_ext[2];         // digit-0 / warm histogram of that call parity inside the exchange buffer (null: the handle's own slot)
+    const double* sel_slots;        // the gathered buckets of the median's bin, one slot per rank: [count, keys ...] (null: the list V.ckeys)
+    int sel_nslots, sel_slot_stride;
+    unsigned long long* wmax_ext;   // where the accumulation enters its maximum raw weight (null: WinScalars::wmax_bits of the call's parity)
 };
 
 // Speculatively chained calls (vba_run_schedule): the kernels of call c are enqueued before call c-1 is known to
@@ -209,7 +214,11 @@ struct DevView {
 #define VBA_WINDOW_RUNS(V, w) (((V).call < 0 || (V).sc[(w)].call_idx == (V).call) && ((V).redo == 2 || ((V).sc[(w)].miss != 0) == ((V).redo != 0)))
 #define VBA_SKIP_CALL(V, w) do { if (!VBA_WINDOW_RUNS(V, w)) return; } while (0)
 
-__device__ __forceinline__ unsigned* hist0_of(const DevView& V, int w, int par) { return V.hist + (size_t)w * kHistStride + (size_t)par * kSelBins; }
+__device__ __forceinline__ unsigned* hist0_of(const DevView& V, int w, int par) {
+    unsigned* own = V.hist + (size_t)w * kHistStride + (size_t)par * kSelBins;
+    unsigned* ext = V.hist0_ext[par];
+    return ext ? ext : own;
+}
 __device__ __forceinline__ unsigned* histd_of(const DevView& V, int w, int digit /*1..5*/) { return V.hist + (size_t)w * kHistStride + (size_t)(digit + 1) * kSelBins; }
 
 // ------------------------------------------------------------------------------------------------ wave helpers

@@ -19,6 +19,9 @@ void launch_set_counts(const DevView& V, int w, int n, int m, hipStream_t s);
 void launch_broadcast_states(const DevView& V, int n, double lamda, hipStream_t s);
 void launch_debug_project(const DevView& V, int w, int m, double* est, double* J, double* wt, hipStream_t s);
 
+void launch_sh_clear_miss(const DevView& V, hipStream_t s);
+void launch_sh_front(const DevView& V, const double* gathered, int ranks, int slot_len, double* bucket_out, int do_fold, int do_resolve, hipStream_t s);
+
 // vba_dyn.hip
 void launch_dynamics(const DevView& V, hipStream_t s);
 void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s);
@@ -35,7 +38,7 @@ void launch_decide(const DevView& V, const double* trial_all, int ranks, hipStre
 
 // vba_shard.hip
 void launch_shard_pack(const DevView& V, double* partial_out, hipStream_t s);
-void launch_shard_reduce(const DevView& V, const double* partial_all, int ranks, hipStream_t s);
+void launch_shard_reduce(const DevView& V, const double* partial_all, int ranks, hipStream_t s, int with_sum = 1);
 void launch_shard_trial_sum(const DevView& V, double* trial_local, hipStream_t s);
 
 }  // namespace vba

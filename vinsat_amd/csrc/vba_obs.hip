@@ -394,10 +394,28 @@ __device__ __forceinline__ double select_finish_list(const DevView& V, int w, co
     // latency mode loads the first 1024 entries speculatively together with the length (one round trip instead of two);
     // with many windows per launch every block of every window would drag 8 KB through the caches for a handful of keys
     unsigned long long pre[4];
+    if (V.sel_nslots > 0 && ck == V.sel_slots) {
+        // sharded mode: the list is the concatenation of the ranks' buckets of one warm bin, slot r = [count_r, keys ...];
+        // entry q of the list lives in the slot whose running count covers it (cnt <= 1024 is guaranteed by the front)
+        unsigned lo_q = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned q = threadIdx.x + 256u * j;
-        pre[j] = ((int64_t)q < cap && (speculate || q < cnt)) ? f64_bits(ck[q]) : 0ull;
+        for (int j = 0; j < 4; ++j) pre[j] = 0ull;
+        for (int r = 0; r < V.sel_nslots; ++r) {
+            const double* slot = ck + (size_t)r * V.sel_slot_stride;
+            const unsigned c_r = (unsigned)slot[0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned q = threadIdx.x + 256u * j;
+                if (q >= lo_q && q < lo_q + c_r && q < cnt) pre[j] = f64_bits(slot[1 + (q - lo_q)]);
+            }
+            lo_q += c_r;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned q = threadIdx.x + 256u * j;
+            pre[j] = ((int64_t)q < cap && (speculate || q < cnt)) ? f64_bits(ck[q]) : 0ull;
+        }
     }
     if (mode == 1 && cnt <= 1024u && V.warm_shift >= 8) {
         // One warm bin: every key is warm_base + rel, rel < 2^warm_shift.  Ranking ~130 keys by counting is a serial loop of
@@ -562,6 +580,8 @@ __device__ __forceinline__ double select_finish_list(const DevView& V, int w, co
 __device__ __forceinline__ double select_finish(const DevView& V, int w, unsigned* lh /*[kSelBins]*/, unsigned* lds_u /*[260]*/,
                                                 unsigned long long* skeys /*[1024] + 1*/) {
     const WinScalars& sc = V.sc[w];
+    if (V.sel_nslots > 0)       // sharded mode, carried keys: the ranks' buckets of the median's bin as gathered
+        return select_finish_list(V, w, V.sel_slots, 1024, sc.sel_cnt, sc.sel_rank[2], 1, sc.warm_base, false, lh, lds_u, skeys);
     return select_finish_list(V, w, V.ckeys + 2 * (size_t)w * V.m_max, 2 * V.m_max, sc.sel_cnt, sc.sel_rank[2], sc.sel_mode, sc.warm_base,
                               V.lat != 0, lh, lds_u, skeys);
 }
@@ -962,7 +982,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const double mx = fmax(fmax(wmx[0], wmx[1]), fmax(wmx[2], wmx[3]));
-        atomicMax(&sc.wmax_bits[V.par], f64_bits(mx));     // positive doubles order like their bit patterns
+        atomicMax(V.wmax_ext ? V.wmax_ext : &sc.wmax_bits[V.par], f64_bits(mx));     // positive doubles order like their bit patterns
     }
     VBA_ASTAMP(6);
 }
@@ -1253,6 +1273,127 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------- sharded mode: front of a carried call
+// Observation-sharded window, carried-keys protocol (vba_sh_run_schedule).  The trial kernel of every rank has left the keys of
+// ITS rows in bin buckets, their warm histogram and its block sums in the rank's exchange buffer; `gathered` holds those of
+// all R ranks (one all-gather of ~10 kB per rank instead of 16 B per observation).  One block, the same arithmetic on the same
+// data on every rank, so every rank decides alike:
+//   fold     the accept test of the call in front on the gathered block sums (observation part: every rank's; pose-chain
+//            part: rank 0's -- all ranks computed the same); a first trial that is not cleanly accepted leaves everything
+//            untouched and the window stalls there for the host's LM loop;
+//   resolve  the R histograms are added up (integers), the bin of the global lower median is found, and this rank's bucket
+//            of that bin goes into `bucket_out` = [count, keys ...] for the second (and last key-sized) exchange; a rank whose
+//            bucket overflowed, a bin longer than 1024 keys over all ranks or a rank outside the binned range is a MISS: the
+//            call takes the exact select over all keys instead (rank-consistent: the decision uses gathered data only).
+// Layout of a rank's slot of `gathered` (doubles): [hist: 1024 (2048 u32) | part_next: nblk_obs | part_trial: nblk_obs + nblk_dyn].
+__global__ __launch_bounds__(256) void k_sh_front(DevView V, const double* gathered, int ranks, int slot_len, double* bucket_out, int do_fold,
+                                                  int do_resolve) {
+    __shared__ unsigned lds_u[260];
+    __shared__ double red[5][4];
+    __shared__ unsigned over;
+    const int w = 0, t = threadIdx.x;
+    WinScalars& sc = V.sc[w];
+    const int off_next = 1024, off_trial = 1024 + V.nblk_obs;
+    if (do_fold) {
+        if (!(V.call >= 0 && sc.pending == V.call - 1 && sc.call_idx == V.call - 1)) return;
+    } else {
+        VBA_SKIP_CALL(V, w);
+    }
+    // sum |r_obs| at the states this call starts from, over all ranks (what fold_commit / k_decide leave is this rank's part)
+    double s_next = 0.0, s_trial = 0.0;
+    for (int q = 0; q < ranks; ++q) {
+        const double* slot = gathered + (size_t)q * slot_len;
+        for (int b = t; b < V.nblk_obs; b += 256) { s_next += slot[off_next + b]; s_trial += slot[off_trial + b]; }
+    }
+    for (int b = t; b < V.nblk_dyn; b += 256) s_trial += gathered[off_trial + V.nblk_obs + b];
+    if (do_fold) {
+        const int pc = V.par ^ 1;
+        DecideIn in;
+        in.s_pred = in.s_prior = 0.0;
+        if (!V.prev.initialize) {
+            const double* pp = V.part_pred + ((size_t)w * 2 + pc) * V.nblk_pred;
+            for (int b = t; b < V.nblk_pred; b += 256) in.s_pred += pp[b];
+        }
+        in.s_trial = s_trial;
+        in.s_next = s_next;
+        in.lam_in = sc.lam[pc];
+        in.so = sc.sum_in[pc];
+        in.flags = sc.fl[pc];
+        const DecideOut d = decide_finish(V, w, in, V.prev, 0, 0.0, nullptr, 0, red);
+        if (!(d.accept && !(d.flags & (2u | 8u | 32u)))) return;        // not clean: no trace
+        fold_commit(V, w, d);
+        if (!do_resolve && t == 0) {                    // the last call of a schedule: decided, nothing begins
+            sc.pending = -1;
+            sc.n_trials = 1;                            // (vba_get_states reports the decided call's)
+            sc.done = 1;
+        }
+    } else if (do_resolve) {
+        // (the call in front was decided by k_decide, which knows this rank's part only)
+        const double v = wave_sum(s_next);
+        __syncthreads();
+        if ((t & 63) == 0) red[0][t >> 6] = v;
+        __syncthreads();
+        if (t == 0) sc.sum_in[V.par] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    }
+    if (!do_resolve) return;
+    // the histograms of all ranks, bin by bin (this thread's eight bins as select_load assigns them)
+    unsigned hl[8], mine[8];
+    if (t == 0) over = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hl[j] = 0u;
+        for (int q = 0; q < ranks; ++q) {
+            const unsigned c = reinterpret_cast<const unsigned*>(gathered + (size_t)q * slot_len)[t * 8 + j];
+            hl[j] += c;
+        }
+        mine[j] = hist0_of(V, w, V.par)[t * 8 + j];
+    }
+    const int64_t count = 2 * V.m_total;
+    const unsigned long long lo = sc.warm_lo[V.par];
+    unsigned long long prefix;
+    long long rank;
+    unsigned in_bin;
+    select_resolve_loaded(hl, kSelBins, 11, 0ull, (count - 1) / 2, prefix, rank, lds_u, &in_bin);
+    const unsigned bin = (unsigned)prefix;
+    // every rank's bucket of that bin must be complete
+    if ((unsigned)(t * 8) <= bin && bin < (unsigned)(t * 8 + 8)) {
+        for (int q = 0; q < ranks; ++q)
+            if (reinterpret_cast<const unsigned*>(gathered + (size_t)q * slot_len)[bin] > (unsigned)V.bucket_cap) over = 1u;
+    }
+    __syncthreads();
+    const bool hit = lo != ~0ull && bin >= 1u && bin <= 2046u && in_bin <= 1024u && !over && !V.warm_force_miss;
+    if (t == 0) {
+        front_commit(V, w, hit, bin, rank, in_bin, false);
+        if (hit) sc.sel_cnt = in_bin;
+        if (V.wmax_ext) *V.wmax_ext = 0ull;
+    }
+    if (!hit) return;
+    // this rank's bucket of the bin: [count, keys ...]
+    unsigned my_cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if ((unsigned)(t * 8 + j) == bin) my_cnt = mine[j];
+    __syncthreads();
+    if ((unsigned)(t * 8) <= bin && bin < (unsigned)(t * 8 + 8)) lds_u[20] = my_cnt;
+    __syncthreads();
+    const unsigned cnt = lds_u[20];
+    const double* bucket = V.wbucket + (((size_t)w * 2 + V.par) * kSelBins + bin) * (size_t)V.bucket_cap;
+    if (t == 0) bucket_out[0] = (double)cnt;
+    for (unsigned q = t; q < cnt; q += 256) bucket_out[1 + q] = bucket[q];
+}
+
+// a call that missed its warm select is repeated with the exact select over all keys: the window takes part again
+__global__ void k_sh_clear_miss(DevView V) {
+    V.sc[0].miss = 0;
+    V.sc[0].fl[V.par] = 0u;
+    V.host_head[0].flags = 0u;
+}
+void launch_sh_clear_miss(const DevView& V, hipStream_t s) { hipLaunchKernelGGL(k_sh_clear_miss, dim3(1), dim3(1), 0, s, V); }
+
+void launch_sh_front(const DevView& V, const double* gathered, int ranks, int slot_len, double* bucket_out, int do_fold, int do_resolve, hipStream_t s) {
+    hipLaunchKernelGGL(k_sh_front, dim3(1), dim3(256), 0, s, V, gathered, ranks, slot_len, bucket_out, do_fold, do_resolve);
 }
 
 // ---------------------------------------------------------------------------------------------- debug

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void k_shard_pack(DevView V, double* out) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_shard_reduce(DevView V, const double* all, int ranks) {
+// with_sum == 0: the slot of sum |r_obs| is not in use (carried keys: the sum came with the trial's exchange)
+__global__ __launch_bounds__(256) void k_shard_reduce(DevView V, const double* all, int ranks, int with_sum) {
     const int n = V.n[0];
     const int cnt = 27 * n;
     const int64_t stride = cnt + 2;
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void k_shard_reduce(DevView V, const double* a
             sa += all[q * stride + cnt + 1];
         }
         V.sc[0].wmax_bits[V.par] = f64_bits(mx);
-        V.sc[0].sum_in[V.par] = sa;
+        if (with_sum) V.sc[0].sum_in[V.par] = sa;
     }
 }
 
@@ -61,8 +62,8 @@ __global__ __launch_bounds__(64) void k_shard_trial_sum(DevView V, double* out) 
 void launch_shard_pack(const DevView& V, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_shard_pack, dim3(64), dim3(256), 0, s, V, out);
 }
-void launch_shard_reduce(const DevView& V, const double* all, int ranks, hipStream_t s) {
-    hipLaunchKernelGGL(k_shard_reduce, dim3(64), dim3(256), 0, s, V, all, ranks);
+void launch_shard_reduce(const DevView& V, const double* all, int ranks, hipStream_t s, int with_sum) {
+    hipLaunchKernelGGL(k_shard_reduce, dim3(64), dim3(256), 0, s, V, all, ranks, with_sum);
 }
 void launch_shard_trial_sum(const DevView& V, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_shard_trial_sum, dim3(1), dim3(64), 0, s, V, out);

@@ -85,6 +85,27 @@ class HipStageEngine:
         self._check(self.lib.vba_sh_call(self.eng.h, int(it), int(bool(init)), int(m_total), ctypes.byref(ntr)), self.lib)
         return ntr.value
 
+    def run_schedule(self, iters, inits, m_total):
+        """``len(iters)`` consecutive BA() calls as ONE host call, chained on the device (``vba_sh_run_schedule``)."""
+        import ctypes
+        n = len(iters)
+        a = (ctypes.c_int * n)(*[int(x) for x in iters])
+        b = (ctypes.c_int * n)(*[int(bool(x)) for x in inits])
+        t = ctypes.c_int()
+        self._check(self.lib.vba_sh_run_schedule(self.eng.h, n, a, b, int(m_total), ctypes.byref(t)), self.lib)
+        return t.value
+
+    def set_protocol(self, carried_keys):
+        """True (default): the carried-keys protocol; False: every call gathers all |r| keys (round 3)."""
+        self._check(self.lib.vba_sh_set_protocol(self.eng.h, int(bool(carried_keys))), self.lib)
+
+    def stats(self):
+        """(bytes of this rank's first exchange per call, calls repeated after a missed select, calls finished by the LM loop)."""
+        import ctypes
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.vba_sh_stats(self.eng.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), self.lib)
+        return a.value, b.value, c.value
+
     def partial_count(self, n):
         return int(self.lib.vba_sh_partial_count(int(n)))
 
@@ -227,6 +248,17 @@ class ShardedBA:
                 raise RuntimeError(f"sharded BA call (iter {it}): LM loop did not terminate within {trials} trials")
         self.n_trials = trials
         return trials
+
+    def run_schedule(self, iters, inits):
+        """``len(iters)`` consecutive ``BA()`` calls; with the library-issued exchanges one host call, chained on the device."""
+        e = self.engine
+        if getattr(e, "native", False):
+            self.n_trials = e.run_schedule(iters, inits, self.m_total)
+            return self.n_trials
+        total = 0
+        for it, init in zip(iters, inits):
+            total += self.step(it, init)
+        return total
 
     def close(self):
         self.engine.close()
