@@ -2018,7 +2018,7 @@ int sh_ensure_buffers(vba_handle h, int64_t m_total) {
     // carried-keys protocol: [hist 1024 | part_next nblk_obs | part_trial trial_stride] per call parity, the gathered copy, the
     // bucket slots [count | keys bucket_cap]
     const int nbo = h->V.nblk_obs, cap = h->V.bucket_cap;
-    const int lenA = 1024 + nbo + h->V.trial_stride, lenB = cap + 1;
+    const int lenA = (1024 + nbo + h->V.trial_stride + 3) & ~3, lenB = (cap + 1 + 3) & ~3;      // (16-byte aligned slots)
     if (S.protocol == 1 && cap > 0 && (S.lenA != lenA || S.lenB != lenB || !S.buf2)) {
         HIPCHK(hipStreamSynchronize(h->stream));
         if (S.buf2) { HIPCHK(hipFree(S.buf2)); S.buf2 = nullptr; }

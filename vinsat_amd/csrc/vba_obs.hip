@@ -1296,31 +1296,51 @@ __global__ __launch_bounds__(256) void k_sh_front(DevView V, const double* gathe
     const int w = 0, t = threadIdx.x;
     WinScalars& sc = V.sc[w];
     const int off_next = 1024, off_trial = 1024 + V.nblk_obs;
-    if (do_fold) {
-        if (!(V.call >= 0 && sc.pending == V.call - 1 && sc.call_idx == V.call - 1)) return;
-    } else {
-        VBA_SKIP_CALL(V, w);
-    }
-    // sum |r_obs| at the states this call starts from, over all ranks (what fold_commit / k_decide leave is this rank's part)
-    double s_next = 0.0, s_trial = 0.0;
+    // Everything this kernel reads is requested FIRST (the addresses depend on nothing it learns later): the scalars of the
+    // window, the block sums and histograms of all ranks, this rank's own histogram, the inputs of the accept test -- one
+    // round trip to memory instead of a chain of five (one block: nobody hides a latency here).
+    const int seen_call = sc.call_idx, seen_pending = sc.pending, seen_miss = sc.miss;
+    const int pc = V.par ^ 1;
+    const double lam_in = sc.lam[pc], so_in = sc.sum_in[pc];
+    const unsigned fl_in = sc.fl[pc];
+    const unsigned long long lo = sc.warm_lo[V.par];
+    double s_next = 0.0, s_trial = 0.0, s_pred = 0.0;
     for (int q = 0; q < ranks; ++q) {
         const double* slot = gathered + (size_t)q * slot_len;
         for (int b = t; b < V.nblk_obs; b += 256) { s_next += slot[off_next + b]; s_trial += slot[off_trial + b]; }
     }
     for (int b = t; b < V.nblk_dyn; b += 256) s_trial += gathered[off_trial + V.nblk_obs + b];
-    if (do_fold) {
-        const int pc = V.par ^ 1;
-        DecideIn in;
-        in.s_pred = in.s_prior = 0.0;
-        if (!V.prev.initialize) {
-            const double* pp = V.part_pred + ((size_t)w * 2 + pc) * V.nblk_pred;
-            for (int b = t; b < V.nblk_pred; b += 256) in.s_pred += pp[b];
+    if (do_fold && !V.prev.initialize) {
+        const double* pp = V.part_pred + ((size_t)w * 2 + pc) * V.nblk_pred;
+        for (int b = t; b < V.nblk_pred; b += 256) s_pred += pp[b];
+    }
+    unsigned hl[8], mine[8];
+    if (do_resolve) {
+        const uint4* own4 = reinterpret_cast<const uint4*>(hist0_of(V, w, V.par)) + 2 * t;
+        const uint4 o0 = own4[0], o1 = own4[1];
+        mine[0] = o0.x; mine[1] = o0.y; mine[2] = o0.z; mine[3] = o0.w; mine[4] = o1.x; mine[5] = o1.y; mine[6] = o1.z; mine[7] = o1.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hl[j] = 0u;
+        for (int q = 0; q < ranks; ++q) {
+            const uint4* g4 = reinterpret_cast<const uint4*>(gathered + (size_t)q * slot_len) + 2 * t;
+            const uint4 g0 = g4[0], g1 = g4[1];
+            hl[0] += g0.x; hl[1] += g0.y; hl[2] += g0.z; hl[3] += g0.w; hl[4] += g1.x; hl[5] += g1.y; hl[6] += g1.z; hl[7] += g1.w;
         }
+    }
+    if (do_fold) {
+        if (!(V.call >= 0 && seen_pending == V.call - 1 && seen_call == V.call - 1)) return;
+    } else {
+        if (!((V.call < 0 || seen_call == V.call) && (V.redo == 2 || (seen_miss != 0) == (V.redo != 0)))) return;     // VBA_SKIP_CALL on the snapshot
+    }
+    if (do_fold) {
+        DecideIn in;
+        in.s_pred = s_pred;
+        in.s_prior = 0.0;
         in.s_trial = s_trial;
         in.s_next = s_next;
-        in.lam_in = sc.lam[pc];
-        in.so = sc.sum_in[pc];
-        in.flags = sc.fl[pc];
+        in.lam_in = lam_in;
+        in.so = so_in;
+        in.flags = fl_in;
         const DecideOut d = decide_finish(V, w, in, V.prev, 0, 0.0, nullptr, 0, red);
         if (!(d.accept && !(d.flags & (2u | 8u | 32u)))) return;        // not clean: no trace
         fold_commit(V, w, d);
@@ -1338,21 +1358,9 @@ __global__ __launch_bounds__(256) void k_sh_front(DevView V, const double* gathe
         if (t == 0) sc.sum_in[V.par] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
     }
     if (!do_resolve) return;
-    // the histograms of all ranks, bin by bin (this thread's eight bins as select_load assigns them)
-    unsigned hl[8], mine[8];
     if (t == 0) over = 0u;
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        hl[j] = 0u;
-        for (int q = 0; q < ranks; ++q) {
-            const unsigned c = reinterpret_cast<const unsigned*>(gathered + (size_t)q * slot_len)[t * 8 + j];
-            hl[j] += c;
-        }
-        mine[j] = hist0_of(V, w, V.par)[t * 8 + j];
-    }
     const int64_t count = 2 * V.m_total;
-    const unsigned long long lo = sc.warm_lo[V.par];
     unsigned long long prefix;
     long long rank;
     unsigned in_bin;
