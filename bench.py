@@ -743,7 +743,7 @@ def run_rank(args):
                 ms_s.append(sb.last_ms())
                 costs.append(c0)
                 lam_s = max(lam_s * 0.1, 1e-9) if ok else lam_s * 10
-            Np = (6 * 500 + 63) // 64 * 64
+            Np = (6 * 500 + 255) // 256 * 256
             fac = float(np.mean([x["factor"] for x in ms_s[1:]]))
             schur = {"parity": "unpinned (the reference keeps landmarks fixed, BA_filtering.py:32-37: no counterpart)",
                      "poses": 500, "landmarks": int(d["X_true"].shape[0]), "rows": int(d["uv"].shape[0]), "reduced_system": 3000,
@@ -751,11 +751,29 @@ def run_rank(args):
                      "trials_per_s": 1e3 / float(np.mean([sum(x.values()) for x in ms_s[1:]])),
                      "cholesky_TFLOPs": Np ** 3 / 3.0 / (fac * 1e-3) / 1e12, "fp64_matrix_peak_TFLOPs": MFMA_F64_PEAK_TFLOPS,
                      "cost_first_last": [costs[0], costs[-1]],
-                     "note": "dense reduced camera system factorised on the matrix cores; the MFMA counters of the 2000-pose / "
-                             "12000 x 12000 case are in profiles/r02_schur_mfma.json (trailing update 13.9 TFLOP/s = 18 % of the fp64 matrix peak)"}
+                     "note": "dense reduced camera system factorised on the matrix cores by panels of 256 columns with look-ahead (round 4); "
+                             "MFMA counters of the 12000 x 12000 case: profiles/r04_schur_mfma.json (trailing update 29.3 TFLOP/s = 37 % of the "
+                             "fp64 matrix peak over all its launches, whole factorisation 25.4 TFLOP/s = 32 %)"}
+            sb.close()
+            # the size at which a dense reduced camera system feeds the matrix cores: 2000 poses / 60 000 landmarks, 12 000 x 12 000
+            d = synth.make_tracked_landmarks(n_poses=2000, n_landmarks=60000, seed=0)
+            st_s = d["states_gt"].copy()
+            st_s[:, :3] += rng.normal(0, 2.0, st_s[:, :3].shape)
+            sb = SchurBA(st_s, d["X0"], d["uv"], np.full(d["uv"].shape[0], 0.95), d["pose_of_row"], d["landmark_of_row"], d["intrinsics"],
+                         sigma_prior=d["sigma"], device=device)
+            lam_s, facs = 1e-4, []
+            for it in range(4):
+                c0, c1, ok = sb.iterate(lam_s)
+                facs.append(sb.last_ms()["factor"])
+                lam_s = max(lam_s * 0.1, 1e-9) if ok else lam_s * 10
+            Np2 = (6 * 2000 + 255) // 256 * 256
+            fac2 = float(np.mean(facs[1:]))
+            schur["large"] = {"poses": 2000, "landmarks": int(d["X_true"].shape[0]), "rows": int(d["uv"].shape[0]), "reduced_system": 12000,
+                              "factor_ms": fac2, "cholesky_TFLOPs": Np2 ** 3 / 3.0 / (fac2 * 1e-3) / 1e12,
+                              "frac_of_fp64_matrix_peak": Np2 ** 3 / 3.0 / (fac2 * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS}
             sb.close()
         except Exception as exc:
-            schur = {"error": repr(exc)[:300]}
+            schur = {"error": repr(exc)[:300]} if schur is None else dict(schur, large_error=repr(exc)[:300])
 
     em.payload = {
         "metric": METRIC,

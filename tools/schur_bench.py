@@ -28,7 +28,7 @@ for it in range(int(sys.argv[3]) if len(sys.argv) > 3 else 6):
     ms.append(m_); hist.append((c0, c1, ok))
     lam = max(lam * 0.1, 1e-9) if ok else lam * 10
 N = 6 * n
-Np = (N + 63) // 64 * 64
+Np = (N + 255) // 256 * 256
 fact = [x["factor"] for x in ms[1:]]
 flops = Np ** 3 / 3.0
 out = {"poses": n, "landmarks": int(d["X_true"].shape[0]), "rows": int(d["uv"].shape[0]), "reduced_system": N,

@@ -2,7 +2,8 @@
 """Per-kernel averages of rocprofv3 --kernel-trace --stats directories: python tools/trace_summary.py <dir> ..."""
 import csv, glob, sys
 for d in sys.argv[1:]:
-    f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+    import os
+    f = sorted(glob.glob(d + "/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)[-1]      # (the newest run of that directory)
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print("==", d)

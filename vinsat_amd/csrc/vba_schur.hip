@@ -43,6 +43,7 @@ using namespace vba;
 typedef double vf4 __attribute__((ext_vector_type(4)));
 
 constexpr int kT = 64;              // tile of the blocked Cholesky
+constexpr int kPanel = 4;           // tile columns per panel: the trailing update runs with K = kPanel * kT = 256 (round 4)
 
 struct SchurView {
     int n, L;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(64) void k_pair_blocks(SchurView V) {
 
 // padding rows of the reduced system (N up to the next multiple of the tile): identity, so the factorisation runs on whole tiles
 __global__ void k_pad_identity(SchurView V) {
-    const int r = V.N + blockIdx.x * 64 + threadIdx.x;
+    const int r = V.N + blockIdx.x * 64 + threadIdx.x;      // (grid: enough blocks of 64 for the padding rows)
     if (r < V.Npad) V.S[(size_t)r * V.Npad + r] = 1.0;
 }
 
@@ -304,6 +305,128 @@ __global__ __launch_bounds__(64) void k_potrf64(SchurView V, int kb, int* info) 
     for (int rr = 0; rr < kT; ++rr) out[(size_t)rr * kT + r] = r <= rr ? x[rr] : 0.0;
 }
 
+// The same tile factorisation BLOCKED (round 4): four block columns of 16.  Only the 16 x 16 diagonal blocks are factorised
+// and inverted element by element (one wave, row per lane, 16 steps each instead of 64); the panel below a diagonal block, the
+// update of the tile's remaining blocks and the assembly of the full inverse (block lower triangular: X_jj = W_j,
+// X_ij = -W_i sum_k L_ik X_kj) are 16 x 16 x 16 products on the matrix cores, the tile living in LDS.  256 threads; the
+// chain of tile factorisations is the critical path of the whole Cholesky once the trailing update runs at K = 256 beside it.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// acc += A B^T (bt = true: b feeds B[lr][k]) or A B (bt = false: b feeds B[k][lr]); 16 x 16 blocks in LDS with leading dimension ld
+__device__ __forceinline__ vf4 mm16(vf4 acc, const double* A, const double* B, int ld, bool bt, int lr, int lk) {
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        const int k = 4 * sidx + lk;
+        const double a = A[lr * ld + k];
+        const double b = bt ? B[lr * ld + k] : B[k * ld + lr];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_potrf64b(SchurView V, int kb, int* info) {
+    constexpr int LD = kT + 1;
+    __shared__ double T[kT * LD];           // the tile, then its factor (lower)
+    __shared__ double X[kT * LD];           // its inverse (lower)
+    __shared__ double Y[4][16 * 17];        // per wave: an intermediate product
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, lr = lane & 15, lk = lane >> 4;
+    double* At = V.S + (size_t)(kb * kT) * V.Npad + kb * kT;
+    for (int e = t; e < kT * kT; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        T[r * LD + c] = At[(size_t)r * V.Npad + c];
+        X[r * LD + c] = 0.0;
+    }
+    __syncthreads();
+    for (int jb = 0; jb < 4; ++jb) {
+        const int o = 16 * jb;
+        if (wv == 0) {      // diagonal block: factor and inverse, row per lane (lanes 16 .. 63 ride along on an identity)
+            const int r = lane;
+            double a[16], x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = r < 16 ? T[(o + r) * LD + o + c] : (c == (r & 15) ? 1.0 : 0.0);
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double d = bcast64(a[j], j);
+                if (!(d > 0.0)) bad = true;
+                const double sd = sqrt(d > 0.0 ? d : 1.0), isd = 1.0 / sd;
+                a[j] = r == j ? sd : a[j] * isd;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) a[c] = fma(-a[j], bcast64(a[j], c), a[c]);
+            }
+            if (bad && r == 0) *info = kb * kT + o + 1;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                double sacc = rr == r ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < rr; ++k) sacc = fma(-bcast64(a[k], rr), x[k], sacc);
+                x[rr] = sacc / bcast64(a[rr], rr);
+            }
+            if (r < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    T[(o + r) * LD + o + c] = c <= r ? a[c] : 0.0;
+                    X[(o + c) * LD + o + r] = r <= c ? x[c] : 0.0;      // x[c] = X[c][r] of this block (lane r owns column r)
+                }
+            }
+        }
+        __syncthreads();
+        // panel below: L_i,jb = A_i,jb W^T, one row tile per wave
+        if (wv < 3 - jb) {
+            const int i = jb + 1 + wv;
+            double* Aij = T + (16 * i) * LD + o;
+            vf4 acc = (vf4){0.0, 0.0, 0.0, 0.0};
+            acc = mm16(acc, Aij, X + o * LD + o, LD, true, lr, lk);
+            wave_lds_sync();        // (all operands of this wave are read before it overwrites its own tile)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Aij[(lk + 4 * q) * LD + lr] = acc[q];
+        }
+        __syncthreads();
+        // the tile's remaining blocks: A_ik -= L_i,jb L_k,jb^T for jb < k <= i
+        {
+            int q = 0;
+            for (int i = jb + 1; i < 4; ++i)
+                for (int k = jb + 1; k <= i; ++k, ++q) {
+                    if ((q & 3) != wv) continue;
+                    vf4 acc = (vf4){0.0, 0.0, 0.0, 0.0};
+                    acc = mm16(acc, T + (16 * i) * LD + o, T + (16 * k) * LD + o, LD, true, lr, lk);
+                    double* C = T + (16 * i) * LD + 16 * k;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) C[(lk + 4 * qq) * LD + lr] -= acc[qq];
+                }
+        }
+        __syncthreads();
+    }
+    // the inverse below its diagonal blocks, by distance from the diagonal: X_ij = -W_i (sum_{k = j}^{i-1} L_ik X_kj)
+    for (int dist = 1; dist < 4; ++dist) {
+        if (wv < 4 - dist) {
+            const int j = wv, i = j + dist;
+            vf4 acc = (vf4){0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < i; ++k) acc = mm16(acc, T + (16 * i) * LD + 16 * k, X + (16 * k) * LD + 16 * j, LD, false, lr, lk);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Y[wv][(lk + 4 * q) * 17 + lr] = acc[q];
+            wave_lds_sync();
+            vf4 acc2 = (vf4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int k = 4 * sidx + lk;
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(16 * i + lr) * LD + 16 * i + k], Y[wv][k * 17 + lr], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) X[(16 * i + lk + 4 * q) * LD + 16 * j + lr] = -acc2[q];
+        }
+        __syncthreads();
+    }
+    double* out = V.invL + (size_t)kb * kT * kT;
+    for (int e = t; e < kT * kT; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if (c <= r) At[(size_t)r * V.Npad + c] = T[r * LD + c];
+        out[e] = c <= r ? X[r * LD + c] : 0.0;
+    }
+}
+
 // One 64x64 tile of  out = alpha * (C + sign * A B^T)  on the matrix cores.  A, B: 64x64 row major with leading dimension
 // lda / ldb.  256 threads = 4 waves, wave wv owns the 32x32 quadrant (wv >> 1, wv & 1) = 2x2 MFMA tiles of 16x16, K = 64
 // in 16 steps of 4.  v_mfma_f64_16x16x4: lane l feeds A[l & 15][4 s + (l >> 4)] and B^T[4 s + (l >> 4)][l & 15] = B[l & 15][..]
@@ -311,8 +434,9 @@ __global__ __launch_bounds__(64) void k_potrf64(SchurView V, int kb, int* info) 
 // panel form safe).
 //   MODE 0 (panel):    S_{I,kb} <- S_{I,kb} invL_kb^T              grid = tiles I > kb
 //   MODE 1 (trailing): S_{I,J}  -= S_{I,kb} S_{J,kb}^T             grid = tiles kb < J <= I
+//   MODE 2 (inside a panel): as MODE 1 for the tile columns kb < J <= jhi only, grid = (rows I >= kb + 1, those columns)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gemm_abt(SchurView V, int kb) {
+__global__ __launch_bounds__(256) void k_gemm_abt(SchurView V, int kb, int jhi = 0) {
     __shared__ double As[kT][kT + 1];
     __shared__ double Bs[kT][kT + 1];
     const int t = threadIdx.x;
@@ -320,6 +444,10 @@ __global__ __launch_bounds__(256) void k_gemm_abt(SchurView V, int kb) {
     if (MODE == 0) {
         I = kb + 1 + blockIdx.x;
         J = kb;
+    } else if (MODE == 2) {
+        I = kb + 1 + blockIdx.x;
+        J = kb + 1 + blockIdx.y;
+        if (J > jhi || I < J) return;
     } else {        // blockIdx.x enumerates the lower triangle of the (nb - kb - 1)^2 trailing tiles
         const int q = blockIdx.x;
         int r = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
@@ -367,6 +495,86 @@ __global__ __launch_bounds__(256) void k_gemm_abt(SchurView V, int kb) {
                 double* p = Cp + (size_t)r * V.Npad + c;
                 if (MODE == 0) *p = acc[x][y][i];
                 else if (I != J || c <= r) *p -= acc[x][y][i];
+            }
+}
+
+// Trailing update of a whole PANEL of kPanel tile columns (round 4): S_{I,J} -= sum_{k in panel} S_{I,k} S_{J,k}^T with K = 256 per
+// launch.  With K = 64 every 64 x 64 tile of the trailing matrix was read and written once per 64 columns -- 4 flop per byte,
+// the update ran at the speed of memory (13.9 TFLOP/s = 3.5 TB/s); here a block owns 128 x 128 of C and walks K = 256 in
+// chunks of 32 through LDS (16 x the arithmetic per byte of C, 2 x per byte of the operands); the next chunk's operands are
+// requested from memory before the current chunk's matrix operations are issued.  Grid: (128-row blocks from the first trailing one, 128-column
+// blocks [cj_lo, cj_hi]); blocks above the diagonal leave at once, diagonal blocks store their lower triangle.
+#ifndef VBA_SYRK_CHUNK
+#define VBA_SYRK_CHUNK 16
+#endif
+constexpr int kSyrkChunk = VBA_SYRK_CHUNK;
+// (four waves per SIMD: two blocks per compute unit, one computes while the other stages, waits at a barrier or updates C)
+__global__ __launch_bounds__(512, 4) void k_syrk_panel(SchurView V, int kb0, int b0, int cj_lo) {
+    __shared__ double As[128][kSyrkChunk + 1];
+    __shared__ double Bs[128][kSyrkChunk + 1];
+    const int bi = b0 + (int)blockIdx.x, bj = cj_lo + (int)blockIdx.y;
+    if (bi < bj) return;
+    // 512 threads = 8 waves, wave wv owns 64 rows x 32 columns of the block (4 x 2 matrix-core tiles, 8 accumulators: two waves
+    // per SIMD fit, one covers the other's LDS round trips and barriers -- with 64 x 64 per wave and one wave per SIMD the
+    // matrix pipe was busy a quarter of the time)
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int r0 = (wv >> 2) * 64, c0 = (wv & 3) * 32;
+    const size_t ld = (size_t)V.Npad;
+    const double* Ap = V.S + (size_t)(bi * 128) * ld + (size_t)kb0 * kT;
+    const double* Bp = V.S + (size_t)(bj * 128) * ld + (size_t)kb0 * kT;
+    constexpr int K = kPanel * kT, NK = K / kSyrkChunk;
+    // staging: 128 rows x kSyrkChunk columns per operand and chunk = 64 kSyrkChunk double2 / 512 threads = kSyrkChunk / 8 each
+    constexpr int NS = kSyrkChunk / 8, C2 = kSyrkChunk / 2;       // double2 per thread; double2 per row
+    double2 pa[NS], pb[NS];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int e = t + 512 * i, row = e / C2, c2 = (e % C2) * 2;
+            pa[i] = *reinterpret_cast<const double2*>(Ap + (size_t)row * ld + kc * kSyrkChunk + c2);
+            pb[i] = *reinterpret_cast<const double2*>(Bp + (size_t)row * ld + kc * kSyrkChunk + c2);
+        }
+    };
+    vf4 acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (vf4){0.0, 0.0, 0.0, 0.0};
+    fetch(0);
+    for (int kc = 0; kc < NK; ++kc) {
+        __syncthreads();            // the matrix operations of the previous chunk have read their operands
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int e = t + 512 * i, row = e / C2, c2 = (e % C2) * 2;
+            As[row][c2] = pa[i].x; As[row][c2 + 1] = pa[i].y;
+            Bs[row][c2] = pb[i].x; Bs[row][c2 + 1] = pb[i].y;
+        }
+        __syncthreads();
+        if (kc + 1 < NK) fetch(kc + 1);
+#pragma unroll
+        for (int sidx = 0; sidx < kSyrkChunk / 4; ++sidx) {
+            const int k = 4 * sidx + lk;
+            double a[4], b[2];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) a[x] = As[r0 + 16 * x + lr][k];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) b[y] = Bs[c0 + 16 * y + lr][k];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+    }
+    double* Cp = V.S + (size_t)(bi * 128) * ld + (size_t)bj * 128;
+    const bool diag = bi == bj;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + 16 * x + lk + 4 * i, c = c0 + 16 * y + lr;
+                if (!diag || c <= r) Cp[(size_t)r * ld + c] -= acc[x][y][i];
             }
 }
 
@@ -486,8 +694,10 @@ struct vba_schur_context {
     int device = 0;
     SchurView V{};
     char* arena = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, aux = nullptr;    // aux: the bulk of a panel's trailing update beside the next panel's factorisation
     hipEvent_t ev[5] = {};
+    hipEvent_t ev_chain = nullptr, ev_bulk = nullptr;
+    int classic = 0;                // VBA_SCHUR_CLASSIC=1: the round-2 tile-by-tile factorisation (comparison)
     int* d_info = nullptr;
     int last_info = 0;              // 0, or 1 + the row at which the last factorisation met a non-positive pivot
     double* S0 = nullptr;       // states buffers
@@ -520,7 +730,7 @@ int vba_schur_create(int device, int n, int64_t m, int L, int nblk, int64_t npai
     SchurView& V = h->V;
     V.n = n; V.m = m; V.L = L; V.nblk = nblk;
     V.N = 6 * n;
-    V.nb = (V.N + kT - 1) / kT;
+    V.nb = (V.N + kT * kPanel - 1) / (kT * kPanel) * kPanel;    // whole panels (the padding rows are an identity block)
     V.Npad = V.nb * kT;
     V.npart = (int)((std::max<int64_t>(m, L) + 255) / 256);
     h->npairs = npairs;
@@ -547,7 +757,11 @@ int vba_schur_create(int device, int n, int64_t m, int L, int nblk, int64_t npai
     V.S = (double*)(A + o_S); V.g = (double*)(A + o_g); V.ybuf = (double*)(A + o_y); V.invL = (double*)(A + o_iL);
     V.dl = (double*)(A + o_dl); V.part = (double*)(A + o_part); h->d_info = (int*)(A + o_info);
     h->h_part.resize(V.npart);
-    bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_bulk, hipEventDisableTiming) == hipSuccess;
+    if (const char* e = std::getenv("VBA_SCHUR_CLASSIC")) h->classic = std::atoi(e);
     for (int k = 0; k < 5 && ok; ++k) ok = hipEventCreate(&h->ev[k]) == hipSuccess;
     if (!ok) { vba_schur_destroy(h); return sfail(VBA_EHIP, "stream / event creation failed"); }
     *out = h;
@@ -558,6 +772,9 @@ int vba_schur_destroy(vba_schur_handle h) {
     if (!h) return VBA_OK;
     hipSetDevice(h->device);
     if (h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
+    if (h->aux) { hipStreamSynchronize(h->aux); hipStreamDestroy(h->aux); }
+    if (h->ev_chain) hipEventDestroy(h->ev_chain);
+    if (h->ev_bulk) hipEventDestroy(h->ev_bulk);
     for (hipEvent_t e : h->ev) if (e) hipEventDestroy(e);
     if (h->arena) hipFree(h->arena);
     delete h;
@@ -653,15 +870,48 @@ int vba_schur_iterate(vba_schur_handle h, double lamda, double* cost_before, dou
     hipLaunchKernelGGL(k_lm_blocks, dim3((V.L + 255) / 256), dim3(256), 0, s, V);
     hipLaunchKernelGGL(k_pose_blocks, dim3((V.n + 15) / 16), dim3(256), 0, s, V);
     hipLaunchKernelGGL(k_pair_blocks, dim3(V.nblk), dim3(64), 0, s, V);
-    if (V.Npad > V.N) hipLaunchKernelGGL(k_pad_identity, dim3(1), dim3(64), 0, s, V);
+    if (V.Npad > V.N) hipLaunchKernelGGL(k_pad_identity, dim3((V.Npad - V.N + 63) / 64), dim3(64), 0, s, V);
     SCHK(hipEventRecord(h->ev[1], s));
-    for (int kb = 0; kb < V.nb; ++kb) {
-        hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, s, V, kb, h->d_info);
-        const int rest = V.nb - kb - 1;
-        if (rest > 0) {
-            hipLaunchKernelGGL((k_gemm_abt<0>), dim3(rest), dim3(256), 0, s, V, kb);
-            hipLaunchKernelGGL((k_gemm_abt<1>), dim3(rest * (rest + 1) / 2), dim3(256), 0, s, V, kb);
+    if (h->classic == 1) {  // round 2: one tile column at a time, trailing update with K = 64 (VBA_SCHUR_CLASSIC=2: panels, round-2 tile kernel)
+        for (int kb = 0; kb < V.nb; ++kb) {
+            hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, s, V, kb, h->d_info);
+            const int rest = V.nb - kb - 1;
+            if (rest > 0) {
+                hipLaunchKernelGGL((k_gemm_abt<0>), dim3(rest), dim3(256), 0, s, V, kb, 0);
+                hipLaunchKernelGGL((k_gemm_abt<1>), dim3(rest * (rest + 1) / 2), dim3(256), 0, s, V, kb, 0);
+            }
         }
+    } else {
+        // Right-looking by PANELS of kPanel tile columns with look-ahead.  The panel is factorised tile column by tile column
+        // (diagonal tile in one wave's registers, panel rows by its inverse, the panel's remaining columns updated with K = 64:
+        // skinny, cheap); then the trailing matrix gets ONE update with K = 256.  That update is split: the 256 columns the NEXT
+        // panel consists of first, on this stream -- the next panel's factorisation (a chain of small dependent launches) then
+        // starts at once and runs beside the bulk of the update on the second stream.
+        const int np = V.nb / kPanel, nB = V.nb / 2;            // panels; 128-row blocks
+        bool bulk_pending = false;
+        for (int p = 0; p < np; ++p) {
+            const int kb0 = p * kPanel, klast = kb0 + kPanel - 1;
+            for (int kb = kb0; kb <= klast; ++kb) {
+                if (h->classic == 2) hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, s, V, kb, h->d_info);
+                else hipLaunchKernelGGL(k_potrf64b, dim3(1), dim3(256), 0, s, V, kb, h->d_info);
+                const int rest = V.nb - kb - 1;
+                if (rest > 0) hipLaunchKernelGGL((k_gemm_abt<0>), dim3(rest), dim3(256), 0, s, V, kb, 0);
+                if (kb < klast) hipLaunchKernelGGL((k_gemm_abt<2>), dim3(rest, klast - kb), dim3(256), 0, s, V, kb, klast);
+            }
+            const int b0 = (kb0 + kPanel) / 2;                  // first 128-block of the trailing matrix
+            if (b0 >= nB) break;
+            SCHK(hipEventRecord(h->ev_chain, s));
+            if (bulk_pending) SCHK(hipStreamWaitEvent(s, h->ev_bulk, 0));      // the previous bulk update wrote the columns of this one
+            hipLaunchKernelGGL(k_syrk_panel, dim3(nB - b0, std::min(2, nB - b0)), dim3(512), 0, s, V, kb0, b0, b0);     // next panel's columns
+            bulk_pending = false;
+            if (nB - b0 > 2) {
+                SCHK(hipStreamWaitEvent(h->aux, h->ev_chain, 0));
+                hipLaunchKernelGGL(k_syrk_panel, dim3(nB - b0 - 2, nB - b0 - 2), dim3(512), 0, h->aux, V, kb0, b0 + 2, b0 + 2);
+                SCHK(hipEventRecord(h->ev_bulk, h->aux));
+                bulk_pending = true;
+            }
+        }
+        if (bulk_pending) SCHK(hipStreamWaitEvent(s, h->ev_bulk, 0));
     }
     SCHK(hipEventRecord(h->ev[2], s));
     for (int kb = 0; kb < V.nb; ++kb)
