@@ -2015,6 +2015,19 @@ int sh_ensure_buffers(vba_handle h, int64_t m_total) {
         S.m_local = h->m[0];
         S.carried = false;
     }
+    // The warm bins must keep the bin of the GLOBAL median short (the gathered buckets of that bin are ranked as one list of at
+    // most 1024 keys): their width follows the key count over all ranks, not this rank's share -- 1/256 binade up to 300 000
+    // keys, 1/512 up to 600 000, 1/1024 beyond (range [c/2, 2c): a median that moves further between two calls is a miss and
+    // takes the exact select, as everywhere).
+    if (S.protocol == 1) {
+        const int64_t keys = 2 * m_total;
+        const int shift = keys <= 300000 ? 44 : (keys <= 600000 ? 43 : 42);
+        if (h->V.warm_shift != shift) {
+            h->V.warm_shift = shift;
+            h->carry_ok = 0;
+            S.carried = false;
+        }
+    }
     // carried-keys protocol: [hist 1024 | part_next nblk_obs | part_trial trial_stride] per call parity, the gathered copy, the
     // bucket slots [count | keys bucket_cap]
     const int nbo = h->V.nblk_obs, cap = h->V.bucket_cap;
