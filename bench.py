@@ -805,7 +805,9 @@ def run_rank(args):
     sharded = None
     hung = threading.Event()
     if (world > 1 or force_dist) and not args.no_sharded:
-        if ndev < world:
+        fake_rccl = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+        rehearse = ndev < world and os.environ.get("VBA_BENCH_FAKE_RCCL") == "1" and os.path.exists(fake_rccl)
+        if ndev < world and not rehearse:
             sharded = {"skipped": f"{world} ranks share {ndev} device(s): RCCL needs one device per rank (rehearsal run)"}
         else:
             # A hung collective must neither cost the headline line nor read as success: the watchdog prints the line
@@ -826,7 +828,10 @@ def run_rank(args):
             watchdog.start()
             try:
                 from vinsat_amd.dist import ShardedBA
-                nccl = dist.new_group(backend="nccl", device_id=torch.device("cuda", device)) if hasattr(dist, "new_group") else None
+                # VBA_BENCH_FAKE_RCCL=1 on a box with fewer devices than ranks: a REHEARSAL of the library-issued leg on the test
+                # double of RCCL (tests/fake_rccl: host shared memory) -- every rank process drives the real kernels and the real
+                # schedule; the rate means nothing (the exchanges synchronise the stream), the leg running through does
+                nccl = None if rehearse else (dist.new_group(backend="nccl", device_id=torch.device("cuda", device)) if hasattr(dist, "new_group") else None)
                 cfg_s = synth.WindowConfig("sharded", cfg.n_poses, cfg.obs_per_pose * world, cfg.stride)
                 det_s, orb_s = synth.make_sequence(cfg_s, seed=0)
                 win_s = od_pipe.prepare_window(det_s, orb_s)
@@ -859,11 +864,15 @@ def run_rank(args):
                     return ns / float(t.item())
 
                 # dispatched by the caller through torch.distributed (four stage calls + three collectives per call) ...
-                sba = ShardedBA.from_window(win_s, device=device, group=nccl)
-                v_torch = rate(sba)
-                sba.close()
+                if rehearse:
+                    v_torch = None
+                else:
+                    sba = ShardedBA.from_window(win_s, device=device, group=nccl)
+                    v_torch = rate(sba)
+                    sba.close()
                 got.update({"value": v_torch, "unit": "BA iterations/s", "poses": cfg.n_poses,
-                            "rccl_ranks": dist.get_world_size(nccl),
+                            "rccl_ranks": 0 if rehearse else dist.get_world_size(nccl),
+                            **({"rehearsal": "library-issued leg on tests/fake_rccl (ranks share a device): not a measurement"} if rehearse else {}),
                             "observations_total": int(win_s.ii.size), "observations_per_rank": int(win_s.ii.size // world),
                             "collectives_per_call": "3 all-gathers (|r| keys, per-pose blocks, trial sums) over RCCL",
                             "transport": "torch.distributed all_gather_into_tensor between the stage calls",
@@ -876,7 +885,7 @@ def run_rank(args):
                 # decided by ALL ranks together (a rank that could not join must not leave the others inside a collective).
                 sba, ok = None, 1.0
                 try:
-                    sba = ShardedBA.from_window(win_s, device=device, native=True)
+                    sba = ShardedBA.from_window(win_s, device=device, native=True, rccl_path=fake_rccl if rehearse else None)
                 except Exception as exc:
                     ok = 0.0
                     sharded["native_error"] = repr(exc)[:300]

@@ -53,3 +53,23 @@ def test_gpus_2_runs_two_replica_ranks_on_this_box():
         assert "skipped" in d["sharded"]
     else:
         assert d["sharded"]["rccl_ranks"] == 2
+
+
+def test_gpus_2_rehearses_the_library_issued_sharded_leg_on_the_test_double_of_rccl():
+    """`bench.py --gpus 2` with VBA_BENCH_FAKE_RCCL=1 on the one-GPU box: both rank processes run the library-issued sharded
+    leg (vba_sh_run_schedule, carried-keys protocol) end to end on tests/fake_rccl -- the bench's own orchestration (joint
+    decision to run, barriers, max-over-ranks, statistics) is what is rehearsed; the rate is not a measurement."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices: the real RCCL leg runs instead")
+    fake_dir = os.path.join(ROOT, "tests", "fake_rccl")
+    subprocess.check_call(["make", "-C", fake_dir], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    env = dict(os.environ, VBA_BENCH_FAKE_RCCL="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "20", "--windows", "0",
+                          "--cpu-seconds", "0", "--sweep", "", "--no-configs", "--no-schur"], capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    sh = d["sharded"]
+    assert "rehearsal" in sh and sh["value_library_issued"] > 10 and sh["first_exchange_bytes_per_rank"] <= 16 * 1024, sh
+    assert sh["calls_repeated_after_a_missed_select"] >= 0 and "native_error" not in sh
