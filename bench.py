@@ -409,7 +409,7 @@ def run_rank(args):
 
     # CPU baseline first: its worker processes are started (and gone) before this process touches the GPU
     cpu = None
-    if rank == 0 and args.cpu_seconds > 0 and not args.dry_run:
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and not args.dry_run:      # (N = 1 only: at N > 1 the other ranks would wait for it)
         try:
             cpu = cpu_baseline(args)
         except Exception as exc:
