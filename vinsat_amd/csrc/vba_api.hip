@@ -274,8 +274,8 @@ int vba_device_count(int* count) {
 // and C2 windows (100 poses / 5 000 rows): latency 107 / 379 / 606 / 943 / 1230 / 1446 / 1541 at W = 4 / 16 / 32 / 64 / 128 / 256 /
 // 512 against bandwidth 51 / 199 / 360 / 662 / 1145 / 1649 / 1931; walk against partitioned solve 954 : 1649 at 256 windows,
 // 2183 : 2071 at 1024, 3227 : 2259 at 4096.
-// * Kernel set: what fills the chip is ROWS, not windows -- the latency-mode kernels win up to ~1.6 million observation rows
-//   per launch (31 C3 windows, ~180 C2 windows; until round 4 the switch was at 16 windows whatever their size).
+// * Kernel set: what fills the chip is rows AND windows -- the latency-mode kernels win up to 31 C3 windows, ~180 C2 windows, ~13
+//   C4 windows (default_latency_mode below; until round 4 the switch was at 16 windows whatever their size).
 // * Solver: the sequential walk is a latency chain per window (~2.2 ms at 500 poses whatever the window count) and pays only
 //   once ~1000 windows share it; below that the chains are cut into chunks (until round 4 the walk took over at 128 windows:
 //   3.3 ms per step at 256 windows where the partitioned solve needs 0.75).
@@ -283,11 +283,13 @@ int vba_device_count(int* count) {
 //   up to 175 000 rows mask 15 (the trial kernel forms the step, the chunk elimination its blocks); up to 450 000 rows 14 (the
 //   trial kernel reads a step that a launch of its own formed: every observation block re-forming the steps of its poses costs
 //   more than that launch as soon as a few windows share the chip); beyond 12 (the assembly is a launch of its own as well).
-constexpr double kLatRowsMax = 1.55e6;
 constexpr int kLatWindowsCap = 192;             // (33 MB of bin buckets per C3 window; per-window prologues)
 constexpr int kPartitionedWindowsMax = 1023;
+// The crossover measured at three window sizes -- ~180 windows of 5 000 rows, 31 of 50 000, ~13 of 200 000 (C4: latency 55.1 / 64.0 /
+// 65.7 k it/s at W = 8 / 12 / 16 against bandwidth 50.0 / 62.9 / 73.7) -- lies on W* = 31 (50 000 / m)^0.7: between "by windows"
+// (exponent 0) and "by rows" (exponent 1), because both the per-window prologues and the rows fill the chip.
 static bool default_latency_mode(int windows, int64_t m_max) {
-    return windows == 1 || (windows <= kLatWindowsCap && (double)windows * (double)m_max <= kLatRowsMax);
+    return windows == 1 || (windows <= kLatWindowsCap && (double)windows <= 31.0 * std::pow(50000.0 / (double)m_max, 0.7));
 }
 static int default_fusion(bool lat, int windows, int64_t m_max) {
     const double rows = (double)windows * (double)m_max;
