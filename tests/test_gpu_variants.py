@@ -178,3 +178,36 @@ def test_one_window_per_wave_walk_forming_its_own_blocks_gives_the_bits_of_the_a
     if not reg:
         assert rel_err(outs[1][0][0], g["states_out_19"][0]) < 1e-7
         assert outs[1][1][3] > 1                         # the rejection window really rejected
+
+
+@pytest.mark.parametrize("chunk", [4, 5, 6, 7, 8, 9, 11, 13])
+def test_three_cyclic_reduction_levels_in_front_give_the_bits_of_two(chunk, monkeypatch):
+    """Round 4, the one more structural try at the single-window solve: THREE cyclic-reduction levels on their own CUs
+    (k_cr_level012: groups of eight separators, fifteen blocks, eight waves; VBA_CR_LEVELS=3) in front of a one-workgroup kernel
+    that starts from n / 8 blocks.  The same eliminations and folds in another place: the bits of two levels in front -- for
+    separator counts of every residue mod 8 (a 300-pose window cut into chunks of 4 .. 13: 74, 59, 49, 42, 37, 33, 27, 23
+    separators, the last one below the size from which levels are split off at all), unpivoted and pivoted.  Measured SLOWER
+    (C3: 11.67 + 12.95 us against 8.45 + 14.99 for the two kernels, +0.45 us on the average call): comparison build only."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    cfg = synth.WindowConfig("cr3", 300, 20, 5)
+    win = od_pipe.prepare_window(*synth.make_sequence(cfg, seed=11))
+    n, m = win.time_idx.size, win.ii.size
+    st0 = od_pipe.initial_guess(win, seed=11)
+    iters, inits = [9, 10, 11, 12, 13], [True, False, False, False, False]
+    for pivot in (False, True):
+        outs = []
+        for levels in ("2", "3"):
+            monkeypatch.setenv("VBA_CR_LEVELS", levels)
+            e = BAEngine(n, m)
+            e.set_solver(chunk, -1)
+            e.set_pivoting(pivot)
+            e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+            e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+            e.set_states(st0, 1e-4)
+            e.run_schedule(iters, inits)
+            outs.append((e.get_states(), e.debug("dpose")))
+            e.close()
+        a, b = outs
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0][0], b[0][0]) and a[0][1] == b[0][1] and a[0][3] == b[0][3], (chunk, pivot)
+        assert np.isfinite(a[1]).all() and np.abs(a[1]).max() > 0

@@ -125,6 +125,7 @@ struct vba_context {
     int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
     int inline_select = 1;                  // latency mode: warm select inside the accumulation (bin buckets); vba_set_warm_select(h, 3) turns it off
     int chunk_waves = 2;                    // vba_set_chunk_waves
+    int cr_levels = 2;                      // cyclic-reduction levels in front of the one-workgroup kernel (VBA_CR_LEVELS / vba_set_cr_levels: 2 or 3)
     int fusion = 15;                        // vba_set_fusion (default: the trial kernel forms the step, the solves form their own blocks, uniform-pass assembly)
     int bucket_cap_alloc = 0;               // allocated capacity of a bin bucket (vba_set_bucket_cap lowers the one in use)
     int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
@@ -475,6 +476,9 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     h->warm_enabled = 1;
     h->fold_enabled = lat;
     if (const char* e = std::getenv("VBA_X_FOLD")) h->fold_enabled = std::atoi(e) != 0;     // (experiment knob)
+#ifdef VBA_VARIANTS
+    if (const char* e = std::getenv("VBA_CR_LEVELS")) h->cr_levels = std::atoi(e) == 3 ? 3 : 2;     // (three levels in front: measured slower, comparison build only)
+#endif
     *out = h;
     return VBA_OK;
 }
@@ -1015,7 +1019,7 @@ void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
     V.resident = !V.lat ? 0 : (h->fusion & 64) ? 2 : (h->fusion & 32) ? 1 : 0;
     V.chunk_waves = h->chunk_waves;
     V.asm_rows = (h->fusion & 8) ? 1 : 0;
-    V.cr_levels = (h->fusion & 16) ? 1 : 2;
+    V.cr_levels = (h->fusion & 16) ? 1 : h->cr_levels;
     V.fuse_walk = ((h->fusion & 4) && !V.lat) ? 1 : 0;
 }
 

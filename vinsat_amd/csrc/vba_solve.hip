@@ -2229,6 +2229,76 @@ __global__ __launch_bounds__(256) void k_cr_level01(DevView V, int s) {
     cr_level01_body<PIVOT>(V, s, blockIdx.y, blockIdx.x, blk);
 }
 
+#ifdef VBA_VARIANTS   // three levels in front (VBA_CR_LEVELS=3): measured 0.45 us per call SLOWER than two, comparison builds
+// The first THREE levels on their own CUs (round 4): eight waves per group of eight separators.  Group t builds the fifteen
+// blocks 8t .. 8t+14, eliminates the even ones (eight waves side by side), folds them into the odd ones, eliminates 8t+1, 8t+5,
+// 8t+9, 8t+13 and folds those into 8t+3, 8t+7, 8t+11, eliminates 8t+3 and 8t+11 and folds them into 8t+7.  It leaves
+//   red3[t] = the three times folded block 8t+7 (252 doubles),  P[8t], P[8t+2], P[8t+4], P[8t+6] (level 0), P[8t+1], P[8t+5]
+//   (level 1) and P[8t+3] (level 2) = [PL | PU | Pg]
+// in global memory; what it shares with the next group (blocks 8t+8 .. 8t+14) is computed by both.  The one-workgroup kernel then
+// starts from n / 8 blocks (7 instead of 15 at 62 separators): its fill shrinks and its first level of eight eliminations, two
+// per SIMD, is gone.  Same eliminations and folds in another place: the bits of two levels in front.
+template <bool PIVOT>
+__device__ __forceinline__ void cr_level012_body(const DevView& V, int s, int w, int t, double* blk) {
+    VBA_SKIP_CALL(V, w);
+    WinScalars& sc = V.sc[w];
+    if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
+    const int n1 = n_separators(V.n[w], s);
+    if (n1 < kCrSplitMin || n1 > 8 * kCrMax || 8 * t >= n1) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;     // 8 waves
+    const size_t rb = (size_t)w * V.p_max;
+    const double lam32 = (double)(float)sc.lam[V.par];
+    const int q0 = 8 * t;
+    CrLanes g;
+    cr_fill<2>(V, w, s, n1, lam32, q0 + wv, 8, blk + (size_t)wv * 252, 8, lane, [&]() { g = cr_lanes(lane); });     // blocks wv, wv + 8
+    __syncthreads();
+    bool bad = false;
+    auto store_P = [&](int u) {         // [PL | PU | Pg] of block q0 + u
+        double* P = V.csol2 + (rb + q0 + u) * 171;
+        const double* B = blk + (size_t)u * 252;
+        for (int e = lane; e < 171; e += 64) P[e] = e < 81 ? B[e] : B[81 + e];
+    };
+    auto fold = [&](int u, int h) {     // the eliminated blocks u - h and u + h into block u
+        if (q0 + u < n1) cr_fold(blk + (size_t)u * 252, blk + (size_t)(u - h) * 252, blk + (size_t)(u + h) * 252, q0 + u + h < n1, g);
+    };
+    // level 0: the even blocks 0, 2, ..., 14
+    if (q0 + 2 * wv < n1) cr_eliminate<PIVOT>(blk + (size_t)(2 * wv) * 252, g, lane, bad);
+    __syncthreads();
+    if (wv < 7) fold(2 * wv + 1, 1);
+    else {
+        for (int u = 0; u < 8; u += 2) if (q0 + u < n1) store_P(u);
+    }
+    __syncthreads();
+    // level 1: blocks 1, 5, 9, 13
+    if (wv < 4 && q0 + 4 * wv + 1 < n1) cr_eliminate<PIVOT>(blk + (size_t)(4 * wv + 1) * 252, g, lane, bad);
+    __syncthreads();
+    if (wv < 3) fold(4 * wv + 3, 2);
+    else if (wv == 3) { if (q0 + 1 < n1) store_P(1); }
+    else if (wv == 4) { if (q0 + 5 < n1) store_P(5); }
+    __syncthreads();
+    // level 2: blocks 3 and 11
+    if (wv < 2 && q0 + 8 * wv + 3 < n1) cr_eliminate<PIVOT>(blk + (size_t)(8 * wv + 3) * 252, g, lane, bad);
+    __syncthreads();
+    if (wv == 0) {
+        if (q0 + 7 < n1) {
+            fold(7, 4);
+            wave_sync_lds();
+            double* R = V.cL2 + rb * 171 + (size_t)t * 252;
+            for (int e = lane; e < 252; e += 64) R[e] = blk[7 * 252 + e];
+        }
+    } else if (wv == 1) {
+        if (q0 + 3 < n1) store_P(3);
+    }
+    report_pivot<PIVOT>(bad, sc, lane, V.par);
+}
+
+template <bool PIVOT>
+__global__ __launch_bounds__(512) void k_cr_level012(DevView V, int s) {
+    __shared__ __attribute__((aligned(16))) double blk[16 * 252];
+    cr_level012_body<PIVOT>(V, s, blockIdx.y, blockIdx.x, blk);
+}
+#endif  // VBA_VARIANTS
+
 // PRE: the first level has been done by k_cr_level0; this kernel continues with the n1 / 2 folded blocks and finishes
 // with the back substitution of the level-0 blocks.
 // PRE 2: the first two levels have been done by k_cr_level01; the system solved here is over the separators 4b + 3.
@@ -2242,8 +2312,8 @@ __device__ __forceinline__ void reduced_cr_body(const DevView& V, int s, int w, 
     if (sc.done || !solver_mine<PIVOT>(V, sc)) return;
     const int n0 = n_separators(V.n[w], s);             // separators of the window
     if (n0 <= 0) return;
-    if (PRE ? (n0 < kCrSplitMin || n0 > (PRE == 2 ? 4 : 2) * kCrMax) : (n0 >= kCrSplitMin || n0 > kCrMax)) return;   // the other variant's window
-    const int n1 = PRE == 2 ? n0 / 4 : (PRE ? n0 / 2 : n0);             // blocks of the system solved here
+    if (PRE ? (n0 < kCrSplitMin || n0 > (PRE == 3 ? 8 : (PRE == 2 ? 4 : 2)) * kCrMax) : (n0 >= kCrSplitMin || n0 > kCrMax)) return;   // the other variant's window
+    const int n1 = PRE == 3 ? n0 / 8 : (PRE == 2 ? n0 / 4 : (PRE ? n0 / 2 : n0));             // blocks of the system solved here
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = kCrThreads / 64;
     const size_t rb = (size_t)w * V.p_max;
@@ -2317,7 +2387,44 @@ __device__ __forceinline__ void reduced_cr_body(const DevView& V, int s, int w, 
         __syncthreads();
         VBA_KSTAMP(tson, tsi++);
     }
-    if (PRE == 2) {
+    if (PRE == 3) {
+        // separators 8b+7 are the blocks solved here.  8b+3 come from the level-2 eliminations, x = Pg - PL x_{q-4} - PU x_{q+4};
+        // then 4b+1 from level 1 (neighbours q -+ 2), then the even ones from level 0 (neighbours q -+ 1)
+        double* x2 = smem + (size_t)n1 * 252;                   // [ceil(n0 / 8)][9]
+        double* x1 = x2 + (size_t)((n0 + 7) / 8) * 9;           // [ceil(n0 / 4)][9]
+        auto x_odd = [&](int q) -> const double* {              // solution of an odd separator
+            return (q & 7) == 7 ? smem + (size_t)(q >> 3) * 252 + 243 : ((q & 7) == 3 ? x2 + (size_t)(q >> 3) * 9 : x1 + (size_t)(q >> 2) * 9);
+        };
+        auto solve_from = [&](int q, int r, int h) {            // row r of separator q from its P rows and the solutions h away
+            const double* P = V.csol2 + (rb + q) * 171;
+            double x = P[162 + r];
+            if (q - h >= 0) {
+                const double* xm = x_odd(q - h);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) x -= P[r * 9 + k] * xm[k];
+            }
+            if (q + h < n0) {
+                const double* xp = x_odd(q + h);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) x -= P[81 + r * 9 + k] * xp[k];
+            }
+            return x;
+        };
+        for (int idx = tid; idx < ((n0 + 7) / 8) * 9; idx += kCrThreads) {
+            const int q = 8 * (idx / 9) + 3, r = idx % 9;
+            if (q < n0) x2[(size_t)(q >> 3) * 9 + r] = solve_from(q, r, 4);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < ((n0 + 3) / 4) * 9; idx += kCrThreads) {
+            const int q = 4 * (idx / 9) + 1, r = idx % 9;
+            if (q < n0) x1[(size_t)(q >> 2) * 9 + r] = solve_from(q, r, 2);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < n0 * 9; idx += kCrThreads) {
+            const int q = idx / 9, r = idx % 9;
+            V.rx[rb * 9 + idx] = (q & 1) ? x_odd(q)[r] : solve_from(q, r, 1);
+        }
+    } else if (PRE == 2) {
         // separators 4b+3 are the blocks solved here.  4b+1 come from the level-1 eliminations, x = Pg - PL x_{q-2} - PU x_{q+2},
         // then the even ones from level 0, x = Pg - PL x_{q-1} - PU x_{q+1}
         double* x1 = smem + (size_t)n1 * 252;       // [ceil(n0 / 4)][9]: the level-1 solutions (behind the blocks)
@@ -2810,7 +2917,11 @@ static void launch_solve_variant(const DevView& V, int initialize, hipStream_t s
         const int n0_max = P - 1, n0_min = (V.n_min + cs - 1) / cs - 1;
         if (n0_max >= kCrSplitMin) {    // first level(s) on their own CUs, the rest in one workgroup
 #ifdef VBA_VARIANTS
-            if (V.cr_levels == 2)
+            if (V.cr_levels == 3) {
+                hipLaunchKernelGGL(k_cr_level012<PIVOT>, dim3((n0_max + 7) / 8, V.W), dim3(512), 0, s, V, cs);
+                hipLaunchKernelGGL((k_solve_reduced_cr<PIVOT, 3>), dim3(V.W), dim3(kCrThreads),
+                                   ((size_t)(n0_max / 8) * 252 + (size_t)((n0_max + 7) / 8) * 9 + (size_t)((n0_max + 3) / 4) * 9) * sizeof(double), s, V, cs);
+            } else if (V.cr_levels == 2)
 #endif
             {
                 hipLaunchKernelGGL(k_cr_level01<PIVOT>, dim3((n0_max + 3) / 4, V.W), dim3(256), 0, s, V, cs);
@@ -2855,6 +2966,7 @@ hipError_t configure_solver_device() {
         {reinterpret_cast<const void*>(k_solve_chunks2<false>), cap}, {reinterpret_cast<const void*>(k_solve_chunks2<true>), cap},
         {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 0>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 0>), cap_cr},
 #ifdef VBA_VARIANTS
+        {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 3>), cap_cr + 200 * 9 * 8}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 3>), cap_cr + 200 * 9 * 8},
         {reinterpret_cast<const void*>(k_solve_reduced_cr<false, 1>), cap_cr}, {reinterpret_cast<const void*>(k_solve_reduced_cr<true, 1>), cap_cr},
         {reinterpret_cast<const void*>(k_solve_resident<false, false, false>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, false, false>), cap_res},
         {reinterpret_cast<const void*>(k_solve_resident<false, true, false>), cap_res}, {reinterpret_cast<const void*>(k_solve_resident<true, true, false>), cap_res},
