@@ -101,7 +101,8 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external);
 /* Choice of the block-tridiagonal solve: chunk = 0 one wavefront walks the whole pose chain (work optimal, used
  * when many windows are batched); chunk in [2,60] cuts the chain into chunks of that many poses that are
  * eliminated in parallel plus a reduced system over the separators; chunk = -1 restores the default
- * (0 for >= 128 windows; otherwise chunks of 8 poses -- fewer up to 520 poses, more beyond 1032 -- and the reduced
+ * (0 for more than 1023 windows -- the walk is a latency chain of ~2.2 ms at 500 poses that only so many windows amortise, see the
+ * sweep in DESIGN.md section 3 --; otherwise chunks of 8 poses -- fewer up to 520 poses, more beyond 1032 -- and the reduced
  * system by cyclic reduction, see vba_set_solver2; two levels of ~n^(1/3) beyond 7700 poses).  With chunk = 0 a
  * wavefront walks one window; chunk = -3 makes three windows of equal pose count share a wavefront (no faster on
  * MI355X at any batch size measured, kept for comparison), chunk = -2 forbids it.  All variants agree to rounding. */
@@ -154,14 +155,14 @@ int vba_set_key_carry(vba_handle h, int on);
  * warm pass of call c + 1 also evaluates the LM accept test of call c in its prologue, which removes the decide launch
  * from the chain.  on == 0: every select takes the exact digit passes and every accept test its own launch (same bits).
  * on == 2 (test knob): every warm select reports a miss, i.e. every carried call takes the repeat path.
- * Latency mode (fewer than 16 windows) goes one step further: the trial kernel drops every key into the bucket of its warm
+ * Latency mode (vba_create_mode) goes one step further: the trial kernel drops every key into the bucket of its warm
  * bin (capacity ~6x the densest bin; a longer bin is a miss), so the bin of the wanted rank needs no pass over the keys --
  * the accumulation kernel resolves the histogram, ranks that bucket and evaluates the folded accept test in its own
  * prologue, and a chained landmark-only call is two kernels.  on == 3: keep the select as its own kernel (comparison). */
 int vba_set_warm_select(vba_handle h, int on);
 /* Tuning / test knob: log2 of the width of a warm bin in bit patterns (52 = one binade).  Defaults: 44 (1/256 binade; 43 for
  * more than 300 000 keys) in latency mode, where the bin of the median must be a short bucket; 49 (1/8 binade) for handles
- * of 16 windows and more, where a block's histogram flush costs one global atomic per bin it touched and the few per cent of
+ * in bandwidth mode, where a block's histogram flush costs one global atomic per bin it touched and the few per cent of
  * the keys in the median's bin are compacted by one pass.  The median is exact for every width. */
 int vba_set_warm_shift(vba_handle h, int shift);
 int vba_warm_select_misses(vba_handle h, int* count);
@@ -169,13 +170,13 @@ int vba_warm_select_misses(vba_handle h, int* count);
  * keys than that overflows -- its bucket is incomplete -- and a call whose median falls into it takes the miss path. */
 int vba_set_bucket_cap(vba_handle h, int cap);
 
-/* Kernel fusion, a bit mask (bits 0 and 1: latency mode, fewer than 16 windows per handle); same results to rounding.
+/* Kernel fusion, a bit mask (bits 0 and 1: latency mode); same results to rounding.
  *   bit 0: the trial kernel forms the step of each pose itself (landmark-only phase: the 6x6 solve; full phase: the
  *          recovery of the partitioned solve) -- no recovery launch and, in the landmark-only phase, no assembly + solve launch;
  *   bit 1: the chunk elimination forms the blocks of its chunk in LDS itself -- no assembly launch in the full phase, the
  *          bands never go through memory.  With the generic formation it gained nothing (rounds 1, 2); formed by column
  *          (asm_form_columns, a row of 16 lanes per pose row) it takes 1.1 us off the average call: default since round 3.
- *   bit 2: (16 windows and more, sequential driver) the solve of the full phase forms each block from the per-pose inputs
+ *   bit 2: (bandwidth mode, sequential driver) the solve of the full phase forms each block from the per-pose inputs
  *          itself -- no assembly launch, the bands never go through memory.  Bit-exact.  With one window per wavefront
  *          (k_solve_forming) it measured slower than assembly + walk (the walk was bound by instruction issue); since the
  *          walk packs four windows into a wavefront (k_solve_quad) it is the faster form and the default.
@@ -191,7 +192,11 @@ int vba_set_bucket_cap(vba_handle h, int cap);
  *          Same bits as three launches.  Measured SLOWER (C3, one window: +2.5 and +6.5 us per call): a hop over a flag is two
  *          round trips to device memory plus the write-back / invalidate of the per-XCD L2s, 4.7 us from the last producer's
  *          last store to the consumer's first load, against ~3.2 us for a kernel boundary.  Comparison / tests only.
- * Default 15 (bits 0 .. 3).  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
+ *   bits 4 .. 6 exist in the comparison build only (vba_has_variants); the default build answers VBA_EINVAL.
+ * Default: 15 (bits 0 .. 3) for one window and for bandwidth mode; latency-mode handles of several windows drop the fusions that
+ * trade instructions for launches once launches are no longer what a call costs -- 15 up to 175 000 rows per launch, 14 (the trial
+ * kernel reads a step that its own launch formed) up to 450 000, 12 (the assembly is a launch as well) beyond: from the round-4
+ * sweep, DESIGN.md section 3.  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
  * formed by 16 lanes together (formed redundantly by every thread it was 6 us SLOWER: instruction issue of a single wave
  * is the time in this mode); bit 1, see above (48.0 against 49.1 us per call).  All masks are covered by the parity tests. */
 int vba_set_fusion(vba_handle h, int mask);
