@@ -102,7 +102,7 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external);
  * when many windows are batched); chunk in [2,60] cuts the chain into chunks of that many poses that are
  * eliminated in parallel plus a reduced system over the separators; chunk = -1 restores the default
  * (0 for more than 1023 windows -- the walk is a latency chain of ~2.2 ms at 500 poses that only so many windows amortise, see the
- * sweep in DESIGN.md section 3 --; otherwise chunks of 8 poses -- fewer up to 520 poses, more beyond 1032 -- and the reduced
+ * sweep in DESIGN.md section 3 --; bandwidth-mode handles: chunks of 12 poses (fewer separators: throughput); otherwise chunks of 8 poses -- fewer up to 520 poses, more beyond 1032 -- and the reduced
  * system by cyclic reduction, see vba_set_solver2; two levels of ~n^(1/3) beyond 7700 poses).  With chunk = 0 a
  * wavefront walks one window; chunk = -3 makes three windows of equal pose count share a wavefront (no faster on
  * MI355X at any batch size measured, kept for comparison), chunk = -2 forbids it.  All variants agree to rounding. */

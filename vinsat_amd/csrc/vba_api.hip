@@ -550,7 +550,11 @@ int vba_set_solver(vba_handle h, int chunk) {
         // <= 64 separators while that keeps the chunks at <= 8 poses, else up to 128 (their first reduction level runs
         // on its own CUs either way, see k_cr_level0)
         const int c64 = (h->n_max + 64) / 65, c128 = (h->n_max + 128) / 129;
-        const int c1 = std::max(std::min(c64, std::max(8, c128)), 2);
+        int c1 = std::max(std::min(c64, std::max(8, c128)), 2);
+        // bandwidth mode: the chunks are there for throughput, not for the shortest chain -- fewer separators (less redundant
+        // work in the reduced system) win: chunks of 12 measured +7 .. +9 % at 100 poses (256 .. 1000 windows) over the latency
+        // rule's chunks of 2, +2 % at 500 poses over chunks of 8 (4 / 8 / 16 / 14 all slower; tools/attic/chunk_bw.sh)
+        if (!h->V.lat) c1 = std::max(c1, std::min(12, std::max(2, h->n_max / 3)));
         if (c1 <= 60) {
             h->V.chunk = c1;
             h->V.chunk2 = -1;
