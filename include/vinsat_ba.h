@@ -349,7 +349,9 @@ int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done)
  *      and every rank enqueues the same collectives whether a call runs or skips, one host synchronisation per schedule.  A call
  *      whose select misses (median outside the binned range, a bucket overflowed) is repeated with protocol 0's front; a trial
  *      that is not cleanly accepted is finished by the ordinary LM loop with the trial sums gathered per round.  All decisions
- *      are taken on gathered data: every rank takes the same.  Needs a latency-mode handle with its default kernel fusion.
+ *      are taken on gathered data: every rank takes the same.  Needs a latency-mode handle with its default kernel fusion,
+ *      created for exactly m_max = ceil(m_total / ranks) rows on every rank (the exchange buffers follow the handle's geometry);
+ *      any other handle takes protocol 0.
  *   0  the round-3 protocol: every call recomputes its keys and gathers all of them (16 B per observation). */
 int vba_sh_unique_id(const char* rccl_path, void* id128);
 int vba_sh_comm_init(vba_handle h, const char* rccl_path, const void* id128, int nranks, int rank);

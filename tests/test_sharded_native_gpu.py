@@ -103,8 +103,8 @@ def _worker_protocols(rank, world, port, tmp):
         iters, inits = list(range(20)), [k < 10 for k in range(20)]
         out = {}
         for confname, conf in (("golden", inp["conf"]), ("rejecting", np.full(m, 3.0))):
-            def make(proto, force_miss=False):
-                eng = BAEngine(n, m)
+            def make(proto, force_miss=False, slack=0):
+                eng = BAEngine(n, m + slack)        # (slack: a handle NOT sized for ceil(m_total / ranks) rows takes the round-3 protocol)
                 eng.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
                 eng.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
                 if force_miss:
@@ -116,8 +116,8 @@ def _worker_protocols(rank, world, port, tmp):
 
             res = {}
             for name, proto, miss, chained in (("carried", 1, False, False), ("carried-chained", 1, False, True), ("round3", 0, False, False),
-                                               ("carried-missing", 1, True, True)):
-                sb = make(proto, miss)
+                                               ("carried-missing", 1, True, True), ("oversized-handle", 1, False, True)):
+                sb = make(proto, miss, 300 if name == "oversized-handle" else 0)
                 sb.set_states(g["states0"][0], 1e-4)
                 if chained:
                     sb.run_schedule(iters[:7], inits[:7])          # two schedules: the second starts from carried keys
@@ -127,7 +127,9 @@ def _worker_protocols(rank, world, port, tmp):
                         sb.step(it, init)
                 res[name] = sb.get_states()
                 first, misses, lm = sb.engine.stats()
-                if proto == 1:
+                if name == "oversized-handle":
+                    assert first == 16 * m and misses == 0      # (its exchange buffers would not match other ranks': round-3 protocol)
+                elif proto == 1:
                     assert first <= 16 * 1024, first                # the first exchange of a call: histogram + block sums, not 16 B per row
                     assert (misses >= 18) == miss, (name, misses)   # forced misses: every carried call fell back (the first has no carried keys)
                     assert (lm > 0) == (confname == "rejecting"), (name, lm)

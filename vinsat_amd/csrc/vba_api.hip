@@ -2234,7 +2234,7 @@ int vba_sh_set_protocol(vba_handle h, int carried_keys) {
 int vba_sh_stats(vba_handle h, int64_t* bytes_first_exchange, int64_t* fallbacks_miss, int64_t* fallbacks_lm) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     auto& S = h->shc;
-    if (bytes_first_exchange) *bytes_first_exchange = (S.protocol == 1 && S.lenA) ? (int64_t)S.lenA * 8 : 16 * S.m_pad;
+    if (bytes_first_exchange) *bytes_first_exchange = (S.protocol == 1 && S.lenA && h->m_max == S.m_pad) ? (int64_t)S.lenA * 8 : 16 * S.m_pad;
     if (fallbacks_miss) *fallbacks_miss = S.fallbacks_miss;
     if (fallbacks_lm) *fallbacks_lm = S.fallbacks_lm;
     return VBA_OK;
@@ -2250,7 +2250,10 @@ int vba_sh_run_schedule(vba_handle h, int ncalls, const int* iters, const int* i
     if (int rc = ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     if (int rc = sh_ensure_buffers(h, m_total)) return rc;
-    if (S.protocol == 0 || !h->V.wbucket || !h->V.lat || !(h->fusion & 1) || h->V.chunk <= 0) {
+    // (the exchange buffers are laid out by the handle's geometry -- observation blocks, bucket capacity --, which must be the same on
+    // every rank: a handle created for exactly ceil(m_total / ranks) rows; any other takes the round-3 protocol, whose slots are sized
+    // by m_total alone)
+    if (S.protocol == 0 || !h->V.wbucket || !h->V.lat || !(h->fusion & 1) || h->V.chunk <= 0 || h->m_max != S.m_pad) {
         // the round-3 protocol, call by call
         long total = 0;
         for (int c = 0; c < ncalls; ++c) {

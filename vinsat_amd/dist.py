@@ -210,7 +210,9 @@ class ShardedBA:
         n, m = win.time_idx.size, win.ii.size
         b = shard_bounds(m, world)
         lo, hi = int(b[rank]), int(b[rank + 1])
-        eng = BAEngine(n, max(hi - lo, 1), windows=1, device=device)
+        # every rank sizes its handle for ceil(m / world) rows: the exchange buffers of the library-issued protocol are laid out by
+        # the handle's geometry (observation blocks, bucket capacity) and must be the same on all ranks
+        eng = BAEngine(n, max(-(-m // world), 1), windows=1, device=device)
         eng.upload_observations(win.landmarks_xyz[lo:hi], win.landmarks_uv[lo:hi], win.confidences[lo:hi], win.ii[lo:hi], n)
         eng.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
         if native:
