@@ -113,3 +113,67 @@ def test_two_pass_sequence_with_the_hop_integrator_matches_reference_run():
     assert rel_err(errors.numpy(), g["errors"]) < 1e-6
     plain = load_golden("gap")
     assert rel_err(g["states_out_39"][0], plain["states_out_39"][0]) > 1e-9     # another integrator, another result
+
+
+def _oracle_ba_window(iters, inits, states, velocities, imu, uv, xyz, ii, time_idx, intr, conf, lam):
+    """Stand-in for vinsat_amd.ba.BA_window on the CPU: one window (tensors) or a ragged batch (lists), the oracle per window."""
+    def one(st, im, u, x, i_, t_, k_, c_, l_):
+        s = st[0].numpy()
+        for it, init in zip(iters, inits):
+            s, l_, hess, _ = O.ba_iteration(it, s, im[0, :, -1, 6:10].numpy(), u[0].numpy(), x[0].numpy(), i_, t_, k_[0].numpy(), c_.numpy(), l_,
+                                            initialize=init)
+        return torch.from_numpy(s)[None], l_, torch.from_numpy(hess)[None]
+    if isinstance(states, list):
+        outs = [one(*a) for a in zip(states, imu, uv, xyz, ii, time_idx, intr, conf, lam)]
+        return [o[0] for o in outs], velocities, [o[1] for o in outs], [o[2] for o in outs]
+    s, l_, h = one(states, imu, uv, xyz, ii, time_idx, intr, conf, lam)
+    return s, velocities, l_, h
+
+
+def test_batched_driver_runs_the_sequences_in_lock_step_and_matches_the_sequential_driver():
+    """streaming_batched (the sequences of a folder as the batch dimension: round r = batch r of every sequence that still has one)
+    against streaming_version sequence by sequence, the oracle standing in for the GPU: C1 (one batch), the two-pass sequence (two
+    batches: round 1 has a single window left) and a second C1 -- identical errors, time stamps and first detections, and the
+    reference's own results for them."""
+    seqs = [synth.make_sequence("C1"), synth.make_two_pass_sequence(), synth.make_sequence("C1", seed=1)]
+    rec = []
+    batched = od_pipe.streaming_batched([(d.copy(), o.copy()) for d, o in seqs], ba_window=_oracle_ba_window, record=rec)
+    assert [(r["round"], r["sequence"]) for r in rec] == [(0, 0), (0, 1), (0, 2), (1, 1)]
+    for k, (d, o) in enumerate(seqs):
+        e, fd, t = od_pipe.streaming_version(detections=d.copy(), orbit_np=o.copy(), ba=_oracle_ba)
+        assert np.array_equal(batched[k][0].numpy(), e.numpy()) and int(batched[k][1]) == int(fd)
+        assert all(np.array_equal(np.atleast_1d(a), np.atleast_1d(b)) for a, b in zip(batched[k][2], t))
+    assert rel_err(batched[0][0].numpy(), load_golden("c1")["errors"]) < 1e-6
+    g = load_golden("gap")
+    assert rel_err(batched[1][0].numpy(), g["errors"]) < 1e-6
+    assert rel_err(rec[1]["states"][0].numpy(), g["states_out_19"][0]) < 1e-9 and rel_err(rec[3]["states"][0].numpy(), g["states_out_39"][0]) < 1e-9
+
+
+def test_batch_arguments_are_split_per_window_and_checked():
+    """vinsat_amd.ba: the dense form (the reference's own shapes with bsz > 1, BA_filtering.py:14) and the ragged form (lists of
+    single-window arguments) come apart into the same per-window arrays; inconsistent shapes are refused."""
+    from vinsat_amd import ba
+    rng = np.random.default_rng(0)
+    B, n, m = 3, 5, 12
+    states = torch.from_numpy(rng.normal(size=(B, n, 10)))
+    imu = torch.from_numpy(rng.normal(size=(B, n, 2, 10)))
+    uv, xyz, K = torch.from_numpy(rng.normal(size=(B, m, 2))), torch.from_numpy(rng.normal(size=(B, m, 3))), torch.from_numpy(rng.normal(size=(B, n, 4)))
+    ii = np.sort(rng.integers(0, n, size=m)).astype(np.int64)
+    t = np.arange(n, dtype=np.int64) * 5
+    conf = rng.uniform(0.5, 1.0, size=(B, m))
+    assert ba._is_batch(states) and ba._is_batch([states[0:1]]) and not ba._is_batch(states[0:1])
+    form, wins = ba._split_batch(states, imu, uv, xyz, ii, t, K, torch.from_numpy(conf), [1e-4, 1e-3, 1e-2])
+    assert form == "dense" and len(wins) == B and [w["lam"] for w in wins] == [1e-4, 1e-3, 1e-2]
+    lst = lambda x: [x[b:b + 1] for b in range(B)]
+    form2, wins2 = ba._split_batch(lst(states), lst(imu), lst(uv), lst(xyz), [ii] * B, [t] * B, lst(K), [torch.from_numpy(conf[b]) for b in range(B)], 1e-4)
+    assert form2 == "ragged"
+    for b, (a, b2) in enumerate(zip(wins, wins2)):
+        for key in ("states", "cum", "uv", "xyz", "ii", "t", "K", "conf"):
+            assert np.array_equal(a[key], b2[key]), key
+        assert np.array_equal(a["cum"], imu[b].numpy()[:, -1, 6:10])
+    with pytest.raises(ValueError):
+        ba._split_batch(lst(states), lst(imu), lst(uv)[:2], lst(xyz), [ii] * B, [t] * B, lst(K), [torch.from_numpy(conf[0])] * B, 1e-4)
+    with pytest.raises(ValueError):
+        ba._split_batch(states, imu, uv, xyz, ii[:-1], t, K, torch.from_numpy(conf), 1e-4)
+    with pytest.raises(ValueError):
+        ba._split_batch(states, imu, uv, xyz, ii, t, K, torch.from_numpy(conf), [1e-4, 1e-4])
