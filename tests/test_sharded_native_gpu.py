@@ -136,6 +136,15 @@ def _worker_protocols(rank, world, port, tmp):
                 else:
                     assert first == 16 * m
                 sb.close()
+            # unsharded calls in between on the same handle: the gathered exchange of the last sharded trial must not be reused
+            sb = make(1)
+            sb.set_states(g["states0"][0], 1e-4)
+            sb.run_schedule(iters[:6], inits[:6])
+            sb.engine.eng.step(iters[6], inits[6])
+            sb.engine.eng.step(iters[7], inits[7])
+            sb.run_schedule(iters[8:], inits[8:])
+            res["mixed-with-unsharded-calls"] = sb.get_states()
+            sb.close()
             single = BAEngine(n, m)
             single.upload_observations(inp["xyz"], inp["uv"], conf, inp["ii"], n)
             single.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
@@ -143,6 +152,8 @@ def _worker_protocols(rank, world, port, tmp):
             single.run_schedule(iters, inits)
             ref = single.get_states()
             single.close()
+            mixed = res.pop("mixed-with-unsharded-calls")
+            assert mixed[1] == ref[1] and np.abs(mixed[0] - ref[0]).max() / np.abs(ref[0]).max() < 1e-9, confname
             base = res["carried"]
             for name, r in res.items():
                 assert np.array_equal(r[0], base[0]) and r[1] == base[1] and r[3] == base[3], (confname, name)     # one set of bits

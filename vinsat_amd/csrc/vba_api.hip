@@ -1137,6 +1137,7 @@ static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool e
     c.carry = h->carry_enabled ? h->carry_ok : 0;
     c.prof = prof != nullptr;
     h->carry_ok = 0;
+    h->shc.carried = false;         // (an unsharded call on a sharded handle: the gathered exchange of the last sharded trial is stale)
     CallCtx C;
     view_for_call(h, C.V, c);
     DevView& V = C.V;
@@ -1323,6 +1324,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     const int emit_kind = h->carry_enabled ? (h->warm_enabled ? 2 : 1) : 0;
     const int carry0 = h->carry_enabled ? h->carry_ok : 0;
     h->carry_ok = 0;
+    h->shc.carried = false;
     struct Abandon {
         vba_handle h; bool armed = true;
         ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = 0; } }
@@ -1542,6 +1544,7 @@ static int iterate_pipelined(vba_handle h, int iter, int initialize, double* sta
     } else {                    // open a chain with this call as its call 0
         const int carry0 = h->carry_ok;
         h->carry_ok = 0;
+        h->shc.carried = false;
         h->chain_par0 = h->par;
         c = 0;
         const CallSpec q = call_spec(0, iter, initialize, carry0, false);
@@ -1833,6 +1836,7 @@ int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, doubl
     h->last_iter = iter;
     h->last_init = initialize;
     h->carry_ok = false;
+    h->shc.carried = false;
     DevView V;
     sharded_view(h, V);
     if (h->hist_dirty || h->need_hist_reset) {
