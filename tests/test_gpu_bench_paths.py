@@ -151,6 +151,31 @@ def test_batched_path_sixteen_c3_windows_stepped_vs_reference_states():
     eng.close()
 
 
+def test_first_windows_of_a_large_handle_keep_what_was_uploaded_right_after_creation():
+    """A handle of 4096 C3 windows (bench.py's batched series) clears a ~50 GB arena when it is created.  The clear is a device-side fill that the host
+    does not wait for by itself, and the handle's streams are non-blocking: before round 4 the fill was still running when
+    the first windows were uploaded and zeroed their observations again (at 4096 windows the first 3..11 windows of
+    bench.py's batched series rejected trials and ended elsewhere).  Every window is uploaded at once after creation and
+    must end the chained 20-call schedule on the bits of a 4-window handle with the same settings."""
+    g, win = load_golden("c3"), _window("c3")
+    iters, inits = [int(x) for x in g["iters"]], [bool(x) for x in g["initialize"]]
+    n = win.time_idx.size
+    out = {}
+    for W in (4, 4096):
+        eng = _engine(win, windows=W, mode=0)
+        eng.set_solver(0)
+        eng.set_accumulate_lanes(8)
+        eng.set_states(g["states0"][0], 1e-4, window=-1)
+        eng.run_schedule(iters, inits)
+        st, lam, _, ntr, flags = eng.get_states_all()
+        eng.close()
+        assert np.all(flags == 0) and np.all(ntr == ntr[-1]) and np.all(lam == lam[-1]), W
+        assert all(np.array_equal(st[w, :n], st[-1, :n]) for w in range(W)), [w for w in range(W) if not np.array_equal(st[w, :n], st[-1, :n])][:8]
+        out[W] = st[0, :n].copy()
+    assert np.array_equal(out[4], out[4096])
+    _close_to_reference(out[4096], g["states_out_19"][0], 19)
+
+
 @pytest.mark.parametrize("name", ["c3", "c4"])
 def test_warm_select_miss_paths_at_bench_size(name):
     """100 000 (C3) and 400 000 (C4: 1/512-binade bins) carried keys: a warm select forced to miss on every call, and bin

@@ -363,7 +363,9 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
         return fail(VBA_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
     }
     h->arena.size = bytes;
-    if (hipMemset(h->arena.base, 0, bytes) != hipSuccess) {
+    // (hipMemset of device memory returns before the fill has run, and the handle's streams are non-blocking: without the wait the
+    // fill of a 50 GB arena was still running when the first windows were uploaded and zeroed their observations again)
+    if (hipMemset(h->arena.base, 0, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
         hipFree(h->arena.base);
         delete h;
         return fail(VBA_EHIP, "hipMemset of the device arena failed");
@@ -2054,6 +2056,7 @@ int sh_ensure_buffers(vba_handle h, int64_t m_total) {
         const size_t total = (size_t)lenA * (2 + R) + (size_t)lenB * (1 + R) + 64;
         HIPCHK(hipMalloc((void**)&S.buf2, total * 8));
         HIPCHK(hipMemset(S.buf2, 0, total * 8));
+        HIPCHK(hipStreamSynchronize(nullptr));      // (the fill runs on the null stream, the exchanges on the handle's non-blocking one)
         S.sendA[0] = S.buf2;
         S.sendA[1] = S.sendA[0] + lenA;
         S.recvA = S.sendA[1] + lenA;

@@ -745,7 +745,7 @@ int vba_schur_create(int device, int n, int64_t m, int L, int nblk, int64_t npai
     const size_t o_S = need((size_t)V.Npad * V.Npad * 8), o_g = need((size_t)V.Npad * 8), o_y = need((size_t)V.Npad * 8), o_iL = need((size_t)V.nb * kT * kT * 8);
     const size_t o_dl = need((size_t)L * 24), o_part = need((size_t)V.npart * 8), o_info = need(256);
     if (hipMalloc(&h->arena, bytes) != hipSuccess) { delete h; return sfail(VBA_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
-    if (hipMemset(h->arena, 0, bytes) != hipSuccess) { hipFree(h->arena); delete h; return sfail(VBA_EHIP, "hipMemset failed"); }
+    if (hipMemset(h->arena, 0, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { hipFree(h->arena); delete h; return sfail(VBA_EHIP, "hipMemset failed"); }
     char* A = h->arena;
     V.lm_ptr = (int*)(A + o_lmptr); V.row_pose = (int*)(A + o_rpose); V.row_lm = (int*)(A + o_rlm);
     V.row_u = (double*)(A + o_u); V.row_v = (double*)(A + o_v); V.row_w = (double*)(A + o_w);
