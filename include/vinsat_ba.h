@@ -127,6 +127,12 @@ int vba_set_integrator(vba_handle h, int hop100);
  * reduction tree, i.e. results are bit-reproducible for equal settings. */
 int vba_set_accumulate_lanes(vba_handle h, int lanes);
 
+/* Tiles of 256 observation rows per block of the latency-mode trial kernel where it runs in its plain geometry (vba_set_fusion
+ * bit 0 off): 0 = automatic (by the number of tiles of the handle: 4 from 600 tiles, 2 from 150), 1, 2, 4 or 8.  A block's keys
+ * share one pass of bin reservations, so a window of 10^6 keys does not queue ~2000 returning atomics on each of the central
+ * bins.  A performance knob only: block sums stay per tile, results are bit-identical for every value. */
+int vba_set_trial_tiles(vba_handle h, int tiles);
+
 /* BA_reg (BA_filtering.py:100-210): the BA call with a propagated-covariance prior per pose.
  * vba_upload_prior: states_prior [n,10] (arguments states_prior / velocity_prior of BA_reg: positions and the velocity
  * columns are used), hessian_state [n,6,6] (argument hessian_state_t: information matrix over [position, velocity]).

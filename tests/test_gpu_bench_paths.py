@@ -176,6 +176,51 @@ def test_first_windows_of_a_large_handle_keep_what_was_uploaded_right_after_crea
     _close_to_reference(out[4096], g["states_out_19"][0], 19)
 
 
+@pytest.mark.parametrize("fusion", [14, 12])
+def test_trial_kernel_tiles_per_block_do_not_change_a_bit(fusion):
+    """vba_set_trial_tiles: an observation block of the plain latency-mode trial kernel takes 1, 2, 4 or 8 tiles of 256 rows and
+    reserves its share of the bin buckets once.  Block sums stay per tile, the histogram is integers, a bucket is a set -- so
+    nothing may depend on the value: three C3-sized windows on one handle (window 1 with confidences of 3: its LM loop
+    rejects trials; window 2 from another initial guess), call by call with a tight bucket capacity (overflowing buckets:
+    the miss path), then the chained schedule with the allocated one."""
+    from vinsat_amd import od_pipe
+    g, win = load_golden("c3"), _window("c3")
+    iters, inits = [int(x) for x in g["iters"]], [bool(x) for x in g["initialize"]]
+    n = win.time_idx.size
+    conf3 = np.full_like(win.confidences, 3.0)
+    st_other = od_pipe.initial_guess(win, seed=7)
+    ref = None
+    for tiles in (1, 2, 4, 8):
+        eng = _engine(win, windows=3, mode=1)
+        eng.set_fusion(fusion)
+        eng.set_trial_tiles(tiles)
+        eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, conf3, win.ii, n, window=1)
+        got = []
+        for chained in (False, True):
+            eng.set_bucket_cap(0 if chained else 64)        # (0: the allocated capacity; 64: the bin of the median overflows)
+            for w in range(3):
+                eng.set_states(st_other if w == 2 else g["states0"][0], 1e-4, window=w)
+            if chained:
+                eng.run_schedule(iters, inits)
+                got.append([eng.get_states(window=w) for w in range(3)])
+            else:
+                for k in range(20):
+                    eng.step(iters[k], inits[k])
+                    got.append([eng.get_states(window=w) for w in range(3)])
+        misses = eng.warm_select_misses()
+        eng.close()
+        assert misses >= 2, misses
+        if ref is None:
+            ref = got
+            assert max(x[1][3] for x in got) >= 3                            # window 1 did reject trials
+            _close_to_reference(got[19][0][0], g["states_out_19"][0], 19)
+            assert np.array_equal(got[19][0][0], got[20][0][0])              # chained = stepped (no tight buckets at the end)
+            continue
+        for a, b in zip(ref, got):
+            for w in range(3):
+                assert np.array_equal(a[w][0], b[w][0]) and a[w][1] == b[w][1] and np.array_equal(a[w][2], b[w][2]) and a[w][3:] == b[w][3:], (tiles, w)
+
+
 @pytest.mark.parametrize("name", ["c3", "c4"])
 def test_warm_select_miss_paths_at_bench_size(name):
     """100 000 (C3) and 400 000 (C4: 1/512-binade bins) carried keys: a warm select forced to miss on every call, and bin
@@ -390,8 +435,9 @@ def _ba_args(inp, n):
                 conf=torch.from_numpy(inp["conf"]), ii=inp["ii"].copy(), t=inp["time_idx"].copy())
 
 
+@pytest.mark.parametrize("fusion", [None, 14], ids=["mask-auto", "mask-14"])
 @pytest.mark.parametrize("fixture", ["c2", "rej"])
-def test_pipelined_driver_loop_gives_the_bits_of_call_by_call_steps(fixture):
+def test_pipelined_driver_loop_gives_the_bits_of_call_by_call_steps(fixture, fusion):
     """vinsat_amd.ba.BA in the reference's loop shape (od_pipe.py:1036-1040).  Behind every call that feeds back the previous
     result the library enqueues the next call speculatively (iter + 1; the phase change at iter 10 is a wrong guess the first
     time and learnt afterwards); the results must be the bits of vba_step-by-step runs and of the reference's fixtures -- also
@@ -406,6 +452,9 @@ def test_pipelined_driver_loop_gives_the_bits_of_call_by_call_steps(fixture):
     n, m = inp["K"].shape[0], inp["xyz"].shape[0]
     a = _ba_args(inp, n)
     ba_mod.release()
+    # mask 14 (what big single windows get: the step is formed by the fused landmark-only assembly / the recovery of the
+    # partitioned solve, which then also write the trial states to mapped host memory): the loop must pipeline there too
+    ba_mod.configure(fusion=fusion if fusion is not None else "auto")
     outs = []
     for rep in range(3):        # the second and third window profit from what the first one taught
         st, lam = torch.from_numpy(g["states0"][0].copy())[None], 1e-4
@@ -419,10 +468,13 @@ def test_pipelined_driver_loop_gives_the_bits_of_call_by_call_steps(fixture):
     hits, discards = ba_mod._cache["eng"].pipeline_stats()
     # most calls were found already enqueued (a call that rejects trials closes the chain: the next one starts afresh)
     assert hits >= (45 if fixture == "c2" else 10), (hits, discards)
+    ba_mod.configure(fusion="auto")
     ba_mod.release()
     # the same schedule step by step on a plain engine
     e = BAEngine(n, m)
     e.set_pipeline(False)
+    if fusion is not None:
+        e.set_fusion(fusion)
     e.upload_observations(inp["xyz"], inp["uv"], inp["conf"], inp["ii"], n)
     e.upload_window(inp["K"], inp["cumrot"], inp["time_idx"])
     e.set_states(g["states0"][0], 1e-4)

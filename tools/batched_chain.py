@@ -9,7 +9,7 @@ from vinsat_amd.engine import BAEngine
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-det, orb = synth.make_sequence("C3")
+det, orb = synth.make_sequence(os.environ.get("VBA_CONFIG", "C3"))       # VBA_CONFIG: another BASELINE config
 win = od_pipe.prepare_window(det, orb)
 st0 = od_pipe.initial_guess(win)
 n, m = win.time_idx.size, win.ii.size

@@ -19,7 +19,10 @@ from bench import run_steps
 def main():
     Ws = [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8, 15, 16, 22, 32, 64, 128, 256, 512, 1024, 4096]
     combos = os.environ.get("VBA_SWEEP_COMBOS", "lat:part,lat:seq,bw:part,bw:seq").split(",")
-    det, orb = synth.make_sequence(os.environ.get("VBA_SWEEP_CONFIG", "C3"))
+    cfg = os.environ.get("VBA_SWEEP_CONFIG", "C3")       # a BASELINE config, or "POSESxROWS_PER_POSE" (e.g. 500x200)
+    if "x" in cfg:
+        cfg = synth.WindowConfig(cfg, int(cfg.split("x")[0]), int(cfg.split("x")[1]), 5)
+    det, orb = synth.make_sequence(cfg)
     win = od_pipe.prepare_window(det, orb)
     st0 = od_pipe.initial_guess(win)
     n, m = win.time_idx.size, win.ii.size
@@ -42,6 +45,8 @@ def main():
                     e.set_solver(0)
                 if os.environ.get("VBA_SWEEP_FUSION"):
                     e.set_fusion(int(os.environ["VBA_SWEEP_FUSION"]))
+                if os.environ.get("VBA_SWEEP_TILES"):
+                    e.set_trial_tiles(int(os.environ["VBA_SWEEP_TILES"]))
                 if os.environ.get("VBA_SWEEP_LANES"):
                     e.set_accumulate_lanes(int(os.environ["VBA_SWEEP_LANES"]))
                 if os.environ.get("VBA_SWEEP_CWAVES"):

@@ -10,7 +10,7 @@ import numpy as np
 from ctypes import byref, c_int64
 from vinsat_amd import od_pipe, synth, _lib
 from vinsat_amd.engine import BAEngine, _p
-det, orb = synth.make_sequence("C3")
+det, orb = synth.make_sequence(os.environ.get("VBA_CONFIG", "C3"))
 win = od_pipe.prepare_window(det, orb)
 st0 = od_pipe.initial_guess(win)
 n, m = win.time_idx.size, win.ii.size

@@ -43,6 +43,7 @@ SIGNATURES = {
     "vba_warm_select_misses": (c_int, [c_void_p, POINTER(c_int)]),
     "vba_set_pivoting": (c_int, [c_void_p, c_int]),
     "vba_set_accumulate_lanes": (c_int, [c_void_p, c_int]),
+    "vba_set_trial_tiles": (c_int, [c_void_p, c_int]),
     "vba_set_integrator": (c_int, [c_void_p, c_int]),
     "vba_solver_fallbacks": (c_int, [c_void_p, POINTER(c_int)]),
     "vba_upload_observations": (c_int, [c_void_p, c_int, c_int, c_int64, PD, PD, PD, PI64]),

@@ -127,6 +127,7 @@ struct vba_context {
     int chunk_waves = 2;                    // vba_set_chunk_waves
     int cr_levels = 2;                      // cyclic-reduction levels in front of the one-workgroup kernel (VBA_CR_LEVELS / vba_set_cr_levels: 2 or 3)
     int fusion = 15;                        // vba_set_fusion (default: the trial kernel forms the step, the solves form their own blocks, uniform-pass assembly)
+    bool fusion_auto = true;                // the mask is the library's own choice (vba_set_fusion not called)
     int bucket_cap_alloc = 0;               // allocated capacity of a bin bucket (vba_set_bucket_cap lowers the one in use)
     int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
     double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
@@ -251,6 +252,7 @@ int ready(vba_handle h) {
 extern "C" {
 
 int vba_set_accumulate_lanes(vba_handle h, int lanes);
+int vba_set_trial_tiles(vba_handle h, int tiles);
 int vba_set_solver(vba_handle h, int chunk);
 
 int vba_version(void) { return 210; }     // 2.1: vba_set_chunk_waves, fusion bits 2..4, warm select mode 3
@@ -292,9 +294,13 @@ constexpr int kPartitionedWindowsMax = 1023;
 static bool default_latency_mode(int windows, int64_t m_max) {
     return windows == 1 || (windows <= kLatWindowsCap && (double)windows <= 31.0 * std::pow(50000.0 / (double)m_max, 0.7));
 }
-static int default_fusion(bool lat, int windows, int64_t m_max) {
+static int default_fusion(bool lat, int windows, int n_max, int64_t m_max) {
     const double rows = (double)windows * (double)m_max;
-    return (!lat || windows == 1) ? 15 : rows <= 175e3 ? 15 : rows <= 450e3 ? 14 : 12;      // (one window: as measured in rounds 2 and 3; the pipelined BA() loop needs bit 0)
+    // one window (round 4, with the trial kernel's observation blocks of several tiles, vba_set_trial_tiles): mask 15 : 14 = 19.8 : 19.6
+    // k it/s at 75 000 rows, 19.3 : 18.8 at 100 000, 17.1 : 17.2 at 150 000, 15.4 : 17.4 at 200 000 (C4), 10.1 : 12.2 at 500 000 rows /
+    // 2004 poses (C5), 15.4 : 16.3 at 100 000 rows / 2000 poses
+    if (windows == 1) return (lat && (m_max >= 150000 || n_max >= 1500)) ? 14 : 15;
+    return !lat ? 15 : rows <= 175e3 ? 15 : rows <= 450e3 ? 14 : 12;
 }
 
 int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* out) {
@@ -423,6 +429,7 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     V.hop = 0; V.pivot = 0; V.call = -1; V.emit = 0; V.carry = 0; V.dyn_in_acc = 0;
     V.par = 0; V.fold = 0; V.redo = 0; V.fused_trial = 0; V.pending_only = 0; V.warm_force_miss = 0;
     V.lat = lat ? 1 : 0;       // latency mode: few windows cannot fill the chip, the kernel COUNT of a call is what costs
+    V.trial_tiles = 1;          // set after construction by vba_set_trial_tiles(h, 0)
     // warm bins: 2^44 bit patterns (1/256 of a binade, range [c/16, c*8)) while a bin of the median's density stays short,
     // 2^43 (1/512, [c/4, c*2)) for the big windows
     V.warm_shift = warm_shift;
@@ -446,7 +453,7 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     // to share them with
     for (int k = 0; k < 64; ++k) h->pred_iter[k] = h->pred_init[k] = -1;
     h->V.host_states = nullptr;
-    h->fusion = default_fusion(lat, windows, m_max);
+    h->fusion = default_fusion(lat, windows, n_max, m_max);
     if ((windows == 1 && (hipEventCreateWithFlags(&h->ev_first, hipEventDisableTiming) != hipSuccess ||
                           hipHostMalloc((void**)&h->h_states_map, (size_t)2 * n_max * 10 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
                           hipHostGetDevicePointer((void**)&h->V.host_states, h->h_states_map, 0) != hipSuccess)) ||
@@ -472,6 +479,7 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     h->have_obs.assign(W, 0); h->have_win.assign(W, 0); h->have_state.assign(W, 0); h->have_prior.assign(W, 0);
     h->perm.resize(W);
     vba_set_accumulate_lanes(h, 0);
+    vba_set_trial_tiles(h, 0);
     vba_set_solver(h, -1);
     // warm select everywhere; the accept test is folded into the next call's first kernel only in latency mode (with many
     // windows the decide launch is 20 us of a 10 ms step, and every block of the select would repeat the test)
@@ -612,6 +620,22 @@ int vba_set_accumulate_lanes(vba_handle h, int lanes) {
     return VBA_OK;
 }
 
+// Tiles of 256 rows per observation block of the latency-mode trial kernel (plain geometry: fusion bit 0 off).  Measured on the
+// chained 20-call schedule (k it/s, tiles 1 / 2 / 4 / 8): one C4 window (782 tiles) 15.3 / 16.4 / 17.4 / 16.2, one C5 window
+// (1954 tiles) 9.8 / 11.5 / 12.2 / 12.1, 8 C3 windows (1568) 113.9 / 120.6 / 121.9, 22 C3 windows (4312) 185 / 197 / 195; one C3
+// window (196, with that fusion mask) 19.7 / 20.6 / 19.8.  Results do not depend on it (see k_trial).
+int vba_set_trial_tiles(vba_handle h, int tiles) {
+    if (!h) return fail(VBA_EINVAL, "null handle");
+    if (int rc_settle = settle(h)) return rc_settle;
+    if (tiles == 0) {
+        const int64_t blocks = (int64_t)h->W * h->V.nblk_obs;
+        tiles = blocks >= 600 ? 4 : (blocks >= 150 ? 2 : 1);
+    }
+    if (tiles != 1 && tiles != 2 && tiles != 4 && tiles != 8) return fail(VBA_EINVAL, "tiles must be 0 (automatic), 1, 2, 4 or 8");
+    h->V.trial_tiles = tiles;
+    return VBA_OK;
+}
+
 int vba_set_key_carry(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
@@ -628,6 +652,7 @@ int vba_set_fusion(vba_handle h, int mask) {
     if (mask & (16 | 32 | 64)) return fail(VBA_EINVAL, "mask bits 4 .. 6 select comparison variants that this build does not carry (make VARIANTS=1)");
 #endif
     h->fusion = mask;
+    h->fusion_auto = false;
     return VBA_OK;
 }
 
@@ -1503,9 +1528,10 @@ static bool host_watch_changed(vba_handle h) {
 }
 
 static bool can_pipeline(vba_handle h) {
-    // (the trial kernel must be the one that forms the trial states: it also writes them to mapped host memory)
+    // (whichever kernel forms the trial states of an unpivoted call -- the trial kernel, or with fusion bit 0 off the fused landmark-only
+    // assembly / the recovery of the partitioned solve -- also writes them to mapped host memory)
     return h->pipeline && h->W == 1 && h->h_states_map && h->carry_enabled && h->warm_enabled >= 1 && h->fold_enabled && h->inline_select &&
-           h->V.wbucket != nullptr && (h->fusion & 1) && h->pivot_mode == 0 && h->V.chunk > 0 && h->V.lat;
+           h->V.wbucket != nullptr && h->pivot_mode == 0 && h->V.chunk > 0 && h->V.lat;
 }
 
 static int iterate_pipelined(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out, double* last_hessian,
@@ -2262,6 +2288,9 @@ int vba_sh_run_schedule(vba_handle h, int ncalls, const int* iters, const int* i
     // (the exchange buffers are laid out by the handle's geometry -- observation blocks, bucket capacity --, which must be the same on
     // every rank: a handle created for exactly ceil(m_total / ranks) rows; any other takes the round-3 protocol, whose slots are sized
     // by m_total alone)
+    // (the carried-keys protocol is written for the trial kernel that forms the step; a handle whose mask was chosen by the library --
+    // big single windows get 14 -- takes 15 here)
+    if (h->fusion_auto && S.protocol != 0 && !(h->fusion & 1)) h->fusion = 15;
     if (S.protocol == 0 || !h->V.wbucket || !h->V.lat || !(h->fusion & 1) || h->V.chunk <= 0 || h->m_max != S.m_pad) {
         // the round-3 protocol, call by call
         long total = 0;

@@ -203,6 +203,7 @@ struct DevView {
     unsigned* hist0_ext[2];         // digit-0 / warm histogram of that call parity inside the exchange buffer (null: the handle's own slot)
     const double* sel_slots;        // the gathered buckets of the median's bin, one slot per rank: [count, keys ...] (null: the list V.ckeys)
     int sel_nslots, sel_slot_stride;
+    int trial_tiles;                // tiles of 256 rows per observation block of the plain latency-mode trial kernel (1, 2, 4; see k_trial)
     unsigned long long* wmax_ext;   // where the accumulation enters its maximum raw weight (null: WinScalars::wmax_bits of the call's parity)
 };
 

@@ -204,6 +204,10 @@ __global__ __launch_bounds__(256) void k_assemble(DevView V) {
                 retract(V.states + (sb + i) * 10, d9, o);
 #pragma unroll
                 for (int r = 0; r < 10; ++r) V.states_new[(sb + i) * 10 + r] = o[r];
+                if (V.host_states) {        // (one-window handles: sb == 0; a pipelined call reads its result from host memory)
+#pragma unroll
+                    for (int r = 0; r < 10; ++r) V.host_states[((size_t)V.par * V.n_max + i) * 10 + r] = o[r];
+                }
             }
         }
         {

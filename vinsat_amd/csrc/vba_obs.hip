@@ -1005,11 +1005,18 @@ constexpr int kEdgesPerBlock16 = 15;
 // PART (many windows per launch, FUSED 0): 0 = one grid does both kinds of block; 1 = the observation blocks only, 2 = the
 // pose-chain blocks only, as two launches -- the orbit propagation of the chain blocks costs the streaming blocks half
 // their occupancy when both are one kernel (96 registers against 40).
-template <int EMIT, int FUSED, int PART = 0>
+// TILES (plain geometry, one grid, latency mode): an observation block takes TILES consecutive tiles of 256 rows.  The
+// block's keys share ONE pass of bin reservations -- a window of 10^6 keys is ~2000 tiles, every one of which hits the few
+// hundred central bins with a returning atomic of its own, and the same-address atomics queue up (block 100 of C5 waited
+// 6 .. 8 of its 15 us for its bases, C3: 0.4 .. 1.8) -- and the grid fits the chip in one round.  Block sums stay per TILE
+// (the slots and the bits of TILES = 1), the histogram is integers, a bucket is a set: the results do not depend on TILES.
+template <int EMIT, int FUSED, int PART = 0, int TILES = 1>
 __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     static_assert(PART == 0 || FUSED == 0, "split launches exist for the plain geometry only");
+    static_assert(TILES == 1 || (PART == 0 && FUSED == 0), "tiled observation blocks exist for the plain one-grid geometry only");
     constexpr bool FORM = FUSED == 1 || FUSED == 2;
     __shared__ double red[kObsBlock / 64];
+    __shared__ double redt[TILES > 1 ? 2 * TILES * (kObsBlock / 64) : 1];
     __shared__ unsigned lh[EMIT == 2 ? kSelBins : (EMIT == 1 ? 1024 : 1)];
     __shared__ double snew[FORM ? (kObsBlock + 1) * 10 : 1];
     __shared__ int lpose[FORM ? kObsBlock : 1];
@@ -1036,8 +1043,10 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     const int tid = threadIdx.x;
     double s = 0.0, s_raw = 0.0;
     const size_t sb = (size_t)w * V.n_max;
-    const bool obs_block = PART == 1 || (PART == 0 && (int)blockIdx.x < V.nblk_obs);
-    const int part_slot = PART == 2 ? V.nblk_obs + (int)blockIdx.x : (int)blockIdx.x;        // this block's place in part_trial
+    const int nfat = (V.nblk_obs + TILES - 1) / TILES;     // observation blocks of this grid
+    const bool obs_block = PART == 1 || (PART == 0 && (int)blockIdx.x < nfat);
+    // this block's place in part_trial (an observation block of several tiles: its first tile's)
+    const int part_slot = PART == 2 ? V.nblk_obs + (int)blockIdx.x : (obs_block ? (int)blockIdx.x * TILES : V.nblk_obs + ((int)blockIdx.x - nfat));
     const double lam32 = (double)(float)sc.lam[par];      // torch.eye() is float32 (BA_filtering.py:54)
     // a window that has fallen back to the pivoted kernels (landmark-only phase) reads the trial states they wrote
     const bool fz = FUSED == 2 || (FUSED == 1 && !(sc.fl[par] & 16u));
@@ -1073,11 +1082,14 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     }
     VBA_OSTAMP(1);
     unsigned bad = 0u;
-    unsigned kbin[2] = {0u, 0u}, kslot[2] = {0u, 0u};      // EMIT 2: warm bin of this thread's two keys and their place in the block's share
-    double kkey[2] = {0.0, 0.0};
-    bool kvalid = false;
+    unsigned kbin[2 * TILES] = {}, kslot[2 * TILES] = {};      // EMIT 2: warm bin of this thread's keys and their place in the block's share
+    double kkey[2 * TILES] = {};
+    bool kvalid[TILES] = {};
+    double s_tile[TILES] = {}, sraw_tile[TILES] = {};          // (TILES > 1: the sums of the tiles, reduced one by one below)
     if (PART != 2 && obs_block) {
-        const int k = blockIdx.x * kObsBlock + tid;
+#pragma unroll
+    for (int tl = 0; tl < TILES; ++tl) {
+        const int k = (blockIdx.x * TILES + tl) * kObsBlock + tid;
         const size_t ob = (size_t)w * V.obs_stride, mb = (size_t)w * V.m_max;
         const bool have = k < m;
         const int pose = have ? (kEarlyPose ? early_pose : V.opose[2 * ob + k]) : -1;
@@ -1124,22 +1136,24 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             const double wk = (V.wraw[mb + k] / wmax) * V.oconf[ob + k];
             const double du = V.ou[ob + k] - u, dv = V.ov[ob + k] - v;
             s = fabs(du * wk) + fabs(dv * wk);
+            s_tile[tl] = s;
             if (EMIT) {
                 const double ru = fabs(du), rv = fabs(dv);
                 reinterpret_cast<double2*>(V.absr + 2 * mb)[k] = make_double2(ru, rv);
                 s_raw = ru + rv;
+                sraw_tile[tl] = s_raw;
                 if (EMIT == 2) {
-                    kbin[0] = warm_bin(f64_bits(ru), wlo, V.warm_shift);
-                    kbin[1] = warm_bin(f64_bits(rv), wlo, V.warm_shift);
+                    kbin[2 * tl] = warm_bin(f64_bits(ru), wlo, V.warm_shift);
+                    kbin[2 * tl + 1] = warm_bin(f64_bits(rv), wlo, V.warm_shift);
                     if (V.wbucket) {        // the place inside the block's share of the bin: a returning atomic
-                        kslot[0] = atomicAdd(&lh[kbin[0]], 1u);
-                        kslot[1] = atomicAdd(&lh[kbin[1]], 1u);
-                        kkey[0] = ru;
-                        kkey[1] = rv;
-                        kvalid = true;
+                        kslot[2 * tl] = atomicAdd(&lh[kbin[2 * tl]], 1u);
+                        kslot[2 * tl + 1] = atomicAdd(&lh[kbin[2 * tl + 1]], 1u);
+                        kkey[2 * tl] = ru;
+                        kkey[2 * tl + 1] = rv;
+                        kvalid[tl] = true;
                     } else {
-                        atomicAdd(&lh[kbin[0]], 1u);
-                        atomicAdd(&lh[kbin[1]], 1u);
+                        atomicAdd(&lh[kbin[2 * tl]], 1u);
+                        atomicAdd(&lh[kbin[2 * tl + 1]], 1u);
                     }
                 } else {
                     atomicAdd(&lh[(unsigned)(f64_bits(ru) >> 53) & 1023u], 1u);
@@ -1147,6 +1161,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
                 }
             }
         }
+    }
     } else if (PART != 1) {
         const int db = part_slot - V.nblk_obs;
         const bool reg = V.reg && !prm.initialize;
@@ -1239,16 +1254,38 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
         }
     }
     VBA_OSTAMP(5);
-    const double t = block_sum<kObsBlock>(s, red);
-    if (tid == 0) V.part_trial[(size_t)w * V.trial_stride + part_slot] = t;
+    if (TILES > 1 && obs_block) {
+        // the 2 TILES sums of the tiles in ONE round of barriers; per sum the order of block_sum (waves 0 .. 3 onto 0.0)
+#pragma unroll
+        for (int tl = 0; tl < TILES; ++tl) {
+            const double a = wave_sum(s_tile[tl]), r2 = wave_sum(sraw_tile[tl]);
+            if ((tid & 63) == 0) {
+                redt[(2 * tl) * (kObsBlock / 64) + (tid >> 6)] = a;
+                redt[(2 * tl + 1) * (kObsBlock / 64) + (tid >> 6)] = r2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * TILES && part_slot + tid / 2 < V.nblk_obs) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < kObsBlock / 64; ++i) t += redt[tid * (kObsBlock / 64) + i];
+            if (tid & 1) { if (EMIT) V.part_next[(size_t)w * V.nblk_obs + part_slot + tid / 2] = t; }
+            else V.part_trial[(size_t)w * V.trial_stride + part_slot + tid / 2] = t;
+        }
+    } else {
+        const double t = block_sum<kObsBlock>(s, red);
+        if (tid == 0) V.part_trial[(size_t)w * V.trial_stride + part_slot] = t;
+    }
     VBA_OSTAMP(6);
     if (FORM && !obs_block) {
         const unsigned long long bp = __ballot(bad & 1u), bn = __ballot(bad & 2u);
         if ((tid & 63) == 0 && (bp || bn)) atomicOr(&sc.fl[par], (bp ? (8u | 16u) : 0u) | (bn ? 2u : 0u));
     }
     if (EMIT && PART != 2 && obs_block) {
-        const double t_raw = block_sum<kObsBlock>(s_raw, red);
-        if (tid == 0) V.part_next[(size_t)w * V.nblk_obs + blockIdx.x] = t_raw;
+        if (TILES == 1) {
+            const double t_raw = block_sum<kObsBlock>(s_raw, red);
+            if (tid == 0) V.part_next[(size_t)w * V.nblk_obs + part_slot] = t_raw;
+        }
         unsigned* hist = hist0_of(V, w, par ^ 1);
         if (bucketing) {
             // ... and each key goes to its place: the next call finds the keys of the wanted bin together, no pass over all keys
@@ -1257,10 +1294,10 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
             for (int q = 0; q < kBinsPerThread; ++q) lh[tid + q * kObsBlock] = bb[q];
             __syncthreads();
             VBA_OSTAMP(7);
-            if (kvalid) {
-                double* pool = V.wbucket + ((size_t)w * 2 + (par ^ 1)) * kSelBins * (size_t)V.bucket_cap;
+            double* pool = V.wbucket + ((size_t)w * 2 + (par ^ 1)) * kSelBins * (size_t)V.bucket_cap;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < 2 * TILES; ++q) {
+                if (kvalid[q / 2]) {
                     const unsigned slot = lh[kbin[q]] + kslot[q];
                     if (kbin[q] >= 1u && kbin[q] <= 2046u && slot < (unsigned)V.bucket_cap) pool[(size_t)kbin[q] * V.bucket_cap + slot] = kkey[q];
                 }
@@ -1570,6 +1607,9 @@ static void launch_trial_emit(const DevView& V, hipStream_t s) {
     if (f == 1) hipLaunchKernelGGL((k_trial<EMIT, 1>), g, b, 0, s, V);
     else if (f == 2) hipLaunchKernelGGL((k_trial<EMIT, 2>), g, b, 0, s, V);
     else if (f == 3) hipLaunchKernelGGL((k_trial<EMIT, 3>), g, b, 0, s, V);
+    else if (EMIT == 2 && V.trial_tiles == 8) hipLaunchKernelGGL((k_trial<EMIT, 0, 0, EMIT == 2 ? 8 : 1>), dim3((V.nblk_obs + 7) / 8 + V.nblk_dyn, V.W), b, 0, s, V);
+    else if (EMIT == 2 && V.trial_tiles == 4) hipLaunchKernelGGL((k_trial<EMIT, 0, 0, EMIT == 2 ? 4 : 1>), dim3((V.nblk_obs + 3) / 4 + V.nblk_dyn, V.W), b, 0, s, V);
+    else if (EMIT == 2 && V.trial_tiles == 2) hipLaunchKernelGGL((k_trial<EMIT, 0, 0, EMIT == 2 ? 2 : 1>), dim3((V.nblk_obs + 1) / 2 + V.nblk_dyn, V.W), b, 0, s, V);
     else hipLaunchKernelGGL((k_trial<EMIT, 0>), g, b, 0, s, V);
 }
 

@@ -2688,6 +2688,10 @@ __global__ __launch_bounds__(256) void k_solve_recover(DevView V, int s) {
         retract(V.states + (sb + i) * 10, d9, o);
 #pragma unroll
         for (int q = 0; q < 10; ++q) V.states_new[(sb + i) * 10 + q] = o[q];
+        if (V.host_states) {        // (one-window handles: sb == 0; a pipelined call reads its result from host memory)
+#pragma unroll
+            for (int q = 0; q < 10; ++q) V.host_states[((size_t)V.par * V.n_max + i) * 10 + q] = o[q];
+        }
     }
     const unsigned long long anybad = __ballot(bad);
     if ((threadIdx.x & 63) == 0 && anybad) atomicOr(&sc.fl[V.par], 2u);

@@ -74,6 +74,10 @@ class BAEngine:
         """Lanes per pose of the accumulation kernel (0 = automatic)."""
         _lib.check(self.lib.vba_set_accumulate_lanes(self.h, int(lanes)), self.lib)
 
+    def set_trial_tiles(self, tiles):
+        """Tiles of 256 rows per observation block of the latency-mode trial kernel (0 = automatic); results do not depend on it."""
+        _lib.check(self.lib.vba_set_trial_tiles(self.h, int(tiles)), self.lib)
+
     def set_key_carry(self, on):
         """True (default): an accepted trial leaves the next call's |r| keys behind; False: every call recomputes them."""
         _lib.check(self.lib.vba_set_key_carry(self.h, int(bool(on))), self.lib)
