@@ -565,6 +565,19 @@ int vba_set_solver(vba_handle h, int chunk) {
         // work in the reduced system) win: chunks of 12 measured +7 .. +9 % at 100 poses (256 .. 1000 windows) over the latency
         // rule's chunks of 2, +2 % at 500 poses over chunks of 8 (4 / 8 / 16 / 14 all slower; tools/attic/chunk_bw.sh)
         if (!h->V.lat) c1 = std::max(c1, std::min(12, std::max(2, h->n_max / 3)));
+        // latency mode, several windows: the chunk elimination holds 256 registers, i.e. 1024 two-wave blocks are one round of
+        // the chip and block 1025 waits for a second one (18 C3 windows of 63 chunks: 26.1 us against 17.7 at 15 windows) --
+        // chunks of up to 12 poses where that keeps the elimination in one round (172.8 -> 180.4 k it/s at 18 windows,
+        // 194.9 -> 202.3 at 22; no difference where it does not fit either way)
+        // latency mode (re-measured in round 4 with the kernels as they are now): chunks of 8 also where 64 separators would allow
+        // shorter ones -- one window of 100 poses (C2) 24.8 k it/s against 23.4 k with chunks of 2, 16 such windows 367 k against 319 k,
+        // 64 windows 903 k against 749 k; 200 poses: on par with the old rule's 4 for one window, +5 % from 16 windows on
+        if (h->V.lat) c1 = std::max(c1, std::min(8, std::max(2, h->n_max / 3)));
+        if (h->V.lat && h->W > 1) {
+            int c = c1;
+            while (c < 12 && (int64_t)h->W * ((h->n_max + c - 1) / c) > 1024) ++c;
+            if ((int64_t)h->W * ((h->n_max + c - 1) / c) <= 1024) c1 = c;
+        }
         if (c1 <= 60) {
             h->V.chunk = c1;
             h->V.chunk2 = -1;
