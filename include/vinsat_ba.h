@@ -102,7 +102,9 @@ int vba_set_stream(vba_handle h, void* hip_stream, int external);
  * when many windows are batched); chunk in [2,60] cuts the chain into chunks of that many poses that are
  * eliminated in parallel plus a reduced system over the separators; chunk = -1 restores the default
  * (0 for more than 1023 windows -- the walk is a latency chain of ~2.2 ms at 500 poses that only so many windows amortise, see the
- * sweep in DESIGN.md section 3 --; bandwidth-mode handles: chunks of 12 poses (fewer separators: throughput); otherwise chunks of 8 poses -- fewer up to 520 poses, more beyond 1032 -- and the reduced
+ * sweep in DESIGN.md section 3 --; bandwidth-mode handles: chunks of 12 poses (fewer separators: throughput); otherwise chunks of 8 poses
+ * (n_max / 3 for chains shorter than 24; more beyond 1032 poses; several latency-mode windows: up to 12 where that keeps the chunk
+ * elimination of all windows in one round of the chip, 1024 two-wave blocks) and the reduced
  * system by cyclic reduction, see vba_set_solver2; two levels of ~n^(1/3) beyond 7700 poses).  With chunk = 0 a
  * wavefront walks one window; chunk = -3 makes three windows of equal pose count share a wavefront (no faster on
  * MI355X at any batch size measured, kept for comparison), chunk = -2 forbids it.  All variants agree to rounding. */
@@ -199,7 +201,9 @@ int vba_set_bucket_cap(vba_handle h, int cap);
  *          round trips to device memory plus the write-back / invalidate of the per-XCD L2s, 4.7 us from the last producer's
  *          last store to the consumer's first load, against ~3.2 us for a kernel boundary.  Comparison / tests only.
  *   bits 4 .. 6 exist in the comparison build only (vba_has_variants); the default build answers VBA_EINVAL.
- * Default: 15 (bits 0 .. 3) for one window and for bandwidth mode; latency-mode handles of several windows drop the fusions that
+ * Default: 15 (bits 0 .. 3) for one window of fewer than 150 000 rows and 1500 poses (a bigger one: 14, with the trial kernel's
+ * observation blocks of several tiles, vba_set_trial_tiles -- C4 17.4 against 15.4 k it/s, C5 12.2 against 10.1; the pipelined
+ * vba_iterate_resident works with either) and for bandwidth mode; latency-mode handles of several windows drop the fusions that
  * trade instructions for launches once launches are no longer what a call costs -- 15 up to 175 000 rows per launch, 14 (the trial
  * kernel reads a step that its own launch formed) up to 450 000, 12 (the assembly is a launch as well) beyond: from the round-4
  * sweep, DESIGN.md section 3.  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
