@@ -274,6 +274,8 @@ int vba_device_count(int* count) {
 //   latency     22   40   71  114  144  168  187  201  204    .  184  189  202  204    .    .    .   (best fusion mask, below)
 //   bandwidth    .   23   38   64  112  139  167  194  212  245  273  314  342  361  367    .  369   (partitioned solve)
 //   ... walk     .    2    4    9    .   17   23    .   34    .   63  114  187  277  366  435  479   (four windows per wavefront)
+// (as measured when the switches were placed; with the tiled trial kernel and the chunk rules that followed the latency row reads
+// 22 / 41 / 74 / 125 / 154 / 177 / 201 / 210 at W = 1 .. 28, bench.py "batched_sweep")
 // and C2 windows (100 poses / 5 000 rows): latency 107 / 379 / 606 / 943 / 1230 / 1446 / 1541 at W = 4 / 16 / 32 / 64 / 128 / 256 /
 // 512 against bandwidth 51 / 199 / 360 / 662 / 1145 / 1649 / 1931; walk against partitioned solve 954 : 1649 at 256 windows,
 // 2183 : 2071 at 1024, 3227 : 2259 at 4096.
