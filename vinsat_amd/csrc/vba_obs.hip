@@ -1085,8 +1085,9 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
     unsigned kbin[2 * TILES] = {}, kslot[2 * TILES] = {};      // EMIT 2: warm bin of this thread's keys and their place in the block's share
     double kkey[2 * TILES] = {};
     bool kvalid[TILES] = {};
-    double s_tile[TILES] = {}, sraw_tile[TILES] = {};          // (TILES > 1: the sums of the tiles, reduced one by one below)
+    double s_tile[TILES] = {}, sraw_tile[TILES] = {};          // (TILES > 1: the sums of the tiles, reduced together below)
     if (PART != 2 && obs_block) {
+    // (the loop over this block's tiles; its body keeps the indentation of the one tile it was)
 #pragma unroll
     for (int tl = 0; tl < TILES; ++tl) {
         const int k = (blockIdx.x * TILES + tl) * kObsBlock + tid;
@@ -1161,7 +1162,7 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
                 }
             }
         }
-    }
+    }   // tiles
     } else if (PART != 1) {
         const int db = part_slot - V.nblk_obs;
         const bool reg = V.reg && !prm.initialize;
