@@ -276,6 +276,14 @@ int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const d
 int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out,
                          double* last_hessian, int* n_trials, unsigned* flags);
 
+/* vba_iterate as the FIRST call of a driver loop whose following calls are vba_iterate_resident (a new window, or states the caller
+ * changed): the states go up and the call is served like a resident one -- returned as soon as its accept test is known, the next
+ * call enqueued behind it (vba_set_pipeline); the watched host buffers are compared as in a resident call (VBA_FLAG_HOST_CHANGED).
+ * Same bits as vba_iterate.  A caller that replaces the states before every call
+ * should use vba_iterate: there the speculated call would be waited for and dropped each time. */
+int vba_iterate_open(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in, double* states_out,
+                     double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags);
+
 /* Pipelining of the driver loop (default on; handles of one window).  vba_iterate_resident returns call k as soon as its
  * accept test is known and has by then enqueued call k + 1 speculatively (iter + 1 / the same phase until the caller has
  * been seen doing something else after that iter), so the device works through the caller's host-side turnaround; a call
@@ -286,7 +294,8 @@ int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_
 int vba_set_pipeline(vba_handle h, int on);
 /* Host buffers of the caller whose content was uploaded (e.g. the ndarray arguments ii / time_idx of BA()) and that the caller
  * might edit in place: every vba_iterate_resident compares `live` with the reference `copy` (bytes each, both must stay valid;
- * 8 slots -- one per array argument of BA() --, live == NULL clears one) while the device works and reports a difference as VBA_FLAG_HOST_CHANGED. */
+ * 8 slots -- one per array argument of BA() --, live == NULL clears one) while the device works -- from 64 kB of watched bytes on a helper
+ * thread of the handle, beside the enqueue of the speculated call -- and reports a difference as VBA_FLAG_HOST_CHANGED. */
 int vba_set_host_watch(vba_handle h, int slot, const void* live, const void* copy, int64_t bytes);
 int vba_pipeline_stats(vba_handle h, int* hits, int* discards);
 

@@ -280,10 +280,18 @@ def _call(eng, reg, iter, initialize, states, lamda_init, reupload):
             eng = reupload()
             out, lam, hess, n_trials, flags = eng.iterate(iter, initialize, float(lamda_init), _np(states)[0])
     else:
-        if not _numpy_unchanged(_cache.get("refs", ())):      # (no resident call, no watch: compare here)
+        # the first call of a window's loop: the calls that follow feed its result back, so it opens the pipelined chain
+        # (vba_iterate_open), and like a resident call it has the library compare the watched ndarrays while the device works;
+        # ndarrays without a watch slot are compared here and now
+        watched = _cache.get("all_watched")
+        if not watched and not _numpy_unchanged(_cache.get("refs", ())):
             invalidate()
             eng = reupload()
-        out, lam, hess, n_trials, flags = eng.iterate(iter, initialize, float(lamda_init), _np(states)[0])
+        out, lam, hess, n_trials, flags = eng.iterate(iter, initialize, float(lamda_init), _np(states)[0], opening=True)
+        if watched and flags & _HOST_CHANGED:
+            invalidate()
+            eng = reupload()
+            out, lam, hess, n_trials, flags = eng.iterate(iter, initialize, float(lamda_init), _np(states)[0])
     return out, lam, hess, n_trials, flags & 7
 
 

@@ -1,6 +1,10 @@
 // vba_api.hip -- C ABI of libvinsat_ba.so (see include/vinsat_ba.h): context, uploads, one BA() step.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,6 +146,18 @@ struct vba_context {
     bool last_pipelined = false;            // the last call went through iterate_pipelined: a speculated call has reused its scratch
     int spec_hits = 0, spec_discards = 0;   // diagnostics (vba_pipeline_stats)
     struct Watch { const void* live = nullptr; const void* copy = nullptr; size_t bytes = 0; } watch[8];   // vba_set_host_watch
+    // The watched buffers are compared by a helper thread of the handle while the calling thread enqueues the speculated call: the
+    // comparison of the reference driver's `ii` (400 kB at C3) is ~9 us of memcmp, and a landmark-only call leaves the host no idle
+    // time to hide it in (23 us of device work against ~29 us of host work per resident call before this).
+    struct WatchWorker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        int request = 0;                    // guarded by m: 0 idle, 1 compare, -1 quit
+        std::atomic<int> done{0};           // 1: `changed` is valid
+        bool changed = false;
+        bool started = false;
+    } ww;
     // vba_set_chain_profile: HIP events at the class boundaries (accumulate | solve | trial) of every call of a chained schedule
     struct ChainProf {
         bool on = false;
@@ -251,6 +267,7 @@ int ready(vba_handle h) {
 
 extern "C" {
 
+static void watch_stop(vba_handle h);
 int vba_set_accumulate_lanes(vba_handle h, int lanes);
 int vba_set_trial_tiles(vba_handle h, int tiles);
 int vba_set_solver(vba_handle h, int chunk);
@@ -513,6 +530,7 @@ int vba_get_mode(vba_handle h, int* mode, int* chunk) {
 int vba_destroy(vba_handle h) {
     if (!h) return VBA_OK;
     (void)settle(h);
+    watch_stop(h);
     hipSetDevice(h->device);
     (void)vba_sh_comm_destroy(h);
     if (h->own_stream) { hipStreamSynchronize(h->own_stream); hipStreamDestroy(h->own_stream); }
@@ -1526,6 +1544,25 @@ int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const d
     return take_back(h, states_out, lamda_out, last_hessian, n_trials, flags);
 }
 
+static bool can_pipeline(vba_handle h);
+static bool host_watch_changed(vba_handle h);
+static int iterate_pipelined(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out, double* last_hessian,
+                             int* n_trials, unsigned* flags);
+
+// vba_iterate as the FIRST call of a driver loop whose following calls will be vba_iterate_resident: the states go up, and the call
+// itself is served like a resident one -- returned as soon as its accept test is known, with the next call already enqueued behind
+// it (a caller that does not come back with a resident call pays for that speculation: use vba_iterate there).
+int vba_iterate_open(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in, double* states_out,
+                     double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags) {
+    if (int rc = vba_set_states(h, 0, states_in, lamda_in)) return rc;
+    if (can_pipeline(h)) return iterate_pipelined(h, iter, initialize, states_out, lamda_out, last_hessian, n_trials, flags);
+    const bool watch_changed = host_watch_changed(h);       // (like every resident call: the caller relies on it)
+    if (int rc = step_impl(h, iter, initialize, nullptr, false, 0)) return rc;
+    if (int rc = take_back(h, states_out, lamda_out, last_hessian, n_trials, flags)) return rc;
+    if (flags && watch_changed) *flags |= VBA_FLAG_HOST_CHANGED;
+    return VBA_OK;
+}
+
 // The driver loop `for iter in range(20): states, ... = BA(iter, states, ...)` (od_pipe.py:1036-1040) hands every call the
 // result of the one before, through the host.  Served call by call the device idles while the host unpacks one result and
 // enqueues the next call, and the host idles while the device works.  Here the two overlap: behind the call that is being
@@ -1540,6 +1577,57 @@ static bool host_watch_changed(vba_handle h) {
     for (const auto& w : h->watch)
         if (w.live && std::memcmp(w.live, w.copy, w.bytes) != 0) return true;
     return false;
+}
+// ... the same on the handle's helper thread: begin before the enqueues, end once the device has answered.  Small watch lists
+// (under 64 kB) are compared in place by watch_end: waking a thread costs more than that.
+static size_t host_watch_bytes(vba_handle h) {
+    size_t b = 0;
+    for (const auto& w : h->watch) if (w.live) b += w.bytes;
+    return b;
+}
+static bool watch_begin(vba_handle h) {
+    if (host_watch_bytes(h) < 65536) return false;
+    auto& W = h->ww;
+    if (!W.started) {
+        W.started = true;
+        W.th = std::thread([h]() {
+            auto& Q = h->ww;
+            for (;;) {
+                {
+                    std::unique_lock<std::mutex> lk(Q.m);
+                    Q.cv.wait(lk, [&] { return Q.request != 0; });
+                    if (Q.request < 0) return;
+                    Q.request = 0;
+                }
+                Q.changed = host_watch_changed(h);
+                Q.done.store(1, std::memory_order_release);
+            }
+        });
+    }
+    W.done.store(0, std::memory_order_relaxed);
+    {
+        std::lock_guard<std::mutex> lk(W.m);
+        W.request = 1;
+    }
+    W.cv.notify_one();
+    return true;
+}
+static bool watch_end(vba_handle h, bool begun) {
+    if (!begun) return host_watch_changed(h);
+    auto& W = h->ww;
+    while (W.done.load(std::memory_order_acquire) == 0) __builtin_ia32_pause();
+    return W.changed;
+}
+static void watch_stop(vba_handle h) {
+    auto& W = h->ww;
+    if (!W.started) return;
+    {
+        std::lock_guard<std::mutex> lk(W.m);
+        W.request = -1;
+    }
+    W.cv.notify_one();
+    W.th.join();
+    W.started = false;
 }
 
 static bool can_pipeline(vba_handle h) {
@@ -1614,6 +1702,12 @@ static int iterate_pipelined(vba_handle h, int iter, int initialize, double* sta
     const bool speculate = ni >= 0;
     const CallSpec qc = call_spec(c, iter, initialize, emit_kind, false);       // (this call, as the stalled path needs it)
     const int par_c = qc.par;
+    const bool watching = watch_begin(h);
+    struct WatchJoin {          // (an early return must not leave the helper comparing buffers the caller may free)
+        vba_handle h; bool begun; bool joined = false;
+        bool end() { joined = true; return watch_end(h, begun); }
+        ~WatchJoin() { if (begun && !joined) (void)watch_end(h, true); }
+    } wj{h, watching};
     if (speculate) {
         const CallSpec qn = call_spec(c + 1, ni, nin, emit_kind, true);
         CallCtx C;
@@ -1625,15 +1719,15 @@ static int iterate_pipelined(vba_handle h, int iter, int initialize, double* sta
         // the first kernel of the speculated call has decided this one; the trial states and the outcome are in mapped host
         // memory by then (k_trial, fold_commit): no copy, the rest of the speculated call runs on under the caller's feet
         HIPCHK(hipGetLastError());
-        watch_changed = host_watch_changed(h);      // (while the device works)
         HIPCHK(hipEventSynchronize(h->ev_first));
+        watch_changed = wj.end();       // (compared while the device worked)
     } else {                    // nothing resident is expected behind this call: decide it with a launch of its own
         CallCtx C;
         view_for_call(h, C.V, qc);
         launch_decide(C.V, nullptr, 0, s);
         HIPCHK(hipGetLastError());
-        watch_changed = host_watch_changed(h);
         HIPCHK(hipStreamSynchronize(s));
+        watch_changed = wj.end();
     }
     h->stepped = true;
     h->last_pipelined = true;

@@ -201,15 +201,16 @@ class BAEngine:
         _lib.check(self.lib.vba_run_schedule(self.h, n, a, b, byref(t)), self.lib)
         return t.value
 
-    def iterate(self, it, initialize, lamda, states):
-        """One ``BA()`` call on window 0: returns (states_new, lamda_out, last_hessian, n_trials, flags)."""
+    def iterate(self, it, initialize, lamda, states, opening=False):
+        """One ``BA()`` call on window 0: returns (states_new, lamda_out, last_hessian, n_trials, flags).  ``opening``: the
+        first call of a driver loop whose following calls will be :meth:`iterate_resident` (``vba_iterate_open``)."""
         s = _f64(states).reshape(-1, 10)
         out = np.empty_like(s)
         lam = c_double()
         hess = np.empty((9, 9))
         nt, fl = c_int(), c_uint()
-        _lib.check(self.lib.vba_iterate(self.h, int(it), int(bool(initialize)), float(lamda), _p(s), _p(out), byref(lam),
-                                        _p(hess), byref(nt), byref(fl)), self.lib)
+        f = self.lib.vba_iterate_open if opening else self.lib.vba_iterate
+        _lib.check(f(self.h, int(it), int(bool(initialize)), float(lamda), _p(s), _p(out), byref(lam), _p(hess), byref(nt), byref(fl)), self.lib)
         return out, lam.value, hess, nt.value, fl.value
 
     def iterate_resident(self, it, initialize):
