@@ -45,9 +45,15 @@ No CPU fallback exists.
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 
 from .engine import BAEngine
+
+_memcmp = ctypes.CDLL(None).memcmp
+_memcmp.argtypes = (ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+_memcmp.restype = ctypes.c_int
 
 _cache = {}
 _WATCH_SLOTS = 8         # vba_set_host_watch: one per array argument of BA()
@@ -88,10 +94,21 @@ def _same_objects(args):
     return True
 
 
+def _same_bytes(a, c):
+    """Equal content of two ndarrays of equal shape and dtype; contiguous ones by one ``memcmp`` (``np.array_equal`` builds a
+    boolean array first: ~5 x the time at 400 kB)."""
+    if a.flags.c_contiguous and c.flags.c_contiguous and a.dtype.kind in "iuf":
+        if a.dtype.kind != "f":
+            return _memcmp(a.ctypes.data, c.ctypes.data, a.nbytes) == 0
+        # (floats: equal bytes are equal values; different bytes may still be equal values, -0.0 == 0.0 -- only then look closer)
+        return _memcmp(a.ctypes.data, c.ctypes.data, a.nbytes) == 0 or np.array_equal(a, c)
+    return np.array_equal(a, c)
+
+
 def _numpy_unchanged(args):
     """True if every ndarray among ``args`` still holds the bytes of the private copy taken when it was uploaded."""
     for a, c in zip(args, _cache.get("np_copies", ())):
-        if c is not None and not (a.shape == c.shape and a.dtype == c.dtype and np.array_equal(a, c)):
+        if c is not None and not (a.shape == c.shape and a.dtype == c.dtype and _same_bytes(a, c)):
             return False
     return True
 
@@ -162,6 +179,7 @@ def invalidate():
     _cache.pop("np_copies", None)
     _cache.pop("all_watched", None)
     _cache.pop("bkey", None)
+    _cache.pop("bleaves", None)
     _cache.pop("brefs", None)
     _cache.pop("bcopies", None)
     _cache.pop("bform", None)
@@ -371,15 +389,22 @@ def _batch_hit(args, device):
     if eng is None or eng.device != device or "bkey" not in _cache:
         return None
     leaves = _leaves(args)
-    if _cache["bkey"] != tuple(_token(a) for a in leaves):
+    # the cheap test first (what every call of a driver loop passes): the very same leaf objects as at the upload, torch tensors
+    # with an unchanged in-place counter -- 154 leaves at 22 windows, whose tokens cost ~0.25 ms to build
+    old = _cache.get("bleaves")
+    same = old is not None and len(old[0]) == len(leaves) and all(a is b for a, b in zip(leaves, old[0])) \
+        and tuple(getattr(a, "_version", None) for a in leaves) == old[1]
+    if not same and _cache["bkey"] != tuple(_token(a) for a in leaves):
         return None
     seen = set()
     for a, c in zip(leaves, _cache.get("bcopies", ())):
         if c is None or id(a) in seen:
             continue
         seen.add(id(a))
-        if not (a.shape == c.shape and a.dtype == c.dtype and np.array_equal(a, c)):
+        if not (a.shape == c.shape and a.dtype == c.dtype and _same_bytes(a, c)):
             return None
+    if not same:        # (fresh objects over the same buffers: remember them for the next call)
+        _cache["bleaves"] = (leaves, tuple(getattr(a, "_version", None) for a in leaves))
     return eng
 
 
@@ -408,6 +433,7 @@ def _batch_engine_for(args, wins, device):
         else:
             copies.append(None)
     _cache["bcopies"] = tuple(copies)
+    _cache["bleaves"] = (leaves, tuple(getattr(a, "_version", None) for a in leaves))
     _cache["brefs"] = args              # keeps the buffers alive: their addresses cannot be reused while cached
     return eng
 
