@@ -669,7 +669,7 @@ def run_rank(args):
         batched_sweep = {"unit": "BA iterations/s", "workload": "W independent C3 windows on one handle, chained 20-call schedule",
                          "points": pts, "monotone": all(b >= 0.97 * a for a, b in zip(vals, vals[1:])),
                          "note": "kernel set and solver are the handle's own choice (vba_create_mode -1): latency-mode kernels up to "
-                                 "31 (50000 / rows)^0.7 windows, partitioned solve up to 1023 windows, see DESIGN.md section 3"}
+                                 "38 (50000 / rows)^0.7 windows (exponent 0.46 beyond 50000 rows), partitioned solve up to 1023 windows, see DESIGN.md section 3"}
         # the same batch behind the reference's call surface: BA_window on lists of 22 windows (the reference's 22 sequences,
         # od_pipe.py:1069-1077), arguments as the driver holds them
         from vinsat_amd import ba as ba_mod

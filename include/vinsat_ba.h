@@ -84,8 +84,9 @@ int vba_create(int device, int windows, int n_max, int64_t m_max, vba_handle* ou
  *           chunk elimination forms its own blocks, the trial kernel forms the step), 64 lanes per pose -- what a handle
  *           whose windows cannot fill the chip by themselves wants;
  *   mode 0  bandwidth mode: streaming kernels with few registers and many windows per launch;
- *   mode -1 (what vba_create passes) chooses by window count and window size -- latency mode up to 31 (50 000 / m_max)^0.7 windows,
- *           the crossover of the measured sweeps over W = 1 .. 4096 windows of 5 000 / 50 000 / 200 000 rows (bench.py
+ *   mode -1 (what vba_create passes) chooses by window count and window size -- latency mode up to 38 (50 000 / m_max)^0.7 windows
+ *           (exponent 0.46 for windows of more than 50 000 rows; at most 192),
+ *           the crossover of the measured sweeps over W = 1 .. 4096 windows of 5 000 / 20 000 / 50 000 / 200 000 rows (bench.py
  *           "batched_sweep").
  * Both modes give the same results to rounding (and the same bits for equal lanes per pose / solver settings). */
 int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode, vba_handle* out);

@@ -296,8 +296,9 @@ int vba_device_count(int* count) {
 // and C2 windows (100 poses / 5 000 rows): latency 107 / 379 / 606 / 943 / 1230 / 1446 / 1541 at W = 4 / 16 / 32 / 64 / 128 / 256 /
 // 512 against bandwidth 51 / 199 / 360 / 662 / 1145 / 1649 / 1931; walk against partitioned solve 954 : 1649 at 256 windows,
 // 2183 : 2071 at 1024, 3227 : 2259 at 4096.
-// * Kernel set: what fills the chip is rows AND windows -- the latency-mode kernels win up to 31 C3 windows, ~180 C2 windows, ~13
-//   C4 windows (default_latency_mode below; until round 4 the switch was at 16 windows whatever their size).
+// * Kernel set: what fills the chip is rows AND windows -- the latency-mode kernels won up to 31 C3 windows, ~180 C2 windows, ~13
+//   C4 windows in that sweep (38 / ~190 / ~20 with the latency set as it is now, see default_latency_mode below; until round 4 the
+//   switch was at 16 windows whatever their size).
 // * Solver: the sequential walk is a latency chain per window (~2.2 ms at 500 poses whatever the window count) and pays only
 //   once ~1000 windows share it; below that the chains are cut into chunks (until round 4 the walk took over at 128 windows:
 //   3.3 ms per step at 256 windows where the partitioned solve needs 0.75).
@@ -310,8 +311,13 @@ constexpr int kPartitionedWindowsMax = 1023;
 // The crossover measured at three window sizes -- ~180 windows of 5 000 rows, 31 of 50 000, ~13 of 200 000 (C4: latency 55.1 / 64.0 /
 // 65.7 k it/s at W = 8 / 12 / 16 against bandwidth 50.0 / 62.9 / 73.7) -- lies on W* = 31 (50 000 / m)^0.7: between "by windows"
 // (exponent 0) and "by rows" (exponent 1), because both the per-window prologues and the rows fill the chip.
+// Re-measured at the end of round 4, after the tiled trial kernel and the chunk rules had made the latency set 4 .. 20 % faster
+// (k it/s, latency : bandwidth): C3 212 : 205 at 32 windows, 216 : 213 at 36, 223 : 226 at 40; C4 80.3 : 73.3 at 16, 79.7 : 80.0 at
+// 20; 200 poses / 20 000 rows 502 : 480 at 64, 544 : 594 at 96; C2 1389 : 1251 at 160, 1399 : 1403 at 192 -- W* = 38 (50 000 / m)^0.7
+// for windows up to C3's size, 38 (50 000 / m)^0.46 beyond.
 static bool default_latency_mode(int windows, int64_t m_max) {
-    return windows == 1 || (windows <= kLatWindowsCap && (double)windows <= 31.0 * std::pow(50000.0 / (double)m_max, 0.7));
+    const double x = m_max <= 50000 ? 0.7 : 0.46;
+    return windows == 1 || (windows <= kLatWindowsCap && (double)windows <= 38.0 * std::pow(50000.0 / (double)m_max, x));
 }
 static int default_fusion(bool lat, int windows, int n_max, int64_t m_max) {
     const double rows = (double)windows * (double)m_max;
