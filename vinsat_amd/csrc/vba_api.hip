@@ -1,6 +1,7 @@
 // vba_api.hip -- C ABI of libvinsat_ba.so (see include/vinsat_ba.h): context, uploads, one BA() step.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <mutex>
@@ -153,8 +154,9 @@ struct vba_context {
         std::thread th;
         std::mutex m;
         std::condition_variable cv;
-        int request = 0;                    // guarded by m: 0 idle, 1 compare, -1 quit
-        std::atomic<int> done{0};           // 1: `changed` is valid
+        unsigned long long seq = 0;         // guarded by m: number of the last request
+        bool quit = false;                  // guarded by m
+        std::atomic<unsigned long long> done_seq{0};    // the request `changed` answers
         bool changed = false;
         bool started = false;
     } ww;
@@ -1598,22 +1600,22 @@ static bool watch_begin(vba_handle h) {
         W.started = true;
         W.th = std::thread([h]() {
             auto& Q = h->ww;
+            unsigned long long taken = 0;
             for (;;) {
                 {
                     std::unique_lock<std::mutex> lk(Q.m);
-                    Q.cv.wait(lk, [&] { return Q.request != 0; });
-                    if (Q.request < 0) return;
-                    Q.request = 0;
+                    Q.cv.wait(lk, [&] { return Q.quit || Q.seq != taken; });
+                    if (Q.quit) return;
+                    taken = Q.seq;
                 }
                 Q.changed = host_watch_changed(h);
-                Q.done.store(1, std::memory_order_release);
+                Q.done_seq.store(taken, std::memory_order_release);
             }
         });
     }
-    W.done.store(0, std::memory_order_relaxed);
     {
         std::lock_guard<std::mutex> lk(W.m);
-        W.request = 1;
+        ++W.seq;
     }
     W.cv.notify_one();
     return true;
@@ -1621,7 +1623,14 @@ static bool watch_begin(vba_handle h) {
 static bool watch_end(vba_handle h, bool begun) {
     if (!begun) return host_watch_changed(h);
     auto& W = h->ww;
-    while (W.done.load(std::memory_order_acquire) == 0) __builtin_ia32_pause();
+    // (bounded: a helper that does not answer within 20 ms -- a forked child has none, a starved host may park it -- is not waited
+    // for; the comparison is then made here, beside it if it still runs: both only read)
+    const auto t0 = std::chrono::steady_clock::now();
+    const unsigned long long mine = W.seq;      // (written by this thread only)
+    for (unsigned spins = 0; W.done_seq.load(std::memory_order_acquire) != mine; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return host_watch_changed(h);
+    }
     return W.changed;
 }
 static void watch_stop(vba_handle h) {
@@ -1629,7 +1638,7 @@ static void watch_stop(vba_handle h) {
     if (!W.started) return;
     {
         std::lock_guard<std::mutex> lk(W.m);
-        W.request = -1;
+        W.quit = true;
     }
     W.cv.notify_one();
     W.th.join();
