@@ -450,9 +450,9 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # initialisation, not measurement: one full schedule, so that every kernel of both phases has been loaded and launched
-    # once before the W warm-up steps (which, for small W, would only ever reach the landmark-only phase)
-    run_steps(eng, st0, 20)
+    # initialisation, not measurement: five full schedules (~5 ms), so that every kernel of both phases has been loaded and
+    # launched and the clocks are up before the W warm-up steps (which, for small W, would only ever reach the landmark-only phase)
+    run_steps(eng, st0, 100)
     run_steps(eng, st0, args.warmup)
     barrier()
     t0 = time.perf_counter()
