@@ -270,6 +270,7 @@ int ready(vba_handle h) {
 extern "C" {
 
 static void watch_stop(vba_handle h);
+static void watch_quiesce(vba_handle h);
 int vba_set_accumulate_lanes(vba_handle h, int lanes);
 int vba_set_trial_tiles(vba_handle h, int tiles);
 int vba_set_solver(vba_handle h, int chunk);
@@ -735,6 +736,7 @@ int vba_set_bucket_cap(vba_handle h, int cap) {
 int vba_set_host_watch(vba_handle h, int slot, const void* live, const void* copy, int64_t bytes) {
     if (!h || slot < 0 || slot >= 8) return fail(VBA_EINVAL, "bad argument (8 watch slots)");
     if (live && (!copy || bytes < 1)) return fail(VBA_EINVAL, "a watched buffer needs its reference copy and a size");
+    watch_quiesce(h);
     h->watch[slot].live = live;
     h->watch[slot].copy = live ? copy : nullptr;
     h->watch[slot].bytes = live ? (size_t)bytes : 0;
@@ -1632,6 +1634,12 @@ static bool watch_end(vba_handle h, bool begun) {
         if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return host_watch_changed(h);
     }
     return W.changed;
+}
+// the helper has answered every request (a wait that gave up after 20 ms may have left it comparing): before the watch list changes
+static void watch_quiesce(vba_handle h) {
+    auto& W = h->ww;
+    if (!W.started) return;
+    while (W.done_seq.load(std::memory_order_acquire) != W.seq) std::this_thread::yield();
 }
 static void watch_stop(vba_handle h) {
     auto& W = h->ww;
