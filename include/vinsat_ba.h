@@ -316,6 +316,15 @@ enum { VBA_K_BEGIN = 0, VBA_K_RESIDUAL, VBA_K_SELECT, VBA_K_ACCUMULATE, VBA_K_DY
        VBA_K_TRIAL, VBA_K_DECIDE, VBA_NKERNELS };
 int vba_step_profiled(vba_handle h, int iter, int initialize, float* ms);
 
+/* vba_run_schedule on a latency-mode handle captures the launches of its first pass (~70 dependent kernels for the driver's 20 calls)
+ * as a hipGraph and replays it while nothing that goes into those launches has changed (the per-call kernel arguments are compared by
+ * hash, the schedule and the host-side switches by value): 45.2 -> 42.6 us per call at C3.  Same kernels, same arguments, same bits;
+ * calls that stall (rejected trial, missed select) are finished by the host afterwards as without a graph.  Default on; off = kernel by
+ * kernel (comparison, debugging; also the environment variable VBA_NO_GRAPH).  A capture or launch that fails once switches it off for
+ * the handle.  vba_schedule_graph_stats: graphs captured / replays so far. */
+int vba_set_schedule_graph(vba_handle h, int on);
+int vba_schedule_graph_stats(vba_handle h, int* captures, int* replays);
+
 /* Class times of the CHAINED schedule (what vba_run_schedule really runs, as opposed to vba_step_profiled's serialised one).
  * on != 0: every vba_run_schedule records HIP events on the handle's stream at three boundaries of each call -- in front of
  * the call's first kernel, behind its accumulation (+ assembly, where that is a launch), behind its solve kernels, behind its

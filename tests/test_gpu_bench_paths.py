@@ -176,6 +176,53 @@ def test_first_windows_of_a_large_handle_keep_what_was_uploaded_right_after_crea
     _close_to_reference(out[4096], g["states_out_19"][0], 19)
 
 
+def test_chained_schedule_replayed_as_a_graph_gives_the_bits_of_kernel_by_kernel_launches():
+    """vba_run_schedule captures the launches of a latency-mode handle's first pass as a hipGraph and replays it while nothing that
+    goes into them has changed (vba_set_schedule_graph).  Same kernels, same arguments: every window of every schedule must end
+    on the bits of a handle that launches kernel by kernel -- on the replay, after a setting that changes kernel arguments (the
+    graph is captured again), after another window was uploaded (only device data changed: the graph stays), with a window that
+    rejects trials (the host finishes its calls behind the replay) and after the schedule itself changed."""
+    from vinsat_amd import od_pipe
+    g, win = load_golden("c3"), _window("c3")
+    iters, inits = [int(x) for x in g["iters"]], [bool(x) for x in g["initialize"]]
+    n = win.time_idx.size
+    conf3 = np.full_like(win.confidences, 3.0)
+    st_other = od_pipe.initial_guess(win, seed=7)
+
+    def run(graph):
+        eng = _engine(win, windows=3, mode=1)
+        eng.set_schedule_graph(graph)
+        eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, conf3, win.ii, n, window=1)
+        out = []
+
+        def schedule(its, ins):
+            for w in range(3):
+                eng.set_states(st_other if w == 2 else g["states0"][0], 1e-4, window=w)
+            eng.run_schedule(its, ins)
+            out.append([eng.get_states(window=w) for w in range(3)])
+        schedule(iters, inits)                  # captured
+        schedule(iters, inits)                  # replayed
+        eng.set_trial_tiles(1)                  # other kernel arguments (and another kernel): captured again
+        eng.set_fusion(14)
+        schedule(iters, inits)
+        schedule(iters, inits)
+        eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n, window=1)     # device data only
+        schedule(iters, inits)
+        schedule(iters[:12], inits[:12])        # another schedule
+        schedule(iters[:12], inits[:12])
+        stats = eng.schedule_graph_stats()
+        eng.close()
+        return out, stats
+    ref, stats0 = run(False)
+    got, stats1 = run(True)
+    assert stats0 == (0, 0) and stats1[0] == 3 and stats1[1] == 4, (stats0, stats1)
+    assert max(x[1][3] for x in ref[:4]) >= 3                                     # window 1 did reject trials
+    for k, (a, b) in enumerate(zip(ref, got)):
+        for w in range(3):
+            assert np.array_equal(a[w][0], b[w][0]) and a[w][1] == b[w][1] and np.array_equal(a[w][2], b[w][2]) and a[w][3:] == b[w][3:], (k, w)
+    _close_to_reference(got[4][0][0], g["states_out_19"][0], 19)
+
+
 @pytest.mark.parametrize("fusion", [14, 12])
 def test_trial_kernel_tiles_per_block_do_not_change_a_bit(fusion):
     """vba_set_trial_tiles: an observation block of the plain latency-mode trial kernel takes 1, 2, 4 or 8 tiles of 256 rows and

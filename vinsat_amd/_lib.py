@@ -44,6 +44,8 @@ SIGNATURES = {
     "vba_set_pivoting": (c_int, [c_void_p, c_int]),
     "vba_set_accumulate_lanes": (c_int, [c_void_p, c_int]),
     "vba_set_trial_tiles": (c_int, [c_void_p, c_int]),
+    "vba_set_schedule_graph": (c_int, [c_void_p, c_int]),
+    "vba_schedule_graph_stats": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "vba_set_integrator": (c_int, [c_void_p, c_int]),
     "vba_solver_fallbacks": (c_int, [c_void_p, POINTER(c_int)]),
     "vba_upload_observations": (c_int, [c_void_p, c_int, c_int, c_int64, PD, PD, PD, PI64]),

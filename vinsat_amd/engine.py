@@ -78,6 +78,16 @@ class BAEngine:
         """Tiles of 256 rows per observation block of the latency-mode trial kernel (0 = automatic); results do not depend on it."""
         _lib.check(self.lib.vba_set_trial_tiles(self.h, int(tiles)), self.lib)
 
+    def set_schedule_graph(self, on):
+        """Replay of a chained schedule's launches as a hipGraph (latency-mode handles; default on).  Same bits either way."""
+        _lib.check(self.lib.vba_set_schedule_graph(self.h, int(bool(on))), self.lib)
+
+    def schedule_graph_stats(self):
+        """(graphs captured, replays) of :meth:`run_schedule` so far."""
+        a, b = c_int(), c_int()
+        _lib.check(self.lib.vba_schedule_graph_stats(self.h, byref(a), byref(b)), self.lib)
+        return a.value, b.value
+
     def set_key_carry(self, on):
         """True (default): an accepted trial leaves the next call's |r| keys behind; False: every call recomputes them."""
         _lib.check(self.lib.vba_set_key_carry(self.h, int(bool(on))), self.lib)
