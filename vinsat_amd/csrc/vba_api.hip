@@ -133,8 +133,10 @@ struct vba_context {
     int cr_levels = 2;                      // cyclic-reduction levels in front of the one-workgroup kernel (VBA_CR_LEVELS / vba_set_cr_levels: 2 or 3)
     int fusion = 15;                        // vba_set_fusion (default: the trial kernel forms the step, the solves form their own blocks, uniform-pass assembly)
     bool fusion_auto = true;                // the mask is the library's own choice (vba_set_fusion not called)
-    hipGraphExec_t gexec = nullptr;         // the first pass of the last chained schedule as a graph (vba_run_schedule), and what it was made for
-    std::vector<unsigned long long> gkey;
+    // the first passes of the last few chained schedules as graphs (vba_run_schedule), each with what it was made for; most recently
+    // used first, at most kGraphCache of them (a driver alternates between a handful of schedules: the 20-call loop, its two phases)
+    struct GraphEntry { std::vector<unsigned long long> key; hipGraphExec_t exec = nullptr; };
+    std::vector<GraphEntry> graphs;
     bool graph_broken = false;              // capture or launch failed once: kernel by kernel from then on
     bool graph_enabled = true;              // vba_set_schedule_graph
     long graph_replays = 0, graph_captures = 0;
@@ -550,7 +552,7 @@ int vba_destroy(vba_handle h) {
     if (h->own_stream) { hipStreamSynchronize(h->own_stream); hipStreamDestroy(h->own_stream); }
     if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); }
     for (hipEvent_t e : h->cprof.ev) if (e) hipEventDestroy(e);
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    for (auto& ge : h->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
     if (h->ev_first) hipEventDestroy(h->ev_first);
     if (h->h_states_map) hipHostFree(h->h_states_map);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -1471,11 +1473,14 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
                 }
                 gkey.push_back(hsh); gkey.push_back((unsigned long long)iters[c]); gkey.push_back((unsigned long long)inits[c]);
             }
-            if (h->gexec && h->gkey == gkey) {
-                if (hipGraphLaunch(h->gexec, s) == hipSuccess) { replayed = true; h->graph_replays++; }
+            size_t hit = h->graphs.size();
+            for (size_t k = 0; k < h->graphs.size(); ++k)
+                if (h->graphs[k].key == gkey) { hit = k; break; }
+            if (hit < h->graphs.size()) {
+                if (hit != 0) std::rotate(h->graphs.begin(), h->graphs.begin() + hit, h->graphs.begin() + hit + 1);     // most recently used first
+                if (hipGraphLaunch(h->graphs[0].exec, s) == hipSuccess) { replayed = true; h->graph_replays++; }
                 else { (void)hipGetLastError(); h->graph_broken = true; }
             } else {
-                if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
                 if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) capturing = true;
                 else { (void)hipGetLastError(); h->graph_broken = true; }
             }
@@ -1518,12 +1523,23 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             hipGraph_t g = nullptr;
             capturing = false;
             HIPCHK(hipStreamEndCapture(s, &g));
-            const hipError_t ei = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
-            if (ei != hipSuccess) { h->gexec = nullptr; (void)hipGraphDestroy(g); return fail(VBA_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+            hipGraphExec_t exec = nullptr;
+            const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
-            h->gkey = gkey;
+            if (ei != hipSuccess) return fail(VBA_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+            constexpr size_t kGraphCache = 8;
+            if (h->graphs.size() >= kGraphCache) {
+                // (the evicted graph may still be executing: the stream is idle here only if the caller made it so -- wait)
+                HIPCHK(hipStreamSynchronize(s));
+                (void)hipGraphExecDestroy(h->graphs.back().exec);
+                h->graphs.pop_back();
+            }
+            vba_context::GraphEntry ge;
+            ge.key = gkey;
+            ge.exec = exec;
+            h->graphs.insert(h->graphs.begin(), std::move(ge));
             h->graph_captures++;
-            HIPCHK(hipGraphLaunch(h->gexec, s));
+            HIPCHK(hipGraphLaunch(exec, s));
         }
         HIPCHK(hipGetLastError());
         if (int rc = read_heads(h)) return rc;
