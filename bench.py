@@ -537,7 +537,10 @@ def run_rank(args):
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
                 "avg_launch_ms": classes_ms[dom], "launches_timed": class_calls[dom],
-                "timing_source": "HIP events on the library's stream at the class boundaries of the chained schedule (vba_set_chain_profile)",
+                "timing_source": "HIP events on the library's stream at the class boundaries of the chained schedule (vba_set_chain_profile); "
+                                 "recorded on a pass that launches kernel by kernel with ~1 us of marker per boundary -- events cannot be recorded "
+                                 "inside the graph replay that `value` is timed on, whose kernels run ~0.5 us shorter each "
+                                 "(profiles/r04_w1_kernel_stats.csv: 14.7 + 7.9 + 14.5 us for the three kernels of the class)",
                 "whole_call": {"bytes": whole, "achieved": whole / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                                "frac": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "note": "SURVEY 8(d) B_alg = 208 m + 5000 n over the timed (chained) ms_per_step"},

@@ -1454,6 +1454,8 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
         std::vector<unsigned long long> gkey;
         // (latency-mode handles only: with the second stream of the bandwidth mode forked inside it the replay measured 1 .. 2.5 % SLOWER
         // than the launches one by one, 40 .. 1024 windows)
+        // (... and not while the chain profile records its events: event records inside a capture fail on this runtime, "invalid resource
+        // handle" -- the class times of vba_chain_profile are those of the kernel-by-kernel launches)
         if (!no_graph && h->graph_enabled && guard == 0 && !prof_pass && h->V.lat && !h->graph_broken && next == 0) {
             gkey.reserve(8 + 3 * (size_t)ncalls);
             gkey.push_back((unsigned long long)ncalls); gkey.push_back((unsigned long long)par0); gkey.push_back((unsigned long long)carry0);
