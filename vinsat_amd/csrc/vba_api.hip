@@ -62,6 +62,8 @@ struct vba_context {
     DevView V{};
     // mutable device pointers (DevView holds const views of some)
     int *d_n = nullptr, *d_m = nullptr, *d_steps = nullptr;
+    int *d_long_idx = nullptr, *d_n_long = nullptr;     // long edges of every window (vba_long.hip)
+    std::vector<int> n_long;                // ... and how many each window has (host copy; DevView::nblk_long is their maximum)
     // per-observation weights and per-pose normal equations exist per call parity (DevView points at the slot of the call):
     // the accumulation of call c + 1 starts before the accept test of call c is known, whose later trials still read them
     double *wraw2 = nullptr, *Hraw2 = nullptr, *braw2 = nullptr;
@@ -364,7 +366,7 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     const int nblk_obs = (int)((M + kObsBlock - 1) / kObsBlock);
     const int nblk_dyn = (int)((N + kObsBlock - 1) / kObsBlock);
     const int nblk_dyn16 = (int)((N - 1 + 14) / 15);      // pose-chain blocks of the 16-lanes-per-pose geometry (vba_set_fusion bit 0)
-    const int trial_stride = nblk_obs + std::max(nblk_dyn, nblk_dyn16);
+    const int trial_stride = nblk_obs + std::max(nblk_dyn, nblk_dyn16) + kLongCap;     // (+ the slots of the long edges, vba_long.hip)
     size_t bytes = 0;
     auto need = [&](size_t b) { bytes += ((b + 255) & ~size_t(255)) + 256; };
     need(W * 4); need(W * 4); need(W * sizeof(WinScalars));
@@ -374,7 +376,9 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     need(W * N * 10 * 8); need(W * N * 10 * 8);
     need(W * N * 4 * 8); need(W * N * 4 * 8); need(W * N * 4);
     const int nblk_pred = (int)((N * kDynLanes + 255) / 256);
-    need(W * 2 * nblk_pred * 8); need(W * 2 * nblk_pred * 8); need(W * 81 * 8);
+    const int pred_stride = nblk_pred + kLongCap;
+    need(W * 2 * pred_stride * 8); need(W * 2 * pred_stride * 8); need(W * 81 * 8);
+    need(W * kLongCap * 4); need(W * 4);
     need(W * N * 36 * 8); need(W * N * 6 * 8);
     need(W * 2 * M * 8); need(2 * W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * trial_stride * 8); need(W * nblk_obs * 8);
     need(W * kHistStride * 4);
@@ -425,7 +429,10 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     V.pose_ptr = V.opose + m_pad;
     h->S[0] = A.take<double>(W * N * 10); h->S[1] = A.take<double>(W * N * 10);
     V.states = V.states_prev = h->S[0]; V.states_new = h->S[1];
-    V.part_pred = A.take<double>(W * 2 * nblk_pred); V.part_prior = A.take<double>(W * 2 * nblk_pred); V.nblk_pred = nblk_pred;
+    V.part_pred = A.take<double>(W * 2 * pred_stride); V.part_prior = A.take<double>(W * 2 * pred_stride); V.nblk_pred = nblk_pred;
+    V.pred_stride = pred_stride;
+    V.long_idx = h->d_long_idx = A.take<int>(W * kLongCap); V.n_long = h->d_n_long = A.take<int>(W);
+    V.nblk_long = 0;
     V.lastD = A.take<double>(W * 81);
     V.intr = h->d_intr = A.take<double>(W * N * 4);
     V.cumrot = h->d_cumrot = A.take<double>(W * N * 4);
@@ -472,7 +479,7 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     {   // every device array a kernel may touch must have been carved: a null here would fault on the GPU
         const void* must[] = {V.n, V.m, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
                               V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.prior_H, V.prior_x, V.absr, V.wraw, V.ckeys, V.part_init, V.part_next,
-                              V.part_pred, V.part_prior, V.lastD,
+                              V.part_pred, V.part_prior, V.lastD, V.long_idx, V.n_long,
                               V.part_trial, V.hist, V.Hraw, V.braw, V.xhat, V.Phi, V.rorb, V.fatt, V.qgrad, V.Hd, V.Hu, V.Hl,
                               V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx, V.csol2, V.cL2, V.cR2, V.rx2, V.res_flags};
         bool ok = A.used <= A.size;
@@ -500,8 +507,8 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
         hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_up[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_up[1], hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_up[0], std::max(obs_stride, 9 * N + 32) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_up[1], std::max(obs_stride, 9 * N + 32) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_up[0], std::max(obs_stride, 9 * N + 96) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_up[1], std::max(obs_stride, 9 * N + 96) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_stage, ((size_t)n_max * 10 + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_back, (size_t)n_max * 10 * sizeof(double) + sizeof(WinScalars), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_head, W * sizeof(WinHead), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -510,7 +517,7 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
         return fail(VBA_EHIP, "stream/event/pinned allocation failed");
     }
     h->stream = h->own_stream;
-    h->n.assign(W, 0); h->m.assign(W, 0);
+    h->n.assign(W, 0); h->m.assign(W, 0); h->n_long.assign(W, 0);
     h->have_obs.assign(W, 0); h->have_win.assign(W, 0); h->have_state.assign(W, 0); h->have_prior.assign(W, 0);
     h->perm.resize(W);
     vba_set_accumulate_lanes(h, 0);
@@ -649,6 +656,7 @@ int vba_set_integrator(vba_handle h, int hop100) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     h->V.hop = hop100 ? 1 : 0;
+    h->V.nblk_long = h->V.hop ? 0 : *std::max_element(h->n_long.begin(), h->n_long.end());
     return VBA_OK;
 }
 
@@ -862,6 +870,14 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
         steps[i] = (int)d;
     }
     steps[n - 1] = 1;   // BA_utils.py:75
+    // long gaps (vba_long.hip): the first kLongCap edges of more than kLongGap steps are marked by a NEGATIVE step count and
+    // listed; the kernels that walk the chain leave them to k_long_factor / k_long_trial (with the hop integrator the sign is
+    // ignored and nothing is long)
+    int long_list[kLongCap + 1];
+    int nl = 0;
+    for (int i = 0; i + 1 < n && nl < kLongCap; ++i)
+        if (steps[i] > kLongGap) { long_list[nl++] = i; steps[i] = -steps[i]; }
+    long_list[kLongCap] = nl;
     const size_t pb = (size_t)window * h->n_max;
     const int ub = h->up_next;
     h->up_next ^= 1;
@@ -870,10 +886,16 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
     std::memcpy(blk, intrinsics, (size_t)n * 32);
     std::memcpy(blk + (size_t)n * 4, cumrot_last, (size_t)n * 32);
     std::memcpy(blk + (size_t)n * 8, steps.data(), (size_t)n * 4);
+    double* lblk = blk + (size_t)n * 8 + (size_t)(n + 1) / 2;      // (the staging block holds max(obs_stride, 9 n_max + 96) doubles)
+    std::memcpy(lblk, long_list, sizeof(long_list));
     HIPCHK(hipMemcpyAsync(h->d_intr + pb * 4, blk, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_cumrot + pb * 4, blk + (size_t)n * 4, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_steps + pb, blk + (size_t)n * 8, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    if (nl) HIPCHK(hipMemcpyAsync(h->d_long_idx + (size_t)window * kLongCap, lblk, (size_t)nl * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_n_long + window, reinterpret_cast<const int*>(lblk) + kLongCap, 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipEventRecord(h->ev_up[ub], h->stream));
+    h->n_long[window] = nl;
+    h->V.nblk_long = h->V.hop ? 0 : *std::max_element(h->n_long.begin(), h->n_long.end());     // (the <= 100 s hops of predict_gpu: no gap is long)
     launch_set_counts(h->V, window, n, -1, h->stream);
     HIPCHK(hipGetLastError());
     h->n[window] = n;

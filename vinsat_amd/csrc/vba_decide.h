@@ -42,16 +42,17 @@ __device__ __forceinline__ DecideIn decide_load(const DevView& V, int w, int pc,
     DecideIn in;
     in.s_pred = in.s_trial = in.s_next = in.s_prior = 0.0;
     if (!prm.initialize) {
-        const double* pp = V.part_pred + ((size_t)w * 2 + pc) * V.nblk_pred;
-        for (int b = t; b < V.nblk_pred; b += 256) in.s_pred += pp[b];
+        const double* pp = V.part_pred + ((size_t)w * 2 + pc) * V.pred_stride;
+        for (int b = t; b < V.nblk_pred + V.nblk_long; b += 256) in.s_pred += pp[b];    // (the long edges' slots behind the blocks')
         if (reg) {
-            const double* pq = V.part_prior + ((size_t)w * 2 + pc) * V.nblk_pred;
+            const double* pq = V.part_prior + ((size_t)w * 2 + pc) * V.pred_stride;
             for (int b = t; b < V.nblk_pred; b += 256) in.s_prior += pq[b];
         }
     }
     if (ranks == 0) {
         const double* pt = V.part_trial + (size_t)w * V.trial_stride;
-        for (int b = t; b < V.nblk_obs + V.nblk_dyn; b += 256) in.s_trial += pt[b];
+        // (the long edges' slots behind the blocks': written by k_long_trial, which has nothing to do in a landmark-only call)
+        for (int b = t; b < V.nblk_obs + V.nblk_dyn + (prm.initialize ? 0 : V.nblk_long); b += 256) in.s_trial += pt[b];
     }
     if (V.emit) {
         const double* pn = V.part_next + (size_t)w * V.nblk_obs;

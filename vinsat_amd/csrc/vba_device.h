@@ -14,6 +14,11 @@ constexpr int kSelItems = 8;            // keys per thread per radix-select pass
 constexpr int kSelPasses = 6;           // 63 key bits = 10 + 11 + 11 + 11 + 11 + 9
 constexpr int kSelBins = 2048;
 constexpr int kDynLanes = 8;            // lanes per pose in the dynamics kernel (6 tangents + attitude + spare)
+// Long gaps of the pose chain (vba_long.hip).  An edge of more than kLongGap one-second RK4 steps is propagated PARALLEL IN TIME
+// by a workgroup of its own (at most kLongCap such edges per window; further ones take the ordinary serial walk).  The kernels
+// that walk the chain leave such an edge alone; the block sums of its residuals go into slots of their own behind the ordinary ones.
+constexpr int kLongGap = 64;
+constexpr int kLongCap = 64;
 constexpr int kHistStride = (kSelPasses + 1) * kSelBins;    // per window: digit 0 twice (call parity), digits 1..5
 constexpr int kWarmCount = 192;         // warm select: up to this many keys are ranked by counting, longer lists by radix digits
 
@@ -146,6 +151,10 @@ struct DevView {
     const double* intr;             // [4]
     const double* cumrot;           // [4]
     const int* steps;               // RK4 steps to the next pose (last = 1)
+    // long gaps (vba_long.hip): the poses i of this window whose edge i -> i + 1 spans more than kLongGap steps, in pose order
+    const int* long_idx;            // [W][kLongCap]
+    const int* n_long;              // [W]
+    int nblk_long;                  // largest n_long over the windows of the handle = extra blocks / slots per window; 0 with the hop integrator
     // BA_reg (BA_filtering.py:100-210): per-pose prior, active when reg != 0 and the call is not landmark-only
     const double* prior_H;          // [36] hessian_state_t
     const double* prior_x;          // [6]  prior position, velocity
@@ -156,11 +165,13 @@ struct DevView {
     double* ckeys;                  // [W][2 m_max]  keys surviving the first two select digits (usually a handful)
     int acc_lanes;                  // lanes per pose in k_obs_accumulate (4..64)
     double* part_init;              // [W][nblk_obs] block sums of |r_obs|
-    double* part_trial;             // [W][trial_stride]: nblk_obs observation blocks, then nblk_dyn pose-chain blocks
+    double* part_trial;             // [W][trial_stride]: nblk_obs observation blocks, then nblk_dyn pose-chain blocks, then nblk_long long edges
     double* part_next;              // [W][nblk_obs] block sums of |r_obs| at the trial states (carried keys)
-    double* part_pred;              // [W][2 (call parity)][nblk_pred] block sums of |r_pred| at the input states (dynamics factor, 32 poses per block)
-    double* part_prior;             // [W][2][nblk_pred] block sums of |r_prior| at the input states (BA_reg)
+    double* part_pred;              // [W][2 (call parity)][pred_stride] block sums of |r_pred| at the input states (dynamics factor, 32 poses per
+                                    // block: nblk_pred of them, then nblk_long slots of the long edges)
+    double* part_prior;             // [W][2][pred_stride] block sums of |r_prior| at the input states (BA_reg; the long slots stay unused)
     int nblk_pred;
+    int pred_stride;                // nblk_pred + kLongCap
     double* lastD;                  // [W][81] undamped diagonal block of the last pose (BA_filtering.py:97: last_hessian)
     // Carried keys: the trial residual of an accepted trial is evaluated at exactly the states the next call starts
     // from, so k_trial<true> (emit) also leaves that call's |r| keys, their exponent histogram and sum |r| behind and

@@ -45,13 +45,17 @@ __global__ __launch_bounds__(256) void k_dynamics_pair(DevView V) {
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int r = 0; r < 6; ++r) t[j][r] = (r == 3 * half + j) ? 1.0 : 0.0;
-            propagate_gap_multi<3>(x, t, V.steps[pb], V.hop);
+            const int steps = V.steps[pb];
+            const bool mine = steps > 0 || V.hop;      // (a long edge is k_long_factor's: transition matrix, prediction, residual, block sum)
+            if (mine) propagate_gap_multi<3>(x, t, abs(steps), V.hop);
             double* Phi = V.Phi + pb * 36;
+            if (mine) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+                for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int r = 0; r < 6; ++r) Phi[6 * r + 3 * half + j] = t[j][r];
-            if (half == 1) {
+                    for (int r = 0; r < 6; ++r) Phi[6 * r + 3 * half + j] = t[j][r];
+            }
+            if (half == 1 && mine) {
                 const double* sn = st + 10;
                 double* xh = V.xhat + pb * 6;
                 double* ro = V.rorb + pb * 6;
@@ -113,8 +117,8 @@ __global__ __launch_bounds__(256) void k_dynamics_pair(DevView V) {
             double tp = 0.0, tq = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { tp += vw[0][threadIdx.x * 4 + k]; tq += vw[1][threadIdx.x * 4 + k]; }
-            V.part_pred[((size_t)w * 2 + V.par) * V.nblk_pred + vb] = tp;
-            if (V.reg) V.part_prior[((size_t)w * 2 + V.par) * V.nblk_pred + vb] = tq;
+            V.part_pred[((size_t)w * 2 + V.par) * V.pred_stride + vb] = tp;
+            if (V.reg) V.part_prior[((size_t)w * 2 + V.par) * V.pred_stride + vb] = tq;
         }
     }
 }
@@ -302,10 +306,11 @@ __global__ __launch_bounds__(256) void k_assemble_rows(DevView V) {
 void launch_dynamics(const DevView& V, hipStream_t s) {
     if (!V.lat) {
         hipLaunchKernelGGL(k_dynamics_pair, dim3((V.n_max + 127) / 128, V.W), dim3(256), 0, s, V);
-        return;
+    } else {
+        const int nb = (V.n_max * kDynLanes + 255) / 256;
+        hipLaunchKernelGGL(k_dynamics, dim3(nb, V.W), dim3(256), 0, s, V);
     }
-    const int nb = (V.n_max * kDynLanes + 255) / 256;
-    hipLaunchKernelGGL(k_dynamics, dim3(nb, V.W), dim3(256), 0, s, V);
+    launch_long_factor(V, s);
 }
 
 void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s) {

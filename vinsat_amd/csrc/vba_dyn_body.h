@@ -26,12 +26,14 @@ __device__ __forceinline__ void dynamics_block(const DevView& V, int w, int bloc
     const double* st = V.states + pb * 10;
     double s_pred = 0.0, s_prior = 0.0;
     if (i < n && c < 6) {
-        if (i < n - 1) {            // the last pose's propagation is discarded by the reference (BA_utils.py:476)
+        const int steps = V.steps[pb];
+        // the last pose's propagation is discarded by the reference (BA_utils.py:476); a long edge (marked by a negative count) is
+        // k_long_factor's: transition matrix, prediction, residual and its block sum
+        if (i < n - 1 && (steps > 0 || V.hop)) {
             double x[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
             double t[6] = {0, 0, 0, 0, 0, 0};
             t[c] = 1.0;
-            const int steps = V.steps[pb];
-            propagate_gap<true>(x, t, steps, V.hop);
+            propagate_gap<true>(x, t, abs(steps), V.hop);
             double* Phi = V.Phi + pb * 36;
 #pragma unroll
             for (int r = 0; r < 6; ++r) Phi[6 * r + c] = t[r];
@@ -72,10 +74,10 @@ __device__ __forceinline__ void dynamics_block(const DevView& V, int w, int bloc
         s_prior = fabs(r6[0]) + fabs(r6[1]) + fabs(r6[2]) + fabs(r6[3]) + fabs(r6[4]) + fabs(r6[5]);
     }
     const double tp = block_sum<256>(s_pred, dred);
-    if (threadIdx.x == 0) V.part_pred[((size_t)w * 2 + V.par) * V.nblk_pred + block] = tp;
+    if (threadIdx.x == 0) V.part_pred[((size_t)w * 2 + V.par) * V.pred_stride + block] = tp;
     if (V.reg) {
         const double tq = block_sum<256>(s_prior, dred);
-        if (threadIdx.x == 0) V.part_prior[((size_t)w * 2 + V.par) * V.nblk_pred + block] = tq;
+        if (threadIdx.x == 0) V.part_prior[((size_t)w * 2 + V.par) * V.pred_stride + block] = tq;
     }
 }
 

@@ -26,6 +26,10 @@ void launch_sh_front(const DevView& V, const double* gathered, int ranks, int sl
 void launch_dynamics(const DevView& V, hipStream_t s);
 void launch_assemble(const DevView& V, int fuse_init_solve, hipStream_t s);
 
+// vba_long.hip (both: nothing to do, and nothing launched, for a handle without long edges)
+void launch_long_factor(const DevView& V, hipStream_t s);
+void launch_long_trial(const DevView& V, hipStream_t s);
+
 // vba_solve.hip
 void launch_solve(const DevView& V, int initialize, hipStream_t s);
 #ifdef VBA_RESIDENT_STAMPS

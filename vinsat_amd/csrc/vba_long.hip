@@ -1,0 +1,265 @@
+// vba_long.hip -- long gaps of the pose chain (A4 over hundreds of seconds), propagated PARALLEL IN TIME.
+//
+// The reference walks a gap of s seconds as s dependent RK4 steps of 1 s (propagate_orbit_dynamics, BA_utils.py:73-87) and
+// differentiates that chain (predict, :457-509).  A window of a later pass of a sequence holds gaps of up to 1000 s
+// (read_detections inserts a knot every 1000 s, od_pipe.py:213-221): on one lane that is a chain of ~10^5 dependent
+// instructions per edge, per LM trial and once more (six times, with a tangent each) for the factor -- 1.28 ms per BA call
+// at a 945 s gap in round 4, thirty times the 500-pose headline window.  Only the 6-vector state is a recurrence, and even
+// that recurrence parallelises: the gap is cut into P ~ sqrt(s) chunks of L ~ sqrt(s) steps and the chunk-start states U_j are
+// found by the parareal iteration (Lions, Maday, Turinici 2001) whose FINE propagator is the reference's own chain of 1 s
+// steps and whose coarse propagator G is ONE RK4 step over the chunk:
+//     U_0 = x0,  U_{j+1} <- F_j(U_j) + (G_j(U_j') - G_j(U_j))        (U' = the new iterate, swept left to right)
+// The fixed point is U_{j+1} = F_j(U_j), the serial chain itself (after k iterations the first k chunks are the serial chain
+// bit for bit).  The coarse step over ~31 s is wrong by ~3e-10 relative, so an iteration contracts the error by ~1e-8: the
+// first one leaves ~1e-15 relative, the second confirms it (iterated until the states move by less than 2^-40 relative -- two
+// iterations up to 1000 s, four at 6000 s; prototype with convergence table: tools/parareal_prototype.py).  What comes out
+// differs from the serial walk by rounding (<= 1e-15 relative measured, the size of the difference between this library's
+// rsq-based acceleration and the reference's sqrt / division), is a function of the states and the step count only, and is the
+// same in every kernel set -- both kernels below call the same long_states().
+// Cost of a 945 s edge: P + K (L + P) = 31 + 2 * 62 step times instead of 945.
+//
+// The transition matrix of a long edge is the ORDERED PRODUCT of the chunks' transition matrices (each from its converged
+// chunk-start state, six tangent lanes per chunk as in dynamics_block), multiplied pairwise in a fixed tree.
+//
+// Edges of at most kLongGap steps never come here: their arithmetic (and the bits of every window without a long gap) is
+// what it was.  With the hop integrator (predict_gpu's <= 100 s steps) no edge is long.
+#include "vba_device.h"
+#include "vba_launch.h"
+
+namespace vba {
+
+namespace {
+
+struct LongPlan { int L, P; };
+
+// chunk length and count for a gap of s steps: a function of s alone (so that every kernel cuts an edge alike)
+__device__ __forceinline__ LongPlan long_plan(int s) {
+    LongPlan p;
+    if (s > 1024) {
+        p.L = (s + 31) / 32;
+    } else {
+        int L = 1;
+        while (L * L < s) ++L;
+        p.L = L;
+    }
+    p.P = (s + p.L - 1) / p.L;         // <= 32
+    return p;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane /*wave-uniform*/) {
+    const unsigned long long b = f64_bits(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), lane);
+    return bits_f64(((unsigned long long)hi << 32) | lo);
+}
+
+// the coarse propagator: one RK4 step of length h (hh = h / 2, h6 = h / 6 precomputed: an IEEE division per step would sit on
+// the critical path of the sweep)
+__device__ __forceinline__ void rk4_coarse(const double* x, double h, double hh, double h6, double* o) {
+    double k1[3], k2[3], k3[3], k4[3], p[3], v2[3], v3[3], v4[3];
+    accel_jvp(x, nullptr, k1, nullptr, false);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { p[i] = x[i] + hh * x[3 + i]; v2[i] = x[3 + i] + hh * k1[i]; }
+    accel_jvp(p, nullptr, k2, nullptr, false);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { p[i] = x[i] + hh * v2[i]; v3[i] = x[3 + i] + hh * k2[i]; }
+    accel_jvp(p, nullptr, k3, nullptr, false);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { p[i] = x[i] + h * v3[i]; v4[i] = x[3 + i] + h * k3[i]; }
+    accel_jvp(p, nullptr, k4, nullptr, false);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o[i] = x[i] + h6 * (x[3 + i] + 2 * v2[i] + 2 * v3[i] + v4[i]);
+        o[3 + i] = x[3 + i] + h6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+    }
+}
+
+constexpr double kLongTol = 0x1p-40;    // the iteration stops when no chunk-start state moved by more than this, relative
+
+// One wavefront.  x0: the state at the start of the gap (the same in every lane), s: its steps.  Lane j < P ends up with the
+// converged chunk-start state U_j in `U`; xh (every lane) = U_P, the state at the end of the gap.  Everything lives in registers:
+// the sweep is computed by all lanes alike from values fetched with v_readlane, a lane keeps what concerns its chunk.
+__device__ __forceinline__ void long_states(const double* x0, int s, const LongPlan pl, int lane, double* U /*[6]*/, double* xh /*[6]*/) {
+    const int P = pl.P;
+    const int last_len = s - (P - 1) * pl.L;
+    const int my_len = lane < P - 1 ? pl.L : (lane == P - 1 ? last_len : 0);
+    const double hL = (double)pl.L, hhL = 0.5 * hL, h6L = hL / 6.0;
+    const double hT = (double)last_len, hhT = 0.5 * hT, h6T = hT / 6.0;
+    double G[6], F[6], u[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { u[c] = x0[c]; U[c] = x0[c]; G[c] = 0.0; }
+    // the coarse chain
+    for (int j = 0; j < P; ++j) {
+        const bool tail = j == P - 1;
+        double g[6];
+        rk4_coarse(u, tail ? hT : hL, tail ? hhT : hhL, tail ? h6T : h6L, g);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            if (lane == j) G[c] = g[c];
+            if (lane == j + 1) U[c] = g[c];
+            u[c] = g[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) xh[c] = u[c];
+    for (int it = 0; it < P; ++it) {
+        // fine: every chunk from its current start state, in parallel
+#pragma unroll
+        for (int c = 0; c < 6; ++c) F[c] = U[c];
+        for (int q = 0; q < my_len; ++q) rk4_step<false>(F, nullptr, 1.0);
+        // sweep (serial over the chunks, the same in every lane)
+        bool moved = false;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) u[c] = x0[c];
+        for (int j = 0; j < P; ++j) {
+            const bool tail = j == P - 1;
+            double g[6], un[6];
+            rk4_coarse(u, tail ? hT : hL, tail ? hhT : hhL, tail ? h6T : h6L, g);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) un[c] = readlane_f64(F[c], j) + (g[c] - readlane_f64(G[c], j));
+            // did the state this chunk ends on move?  (the lane of the next chunk holds the old one; the last is xh)
+            const double np = fmax(fmax(fabs(un[0]), fabs(un[1])), fabs(un[2])) * kLongTol;
+            const double nv = fmax(fmax(fabs(un[3]), fabs(un[4])), fabs(un[5])) * kLongTol;
+            const bool holder = tail ? true : lane == j + 1;
+            bool mv = false;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double old = tail ? xh[c] : U[c];
+                mv = mv || !(fabs(un[c] - old) <= (c < 3 ? np : nv));       // (a NaN counts as moved: the loop ends at P iterations)
+            }
+            moved = moved || (holder && mv);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                if (lane == j) G[c] = g[c];
+                if (!tail && lane == j + 1) U[c] = un[c];
+                if (tail) xh[c] = un[c];
+                u[c] = un[c];
+            }
+        }
+        if (!__any(moved)) break;
+    }
+}
+
+}  // namespace
+
+// The orbit residual of the long edges at the TRIAL states (BA_filtering.py:63-67): sqrt(Sigma) sum |[x_hat - p', 100 (v_hat - v')]|
+// of edge long_idx[k] into slot nblk_obs + nblk_dyn + k of part_trial (k_trial's pose-chain lanes left that edge's orbit part out
+// and kept its attitude part).  One wavefront per long edge; gated as k_trial is.
+__global__ __launch_bounds__(64) void k_long_trial(DevView V) {
+    const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
+    if (V.sc[w].done) return;
+    const int k = blockIdx.x, lane = threadIdx.x;
+    double* slot = V.part_trial + (size_t)w * V.trial_stride + V.nblk_obs + V.nblk_dyn + k;
+    if (k >= V.n_long[w]) {
+        if (lane == 0) *slot = 0.0;
+        return;
+    }
+    const int i = V.long_idx[(size_t)w * kLongCap + k];
+    const size_t sb = (size_t)w * V.n_max;
+    const double* st = V.states_new + (sb + i) * 10;
+    const double* sn = st + 10;
+    const double x0[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
+    const int s = -V.steps[sb + i];
+    double U[6], x[6];
+    long_states(x0, s, long_plan(s), lane, U, x);
+    if (lane == 0) {
+        const double r = fabs(x[0] - sn[0]) + fabs(x[1] - sn[1]) + fabs(x[2] - sn[2]) +
+                         fabs((x[3] - sn[7]) * kVelCoeff) + fabs((x[4] - sn[8]) * kVelCoeff) + fabs((x[5] - sn[9]) * kVelCoeff);
+        *slot = r * V.prm.sqrt_sigma;
+    }
+}
+
+// The dynamics factor of the long edges at the INPUT states: transition matrix Phi, prediction x_hat, residual r_orbit of pose
+// long_idx[k], and sum |r_orbit| into slot nblk_pred + k of part_pred (parity of the call).  One workgroup of 256 per long edge:
+// wave 0 finds the chunk-start states, then 8 lanes per chunk (6 tangents, as dynamics_block) carry the chunk's transition matrix,
+// and the P matrices are multiplied in order, pairwise: Phi = M_{P-1} ... M_1 M_0.
+__global__ __launch_bounds__(256) void k_long_factor(DevView V) {
+    __shared__ double Us[32][6];
+    __shared__ double M[2][32][36];
+    const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
+    const int k = blockIdx.x, tid = threadIdx.x;
+    double* slot = V.part_pred + ((size_t)w * 2 + V.par) * V.pred_stride + V.nblk_pred + k;
+    if (k >= V.n_long[w]) {
+        if (tid == 0) *slot = 0.0;
+        return;
+    }
+    const int i = V.long_idx[(size_t)w * kLongCap + k];
+    const size_t pb = (size_t)w * V.n_max + i;
+    const double* st = V.states + pb * 10;
+    const int s = -V.steps[pb];
+    const LongPlan pl = long_plan(s);
+    if (tid < 64) {
+        const double x0[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
+        double U[6], x[6];
+        long_states(x0, s, pl, tid, U, x);
+        if (tid < pl.P) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Us[tid][c] = U[c];
+        }
+        if (tid == 0) {
+            const double* sn = st + 10;
+            double* xh = V.xhat + pb * 6;
+            double* ro = V.rorb + pb * 6;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) xh[r] = x[r];
+            ro[0] = x[0] - sn[0];
+            ro[1] = x[1] - sn[1];
+            ro[2] = x[2] - sn[2];
+            ro[3] = (x[3] - sn[7]) * kVelCoeff;
+            ro[4] = (x[4] - sn[8]) * kVelCoeff;
+            ro[5] = (x[5] - sn[9]) * kVelCoeff;
+            *slot = fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]);
+        }
+    }
+    __syncthreads();
+    {   // the chunks' transition matrices
+        const int j = tid >> 3, c = tid & 7;
+        if (j < pl.P && c < 6) {
+            double x[6], t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 6; ++r) x[r] = Us[j][r];
+            t[c] = 1.0;
+            const int len = j < pl.P - 1 ? pl.L : s - (pl.P - 1) * pl.L;
+            for (int q = 0; q < len; ++q) rk4_step<true>(x, t, 1.0);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) M[0][j][6 * r + c] = t[r];
+        }
+    }
+    __syncthreads();
+    int cnt = pl.P, cur = 0;
+    while (cnt > 1) {
+        const int half = (cnt + 1) >> 1;
+        for (int e = tid; e < half * 36; e += 256) {
+            const int a = e / 36, rc = e % 36, r = rc / 6, c = rc % 6;
+            double v;
+            if (2 * a + 1 < cnt) {
+                const double* hi = M[cur][2 * a + 1];
+                const double* lo = M[cur][2 * a];
+                v = hi[6 * r] * lo[c];
+#pragma unroll
+                for (int q = 1; q < 6; ++q) v = fma(hi[6 * r + q], lo[6 * q + c], v);
+            } else {
+                v = M[cur][2 * a][rc];
+            }
+            M[cur ^ 1][a][rc] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+        cnt = half;
+    }
+    if (tid < 36) V.Phi[pb * 36 + tid] = M[cur][0][tid];
+}
+
+void launch_long_factor(const DevView& V, hipStream_t s) {
+    if (V.nblk_long <= 0 || V.hop) return;
+    hipLaunchKernelGGL(k_long_factor, dim3(V.nblk_long, V.W), dim3(256), 0, s, V);
+}
+
+void launch_long_trial(const DevView& V, hipStream_t s) {
+    if (V.nblk_long <= 0 || V.hop || V.prm.initialize) return;
+    hipLaunchKernelGGL(k_long_trial, dim3(V.nblk_long, V.W), dim3(64), 0, s, V);
+}
+
+}  // namespace vba

@@ -1222,9 +1222,11 @@ __global__ __launch_bounds__(kObsBlock) void k_trial(DevView V) {
         if (edge_thread && !prm.initialize && i < n - 1) {
             double x[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
             const int steps = V.steps[sb + i];
-            propagate_gap<false>(x, nullptr, steps, V.hop);
-            s = fabs(x[0] - sn[0]) + fabs(x[1] - sn[1]) + fabs(x[2] - sn[2]) +
-                fabs((x[3] - sn[7]) * kVelCoeff) + fabs((x[4] - sn[8]) * kVelCoeff) + fabs((x[5] - sn[9]) * kVelCoeff);
+            if (steps > 0 || V.hop) {       // (a long edge's orbit residual is k_long_trial's, in a slot of its own)
+                propagate_gap<false>(x, nullptr, abs(steps), V.hop);
+                s = fabs(x[0] - sn[0]) + fabs(x[1] - sn[1]) + fabs(x[2] - sn[2]) +
+                    fabs((x[3] - sn[7]) * kVelCoeff) + fabs((x[4] - sn[8]) * kVelCoeff) + fabs((x[5] - sn[9]) * kVelCoeff);
+            }
             double att = fabs(attitude_residual(st + 3, V.cumrot + (sb + i) * 4, sn + 3));
             // BA_reg evaluates the trial's dynamics residual with quat_coeff_prior = 1 where BA passes quat_coeff = 100
             // (BA_filtering.py:172, 174 vs :63, 65): reproduced as written
@@ -1347,10 +1349,10 @@ __global__ __launch_bounds__(256) void k_sh_front(DevView V, const double* gathe
         const double* slot = gathered + (size_t)q * slot_len;
         for (int b = t; b < V.nblk_obs; b += 256) { s_next += slot[off_next + b]; s_trial += slot[off_trial + b]; }
     }
-    for (int b = t; b < V.nblk_dyn; b += 256) s_trial += gathered[off_trial + V.nblk_obs + b];
+    for (int b = t; b < V.nblk_dyn + (V.prev.initialize ? 0 : V.nblk_long); b += 256) s_trial += gathered[off_trial + V.nblk_obs + b];
     if (do_fold && !V.prev.initialize) {
-        const double* pp = V.part_pred + ((size_t)w * 2 + pc) * V.nblk_pred;
-        for (int b = t; b < V.nblk_pred; b += 256) s_pred += pp[b];
+        const double* pp = V.part_pred + ((size_t)w * 2 + pc) * V.pred_stride;
+        for (int b = t; b < V.nblk_pred + V.nblk_long; b += 256) s_pred += pp[b];
     }
     unsigned hl[8], mine[8];
     if (do_resolve) {
@@ -1594,6 +1596,9 @@ void launch_obs_accumulate(const DevView& V, hipStream_t s) {
         case 32: hipLaunchKernelGGL((k_obs_accumulate<32, false, false>), g, b, 0, s, V); break;
         default: hipLaunchKernelGGL((k_obs_accumulate<64, false, false>), g, b, 0, s, V); break;
     }
+    // the long edges of the dynamics factor that rode in this grid (behind the folded accept test: the window has moved on to
+    // this call, or the kernel leaves it alone as every later kernel of the call does)
+    if (V.dyn_in_acc) launch_long_factor(V, s);
 }
 
 template <int EMIT>
@@ -1618,6 +1623,7 @@ void launch_trial(const DevView& V, hipStream_t s) {
     if (V.emit == 2) launch_trial_emit<2>(V, s);
     else if (V.emit == 1) launch_trial_emit<1>(V, s);
     else launch_trial_emit<0>(V, s);
+    launch_long_trial(V, s);        // the orbit residual of the long edges at the trial states (vba_long.hip)
 }
 
 void launch_debug_project(const DevView& V, int w, int m, double* est, double* J, double* wt, hipStream_t s) {

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void k_shard_trial_sum(DevView V, double* out) 
     const int lane = threadIdx.x;
     double so = 0.0, sd = 0.0;
     for (int b = lane; b < V.nblk_obs; b += 64) so += V.part_trial[b];
-    for (int b = lane; b < V.nblk_dyn; b += 64) sd += V.part_trial[V.nblk_obs + b];
+    for (int b = lane; b < V.nblk_dyn + (V.prm.initialize ? 0 : V.nblk_long); b += 64) sd += V.part_trial[V.nblk_obs + b];
     so = wave_sum(so);
     sd = wave_sum(sd);
     if (lane == 0) { out[0] = so; out[1] = sd; }
