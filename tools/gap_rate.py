@@ -11,7 +11,7 @@ win = od_pipe.prepare_window(*synth.make_two_pass_sequence())
 st0 = od_pipe.initial_guess(win)
 n, m = win.time_idx.size, win.ii.size
 print("poses", n, "rows", m, "gaps", np.diff(win.time_idx)[np.diff(win.time_idx) > 64])
-for hop in (False, True):
+for hop in ((False,) if "--rk4" in sys.argv else (False, True)):
     e = BAEngine(n, m)
     e.set_integrator(hop)
     e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)

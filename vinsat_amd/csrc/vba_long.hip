@@ -10,13 +10,14 @@
 // steps and whose coarse propagator G is ONE RK4 step over the chunk:
 //     U_0 = x0,  U_{j+1} <- F_j(U_j) + (G_j(U_j') - G_j(U_j))        (U' = the new iterate, swept left to right)
 // The fixed point is U_{j+1} = F_j(U_j), the serial chain itself (after k iterations the first k chunks are the serial chain
-// bit for bit).  The coarse step over ~31 s is wrong by ~3e-10 relative, so an iteration contracts the error by ~1e-8: the
-// first one leaves ~1e-15 relative, the second confirms it (iterated until the states move by less than 2^-40 relative -- two
-// iterations up to 1000 s, four at 6000 s; prototype with convergence table: tools/parareal_prototype.py).  What comes out
-// differs from the serial walk by rounding (<= 1e-15 relative measured, the size of the difference between this library's
-// rsq-based acceleration and the reference's sqrt / division), is a function of the states and the step count only, and is the
-// same in every kernel set -- both kernels below call the same long_states().
-// Cost of a 945 s edge: P + K (L + P) = 31 + 2 * 62 step times instead of 945.
+// bit for bit).  The coarse step over ~35 s is wrong by ~5e-10 relative, so an iteration contracts the error by ~1e-8: the
+// first one leaves ~1e-15 relative, and the fine pass of the second finds every chunk landing on the next chunk's start state
+// to 2^-45 relative -- the chain's defect -- and stops there (one sweep and two fine passes up to ~1000 s, three or four
+// sweeps at 6000 s; prototype with convergence table: tools/parareal_prototype.py).  What comes out differs from the serial
+// walk by rounding (<= 1e-15 relative measured, the size of the difference between this library's rsq-based acceleration and
+// the reference's sqrt / division), is a function of the states and the step count only, and is the same in every kernel set
+// -- both kernels below call the same long_states().
+// Cost of a 935 s edge: 2 P + 2 L = 2 * 26 + 2 * 37 step times instead of 935.
 //
 // The transition matrix of a long edge is the ORDERED PRODUCT of the chunks' transition matrices (each from its converged
 // chunk-start state, six tangent lanes per chunk as in dynamics_block), multiplied pairwise in a fixed tree.
@@ -35,14 +36,12 @@ struct LongPlan { int L, P; };
 // chunk length and count for a gap of s steps: a function of s alone (so that every kernel cuts an edge alike)
 __device__ __forceinline__ LongPlan long_plan(int s) {
     LongPlan p;
-    if (s > 1024) {
-        p.L = (s + 31) / 32;
-    } else {
-        int L = 1;
-        while (L * L < s) ++L;
-        p.L = L;
-    }
-    p.P = (s + p.L - 1) / p.L;         // <= 32
+    // a sweep step costs ~1.7 fine steps and there are two fine passes per sweep: L ~ sqrt(1.4 s) balances them
+    int L = 1;
+    while (5 * L * L < 7 * s) ++L;
+    if (32 * L < s) L = (s + 31) / 32;
+    p.L = L;
+    p.P = (s + L - 1) / L;             // <= 32
     return p;
 }
 
@@ -74,20 +73,24 @@ __device__ __forceinline__ void rk4_coarse(const double* x, double h, double hh,
     }
 }
 
-constexpr double kLongTol = 0x1p-40;    // the iteration stops when no chunk-start state moved by more than this, relative
+constexpr double kLongTol = 0x1p-45;    // a chunk's fine end state and the next chunk's start state agree to this, relative: converged
 
 // One wavefront.  x0: the state at the start of the gap (the same in every lane), s: its steps.  Lane j < P ends up with the
 // converged chunk-start state U_j in `U`; xh (every lane) = U_P, the state at the end of the gap.  Everything lives in registers:
-// the sweep is computed by all lanes alike from values fetched with v_readlane, a lane keeps what concerns its chunk.
+// the sweep is computed by all lanes alike from values fetched with v_readlane, a lane keeps what concerns its chunk (its start
+// state U, its end state N = the next chunk's start, its coarse value G).
+// The iteration ends when the DEFECT of the chain is below tolerance: every chunk's fine propagation from its start state
+// lands on the next chunk's start state, i.e. the U_j are the serial chain up to that tolerance -- checked right behind the
+// fine pass, so a converged iterate costs no sweep of its own (one sweep, two fine passes for gaps up to ~1000 s).
 __device__ __forceinline__ void long_states(const double* x0, int s, const LongPlan pl, int lane, double* U /*[6]*/, double* xh /*[6]*/) {
     const int P = pl.P;
     const int last_len = s - (P - 1) * pl.L;
     const int my_len = lane < P - 1 ? pl.L : (lane == P - 1 ? last_len : 0);
     const double hL = (double)pl.L, hhL = 0.5 * hL, h6L = hL / 6.0;
     const double hT = (double)last_len, hhT = 0.5 * hT, h6T = hT / 6.0;
-    double G[6], F[6], u[6];
+    double G[6], F[6], N[6], u[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { u[c] = x0[c]; U[c] = x0[c]; G[c] = 0.0; }
+    for (int c = 0; c < 6; ++c) { u[c] = x0[c]; U[c] = x0[c]; G[c] = 0.0; N[c] = x0[c]; }
     // the coarse chain
     for (int j = 0; j < P; ++j) {
         const bool tail = j == P - 1;
@@ -95,20 +98,25 @@ __device__ __forceinline__ void long_states(const double* x0, int s, const LongP
         rk4_coarse(u, tail ? hT : hL, tail ? hhT : hhL, tail ? h6T : h6L, g);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            if (lane == j) G[c] = g[c];
+            if (lane == j) { G[c] = g[c]; N[c] = g[c]; }
             if (lane == j + 1) U[c] = g[c];
             u[c] = g[c];
         }
     }
-#pragma unroll
-    for (int c = 0; c < 6; ++c) xh[c] = u[c];
-    for (int it = 0; it < P; ++it) {
+    for (int it = 0; it <= P; ++it) {
         // fine: every chunk from its current start state, in parallel
 #pragma unroll
         for (int c = 0; c < 6; ++c) F[c] = U[c];
         for (int q = 0; q < my_len; ++q) rk4_step<false>(F, nullptr, 1.0);
+        if (it > 0) {       // (the coarse chain alone is never close enough)
+            const double np = fmax(fmax(fabs(N[0]), fabs(N[1])), fabs(N[2])) * kLongTol;
+            const double nv = fmax(fmax(fabs(N[3]), fabs(N[4])), fabs(N[5])) * kLongTol;
+            bool off = false;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) off = off || !(fabs(F[c] - N[c]) <= (c < 3 ? np : nv));     // (a NaN never converges: P + 1 iterations)
+            if (!__any(off && lane < P)) break;
+        }
         // sweep (serial over the chunks, the same in every lane)
-        bool moved = false;
 #pragma unroll
         for (int c = 0; c < 6; ++c) u[c] = x0[c];
         for (int j = 0; j < P; ++j) {
@@ -117,27 +125,16 @@ __device__ __forceinline__ void long_states(const double* x0, int s, const LongP
             rk4_coarse(u, tail ? hT : hL, tail ? hhT : hhL, tail ? h6T : h6L, g);
 #pragma unroll
             for (int c = 0; c < 6; ++c) un[c] = readlane_f64(F[c], j) + (g[c] - readlane_f64(G[c], j));
-            // did the state this chunk ends on move?  (the lane of the next chunk holds the old one; the last is xh)
-            const double np = fmax(fmax(fabs(un[0]), fabs(un[1])), fabs(un[2])) * kLongTol;
-            const double nv = fmax(fmax(fabs(un[3]), fabs(un[4])), fabs(un[5])) * kLongTol;
-            const bool holder = tail ? true : lane == j + 1;
-            bool mv = false;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                const double old = tail ? xh[c] : U[c];
-                mv = mv || !(fabs(un[c] - old) <= (c < 3 ? np : nv));       // (a NaN counts as moved: the loop ends at P iterations)
-            }
-            moved = moved || (holder && mv);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                if (lane == j) G[c] = g[c];
-                if (!tail && lane == j + 1) U[c] = un[c];
-                if (tail) xh[c] = un[c];
+                if (lane == j) { G[c] = g[c]; N[c] = un[c]; }
+                if (lane == j + 1) U[c] = un[c];
                 u[c] = un[c];
             }
         }
-        if (!__any(moved)) break;
     }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) xh[c] = readlane_f64(N[c], P - 1);
 }
 
 }  // namespace
