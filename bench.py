@@ -202,6 +202,20 @@ def config_series(BAEngine, od_pipe, synth, device, sync):
     return out
 
 
+def timed_region(work, barrier, sync, reduce_max):
+    """The contract's timed region: barrier + device synchronisation, t0, `work` (synchronous on return), device synchronisation, t1,
+    THEN the trailing barrier and the MAX over ranks.  The trailing barrier is the control plane (gloo over the host: 0.1 - 0.5 ms
+    with eight local ranks) and must not be charged to a region that is 0.86 ms long at the driver's --steps 20; `work` having
+    returned and the device being idle is what ends this rank's time, the MAX over ranks takes care of the slowest."""
+    barrier()
+    t0 = time.perf_counter()
+    work()
+    sync()
+    dt = time.perf_counter() - t0
+    barrier()
+    return reduce_max(dt)
+
+
 # ------------------------------------------------------------------------------------------------ launcher (N > 1)
 def free_port():
     with socket.socket() as s:
@@ -387,8 +401,26 @@ def dry_run(args, em, rank, world):
     if world > 1:
         dist.barrier()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # the timed region of the real run (timed_region) around a stand-in for the work: 20 ms of sleep.  VBA_BENCH_BARRIER_SLEEP_MS
+    # makes the barrier slow on purpose -- the region must not see it (tests/test_bench_launcher.py)
+    slow = float(os.environ.get("VBA_BENCH_BARRIER_SLEEP_MS", "0")) * 1e-3
+
+    def barrier():
+        if slow:
+            time.sleep(slow)
+        if world > 1:
+            dist.barrier()
+
+    def reduce_max(dt):
+        if world == 1:
+            return dt
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    dt = timed_region(lambda: time.sleep(0.02), barrier, lambda: None, reduce_max)
     em.payload = {"metric": METRIC, "value": 0.0, "unit": "BA iterations/s", "n_gpus": world, "dry_run": True,
-                  "max_over_ranks": float(t.item())}
+                  "max_over_ranks": float(t.item()), "timed_region_ms": 1e3 * dt}
     em.emit()
     if world > 1:
         dist.destroy_process_group()
@@ -450,6 +482,13 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max(dt):
+        if dist is None:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     # initialisation, not measurement: five full schedules (~5 ms), so that every kernel of both phases has been loaded and
     # launched and the clocks are up before the W warm-up steps (which, for small W, would only ever reach the landmark-only phase)
     run_steps(eng, st0, 100)
@@ -460,26 +499,12 @@ def run_rank(args):
     run_steps(eng, st0, 40)
     run_steps(eng, st0, 1)
     run_steps(eng, st0, args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(eng, st0, args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # EXACTLY args.steps steps between a barrier + device synchronisation and a device synchronisation; the trailing barrier and
+    # the MAX over ranks follow outside the region (timed_region)
+    dt = timed_region(lambda: run_steps(eng, st0, args.steps), barrier, torch.cuda.synchronize, reduce_max)
     value = world * args.steps / dt
     # companion of the driver-sized sample (20 steps = 1 ms): the same loop over 200 steps, same bracketing
-    barrier()
-    t2 = time.perf_counter()
-    run_steps(eng, st0, 200)
-    barrier()
-    dt200 = time.perf_counter() - t2
-    if dist is not None:
-        t = torch.tensor([dt200], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt200 = float(t.item())
+    dt200 = timed_region(lambda: run_steps(eng, st0, 200), barrier, torch.cuda.synchronize, reduce_max)
 
     # ---- class times of the CHAINED schedule (the one `value` is timed on), HIP events on the library's stream at the class
     # boundaries of every call (vba_set_chain_profile): accumulate (select and the previous call's accept test folded in),
@@ -832,7 +857,7 @@ def run_rank(args):
                     em.emit(sharded={"error": "sharded measurement timed out (collective hung)"})
                 os._exit(3)     # ... and the run FAILS either way: a hung collective is a defect, never a result
 
-            watchdog = threading.Timer(240.0, bail)
+            watchdog = threading.Timer(420.0, bail)
             watchdog.daemon = True
             watchdog.start()
             try:
@@ -841,13 +866,10 @@ def run_rank(args):
                 # double of RCCL (tests/fake_rccl: host shared memory) -- every rank process drives the real kernels and the real
                 # schedule; the rate means nothing (the exchanges synchronise the stream), the leg running through does
                 nccl = None if rehearse else (dist.new_group(backend="nccl", device_id=torch.device("cuda", device)) if hasattr(dist, "new_group") else None)
-                cfg_s = synth.WindowConfig("sharded", cfg.n_poses, cfg.obs_per_pose * world, cfg.stride)
-                det_s, orb_s = synth.make_sequence(cfg_s, seed=0)
-                win_s = od_pipe.prepare_window(det_s, orb_s)
-                st_s = od_pipe.initial_guess(win_s)
                 ns = min(args.steps, 100)
+                rccl_ranks = 0 if rehearse else dist.get_world_size(nccl)
 
-                def run(sba, count):
+                def run(sba, st_s, count):
                     """`count` BA() calls walking the 20-call schedule: one chained device call per schedule where the library
                     issues the exchanges (vba_sh_run_schedule), call by call through torch.distributed otherwise."""
                     k = 0
@@ -862,56 +884,74 @@ def run_rank(args):
                                 sba.step(it, init)
                         k += cnt
 
-                def rate(sba):
-                    run(sba, 20)
-                    barrier()
-                    ts = time.perf_counter()
-                    run(sba, ns)
-                    barrier()
-                    t = torch.tensor([time.perf_counter() - ts], dtype=torch.float64)
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    return ns / float(t.item())
+                def rate(sba, st_s):
+                    run(sba, st_s, 20)
+                    return ns / timed_region(lambda: run(sba, st_s, ns), barrier, torch.cuda.synchronize, reduce_max)
 
-                # dispatched by the caller through torch.distributed (four stage calls + three collectives per call) ...
-                if rehearse:
+                def leg(win_s, st_s, what):
+                    """ONE window of FIXED size, its rows split over the ranks: the rate with the exchanges dispatched by the caller
+                    (torch.distributed), then issued by the library, beside the same window unsharded on one GPU (rank 0's device)."""
+                    ns_, ms_ = win_s.time_idx.size, win_s.ii.size
+                    e1 = BAEngine(ns_, ms_, device=device)
+                    load_windows(e1, win_s, ns_, 1)
+                    run_steps(e1, st_s, 20)
+                    one = ns / timed_region(lambda: run_steps(e1, st_s, ns), barrier, torch.cuda.synchronize, reduce_max)
+                    e1.close()
+                    out = {"window": what, "poses": int(ns_), "observations_total": int(ms_), "observations_per_rank": int(ms_ // world),
+                           "unit": "BA iterations/s", "rccl_ranks": rccl_ranks, "one_gpu_unsharded": one}
                     v_torch = None
-                else:
-                    sba = ShardedBA.from_window(win_s, device=device, group=nccl)
-                    v_torch = rate(sba)
-                    sba.close()
-                got.update({"value": v_torch, "unit": "BA iterations/s", "poses": cfg.n_poses,
-                            "rccl_ranks": 0 if rehearse else dist.get_world_size(nccl),
+                    if not rehearse:
+                        sba = ShardedBA.from_window(win_s, device=device, group=nccl)
+                        v_torch = rate(sba, st_s)
+                        sba.close()
+                    out.update(value=v_torch, value_torch_dispatched=v_torch, vs_one_gpu=(v_torch / one) if v_torch else None)
+                    got[what.split(":")[0]] = dict(out)
+                    # ... and issued by the library (RCCL on its own stream, one host call per schedule; the id of its communicator
+                    # travels over the gloo control group).  Whether the leg runs is decided by ALL ranks together (a rank that could
+                    # not join must not leave the others inside a collective).
+                    sba, ok = None, 1.0
+                    try:
+                        sba = ShardedBA.from_window(win_s, device=device, native=True, rccl_path=fake_rccl if rehearse else None)
+                    except Exception as exc:
+                        ok = 0.0
+                        out["native_error"] = repr(exc)[:300]
+                    agree = torch.tensor([ok], dtype=torch.float64)
+                    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+                    if float(agree.item()) > 0.5:
+                        v_native = rate(sba, st_s)
+                        first_b, n_miss, n_lm = sba.engine.stats()
+                        out.update(value_library_issued=v_native, library_issued_vs_one_gpu=v_native / one,
+                                   first_exchange_bytes_per_rank=first_b, calls_repeated_after_a_missed_select=n_miss,
+                                   calls_finished_by_the_lm_loop=n_lm, rccl_library=sba.engine.rccl_path)
+                    elif "native_error" not in out:
+                        out["native_error"] = "another rank could not join the library's communicator"
+                    if sba is not None:
+                        sba.close()
+                    got[what.split(":")[0]] = dict(out)
+                    return out
+
+                got.update({"unit": "BA iterations/s", "rccl_ranks": rccl_ranks,
                             **({"rehearsal": "library-issued leg on tests/fake_rccl (ranks share a device): not a measurement"} if rehearse else {}),
-                            "observations_total": int(win_s.ii.size), "observations_per_rank": int(win_s.ii.size // world),
                             "collectives_per_call": "3 all-gathers (|r| keys, per-pose blocks, trial sums) over RCCL",
-                            "transport": "torch.distributed all_gather_into_tensor between the stage calls",
-                            "value_torch_dispatched": v_torch})
+                            "transport": "torch.distributed all_gather_into_tensor between the stage calls (value); ncclAllGather issued by "
+                                         "libvinsat_ba.so on its stream, calls chained on the device (value_library_issued)",
+                            "protocol_library_issued": "carried keys: all-gather of [warm histogram | block sums], of the median bin's bucket, of "
+                                                       "the per-pose normal equations (vba_sh_run_schedule)",
+                            "note": "`value` of every entry is the caller-dispatched rate: the library-issued path has been compared with it bit "
+                                    "for bit at one rank and on the test double of tests/fake_rccl only, not yet on two real devices"})
+                # the configs BASELINE.json names as sharded, FIXED totals whatever the rank count: C4 = 500 poses / 200 000 rows,
+                # C5 = 2004 poses / 500 000 rows (strong scaling of one window) ...
+                for name in ("C4", "C5"):
+                    win_s = od_pipe.prepare_window(*synth.make_sequence(name))
+                    leg(win_s, od_pipe.initial_guess(win_s), f"{name}: fixed total, rows split over {world} rank(s)")
+                # ... and the headline window with its rows multiplied by the rank count (per-rank rows fixed)
+                cfg_s = synth.WindowConfig("sharded", cfg.n_poses, cfg.obs_per_pose * world, cfg.stride)
+                win_s = od_pipe.prepare_window(*synth.make_sequence(cfg_s, seed=0))
+                weak = leg(win_s, od_pipe.initial_guess(win_s), f"weak: {cfg.name} with {cfg.obs_per_pose} x {world} rows per pose")
+                got.update(value=weak["value"], value_library_issued=weak.get("value_library_issued"), poses=weak["poses"],
+                           observations_total=weak["observations_total"], observations_per_rank=weak["observations_per_rank"],
+                           value_is="the weak-scaled window's caller-dispatched rate (the entry of rounds 1-4); C4 / C5 are the fixed-size windows")
                 sharded = dict(got)
-                # ... and issued by the library (RCCL on its own stream, one host call per BA call; the id of its
-                # communicator travels over the gloo control group).  A failure here keeps the rate above.
-                # `value` stays the caller-dispatched rate: the library-issued path has been compared with it bit for bit at
-                # one rank and on the test double of tests/fake_rccl only, not yet on two real devices.  Whether the leg runs is
-                # decided by ALL ranks together (a rank that could not join must not leave the others inside a collective).
-                sba, ok = None, 1.0
-                try:
-                    sba = ShardedBA.from_window(win_s, device=device, native=True, rccl_path=fake_rccl if rehearse else None)
-                except Exception as exc:
-                    ok = 0.0
-                    sharded["native_error"] = repr(exc)[:300]
-                agree = torch.tensor([ok], dtype=torch.float64)
-                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-                if float(agree.item()) > 0.5:
-                    v_native = rate(sba)
-                    first_b, n_miss, n_lm = sba.engine.stats()
-                    sharded.update(value_library_issued=v_native, value_library_issued_vs_unsharded=v_native / value * world,
-                                   protocol="carried keys: all-gather of [warm histogram | block sums], of the median bin's bucket, of the "
-                                            "per-pose normal equations; calls chained on the device (vba_sh_run_schedule)",
-                                   first_exchange_bytes_per_rank=first_b, calls_repeated_after_a_missed_select=n_miss, calls_finished_by_the_lm_loop=n_lm,
-                                   transport_library_issued="ncclAllGather issued by libvinsat_ba.so on its stream (vba_sh_call), " + sba.engine.rccl_path)
-                elif "native_error" not in sharded:
-                    sharded["native_error"] = "another rank could not join the library's communicator"
-                if sba is not None:
-                    sba.close()
             except Exception as exc:      # never lose the headline line to the secondary measurement
                 sharded = {"error": repr(exc)[:300]}
             watchdog.cancel()

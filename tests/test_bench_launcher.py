@@ -10,8 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(*argv, timeout=240):
+def _run(*argv, timeout=240, **extra_env):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
     return subprocess.run([sys.executable, BENCH, *argv], env=env, capture_output=True, text=True, timeout=timeout)
 
 
@@ -23,6 +24,16 @@ def test_gpus_2_starts_two_ranks_and_prints_one_line():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True
     assert out["max_over_ranks"] == 2.0            # the all-reduce(MAX) really saw rank 1's contribution
+
+
+def test_a_slow_barrier_is_not_charged_to_the_timed_region():
+    """The region of `value` ends when this rank's work has returned and its device is idle; the trailing barrier (gloo, the
+    control plane) and the MAX over ranks come after it.  Stand-in work of 20 ms, a barrier made 60 ms slow on purpose."""
+    for world in ("1", "2"):
+        p = _run("--gpus", world, "--dry-run", VBA_BENCH_BARRIER_SLEEP_MS="60")
+        assert p.returncode == 0, p.stderr[-2000:]
+        ms = json.loads(p.stdout.strip())["timed_region_ms"]
+        assert 19.0 <= ms < 45.0, ms
 
 
 def test_single_rank_needs_no_process_group():

@@ -1,0 +1,138 @@
+"""Long gaps of the pose chain (vinsat_amd/csrc/vba_long.hip: parallel-in-time propagation, ordered product of the chunks'
+transition matrices) against the oracle's serial chain of 1 s RK4 steps (reference: BA_utils.py:73-87, 457-509)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from oracle import ba_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+D = np.array([1.0, 1.0, 1.0, 100.0, 100.0, 100.0])
+
+
+def _window(n, rows_per_pose=6, seed=5):
+    from vinsat_amd import od_pipe, synth
+    det, orb = synth.make_sequence(synth.WindowConfig("long", n, rows_per_pose, 5), seed=seed)
+    return od_pipe.prepare_window(det, orb)
+
+
+def _engine(win, t):
+    from vinsat_amd.engine import BAEngine
+    n = t.size
+    eng = BAEngine(n, win.ii.size)
+    eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+    eng.upload_window(win.intrinsics, win.cumrot_last, t)
+    return eng
+
+
+def _check_factor(eng, st, t, cumrot, phi_tol=1e-12, it=12, lam=1e-3):
+    """One full-phase call on `st`; the factor it formed at those states against the oracle's serial walk."""
+    out = eng.iterate(it, False, lam, st)
+    r, E, F = O.orbit_factor(st, t, jacobian=True)
+    Phi = eng.debug("Phi")[:-1]
+    assert rel_err((D[None, :, None] * Phi)[:, :, :3], E[:, :, 0:3]) < phi_tol
+    assert rel_err((D[None, :, None] * Phi)[:, :, 3:], E[:, :, 6:9]) < phi_tol
+    # per edge as well: a long edge's block must not hide behind a large short one
+    for i in range(Phi.shape[0]):
+        assert rel_err(D[:, None] * Phi[i], np.concatenate([E[i][:, 0:3], E[i][:, 6:9]], -1)) < 10 * phi_tol, i
+    rp = eng.debug("r_pred")
+    # x_hat - x_next: positions of ~7000 km, velocities x 100: 1e-9 absolute is 1.4e-13 relative of the propagated state
+    assert np.abs(rp[:, :6] - r).max() < 1e-9
+    return out
+
+
+def test_two_pass_window_factor_against_the_serial_chain():
+    """The reference's two-pass window (gaps of 935 and 510 s), at the states the reference itself reached before call 25."""
+    from vinsat_amd import od_pipe, synth
+    g = load_golden("gap")
+    win = od_pipe.prepare_window(*synth.make_two_pass_sequence())
+    t = win.time_idx
+    assert sorted(np.diff(t)[np.diff(t) > 64]) == [510, 935]
+    eng = _engine(win, t)
+    st = g["states_out_24"][0]
+    assert not g["initialize"][25]
+    out = _check_factor(eng, st, t, win.cumrot_last, it=int(g["iters"][25]), lam=float(g["lamda_in"][25]))
+    ref = g["states_out_25"][0]
+    assert g["n_trials"][25] == out[3] and g["lamda_out"][25] == out[1]
+    assert rel_err(out[0], ref) < 1e-8
+    eng.close()
+
+
+@pytest.mark.parametrize("gaps", [(64, 65, 66), (100, 7, 1024, 3), (1025, 2, 2000), (3000,), (729, 730, 731)],
+                         ids=["threshold", "mixed", "over-1024", "3000s", "plan-edge"])
+def test_gap_lengths_around_every_rule_of_the_partition(gaps):
+    """64 steps stay on the serial walk, 65 are cut into chunks; 1024 / 1025: the chunk count saturates at 32; 3000 s needs
+    more than one sweep; short edges beside long ones keep their arithmetic."""
+    n = len(gaps) + 3
+    win = _window(n)
+    steps = np.array([5] + list(gaps) + [4], dtype=np.int64)
+    t = np.concatenate([[10], 10 + np.cumsum(steps)]).astype(np.int64)
+    eng = _engine(win, t)
+    rng = np.random.default_rng(2)
+    st = win.states_gt.copy()
+    st[:, :3] += rng.normal(0, 20.0, size=(n, 3))
+    st[:, 7:] *= 1.0 + rng.normal(0, 0.01, size=(n, 3))
+    _check_factor(eng, st, t, win.cumrot_last)
+    eng.close()
+
+
+def test_trial_residual_and_decisions_follow_the_oracle_across_long_gaps():
+    """Whole calls (accept test with the long edges' residual slots, several trials) against the oracle."""
+    from vinsat_amd import od_pipe
+    from test_gpu_parity import _oracle_vs_gpu
+    win = _window(9, rows_per_pose=12, seed=8)
+    steps = np.array([5, 300, 5, 5, 90, 5, 700, 5], dtype=np.int64)
+    t = np.concatenate([[10], 10 + np.cumsum(steps)]).astype(np.int64)
+    eng = _engine(win, t)
+    args = (win.cumrot_last, win.landmarks_uv, win.landmarks_xyz, win.ii, t, win.intrinsics, win.confidences)
+    st = od_pipe.initial_guess(win)
+    lam = 1e-4
+    for it, init in ((0, True), (1, True), (10, False), (11, False), (12, False), (13, False)):
+        st, lam, ntr, flags = _oracle_vs_gpu(eng, args, it, init, lam, st, tol=1e-7)
+    eng.close()
+
+
+def test_more_long_edges_than_slots_fall_back_to_the_serial_walk():
+    """kLongCap = 64 long edges per window go parallel in time, further ones take the ordinary lanes."""
+    n = 72
+    win = _window(n, rows_per_pose=3)
+    steps = np.full(n - 1, 70, dtype=np.int64)
+    t = np.concatenate([[10], 10 + np.cumsum(steps)]).astype(np.int64)
+    eng = _engine(win, t)
+    _check_factor(eng, win.states_gt.copy(), t, win.cumrot_last)
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0], ids=["latency-kernels", "bandwidth-kernels"])
+def test_long_edges_in_a_batch_have_the_bits_of_the_window_alone(mode):
+    """Windows with different numbers of long edges on one handle (the extra blocks of a window without one write zeros),
+    with either kernel set (dynamics_block riding in the accumulation / k_dynamics_pair on the second stream)."""
+    from vinsat_amd.engine import BAEngine
+    wins, ts = [], []
+    for k, gaps in enumerate([(5, 5, 5), (200, 5, 400), (5, 80, 5)]):
+        win = _window(4, seed=20 + k)
+        t = np.concatenate([[10], 10 + np.cumsum(np.array(gaps, dtype=np.int64))]).astype(np.int64)
+        wins.append(win)
+        ts.append(t)
+    m_max = max(w.ii.size for w in wins)
+    sched = ([0, 1, 10, 11, 12], [True, True, False, False, False])
+
+    def run(idx):
+        e = BAEngine(4, m_max, windows=len(idx), mode=mode)
+        for slot, k in enumerate(idx):
+            w = wins[k]
+            e.upload_observations(w.landmarks_xyz, w.landmarks_uv, w.confidences, w.ii, 4, window=slot)
+            e.upload_window(w.intrinsics, w.cumrot_last, ts[k], window=slot)
+            st = w.states_gt.copy()
+            st[:, :3] += 3.0
+            e.set_states(st, 1e-4, window=slot)
+        e.run_schedule(*sched)
+        out = [e.get_states(window=slot)[0].copy() for slot in range(len(idx))]
+        e.close()
+        return out
+
+    together = run([0, 1, 2])
+    for k in range(3):
+        alone = run([k])[0]
+        assert np.array_equal(together[k], alone), k
