@@ -98,6 +98,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = every core of this box)")
     ap.add_argument("--no-sharded", action="store_true")
+    ap.add_argument("--no-driver", action="store_true", help="skip the end-to-end series of the drop-in driver (streaming_version, run_folder)")
     ap.add_argument("--no-schur", action="store_true", help="skip the free-landmark Schur add-on leg (parity unpinned, not part of the metric)")
     ap.add_argument("--rank-timeout", type=float, default=900.0, help="launcher: seconds before hung rank processes are ended")
     ap.add_argument("--cpu-worker", type=int, default=-1, help=argparse.SUPPRESS)     # internal: CPU baseline worker
@@ -214,6 +215,67 @@ def timed_region(work, barrier, sync, reduce_max):
     dt = time.perf_counter() - t0
     barrier()
     return reduce_max(dt)
+
+
+def driver_series(od_pipe, synth, errors_eval, device):
+    """The drop-in pipeline end to end: wall time of `streaming_version` (reference od_pipe.py:911-1062) on
+    the C2, C3 and two-pass sequences and of `errors_eval.run_folder` (the reference's loop over 22 sequence files,
+    od_pipe.py:1063-1086) sequentially and batched, split into data preparation / BA calls (uploads and result copies included)
+    / bookkeeping (batch cut, dead reckoning across a gap, error records), beside the reference's own wall time for the same
+    sequence where a fixture recorded it (tests/golden/*.npz ref_wall_seconds: build container, 8 vCPU)."""
+    import shutil
+    import tempfile
+    out = {"unit": "ms", "sequences": {}}
+    for name, fixture in (("C2", "c2"), ("C3", "c3"), ("two-pass", "gap")):
+        det, orb = synth.make_two_pass_sequence() if name == "two-pass" else synth.make_sequence(name)
+        od_pipe.streaming_version(detections=det.copy(), orbit_np=orb.copy())          # engines created, kernels loaded
+        best = None
+        for _ in range(3):
+            t = {}
+            t0 = time.perf_counter()
+            od_pipe.streaming_version(detections=det.copy(), orbit_np=orb.copy(), timing=t)
+            wall = time.perf_counter() - t0
+            if best is None or wall < best[0]:
+                best = (wall, t)
+        wall, t = best
+        e = {"wall": 1e3 * wall, "prep": 1e3 * t["prep"], "ba": 1e3 * t["ba"], "bookkeeping": 1e3 * t["bookkeeping"],
+             "ba_calls": int(t["ba_calls"]), "rows": int(det.shape[0]), "host_over_ba": (t["prep"] + t["bookkeeping"]) / t["ba"]}
+        gpath = os.path.join(ROOT, "tests", "golden", fixture + ".npz")
+        if os.path.exists(gpath):
+            g = np.load(gpath)
+            if "ref_wall_seconds" in g:
+                e["reference_wall"] = 1e3 * float(g["ref_wall_seconds"])
+                e["reference_threads"] = int(g["ref_threads"]) if "ref_threads" in g else None
+        out["sequences"][name] = e
+    # 22 synthetic sequences on disk, as the reference's __main__ finds them
+    tmp = tempfile.mkdtemp(prefix="vba_bench_folder_")
+    try:
+        for sub in ("tmp_dets", "tmp_pose"):
+            os.makedirs(os.path.join(tmp, sub))
+        rows = 0
+        for k in range(22):
+            det, orb = synth.make_sequence("C3", seed=100 + k)
+            rows += det.shape[0]
+            np.save(os.path.join(tmp, "tmp_dets", f"{k:05d}_all_detections.npy"), det)
+            np.save(os.path.join(tmp, "tmp_pose", f"{k:05d}_orbit_eci_zyxvecs.npy"), orb)
+        folder = {"sequences": 22, "rows": int(rows), "window": "C3 (500 poses / 50 000 rows each)"}
+        for key, kw in (("batched", dict(batched=True)), ("sequential", dict())):
+            errors_eval.run_folder(tmp, **kw)
+            st = []
+            t0 = time.perf_counter()
+            errors_eval.run_folder(tmp, stats=st, **kw)
+            wall = time.perf_counter() - t0
+            s0 = st[0]
+            folder[key] = {"wall": 1e3 * wall, "prep": 1e3 * s0["prep"], "ba": 1e3 * s0["ba"], "bookkeeping": 1e3 * s0["bookkeeping"],
+                           "ba_calls": int(s0["ba_calls"]), "ba_iterations_per_s_end_to_end": s0["ba_calls"] / wall,
+                           "host_over_ba": (s0["prep"] + s0["bookkeeping"]) / s0["ba"]}
+        out["folder"] = folder
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["note"] = ("wall = one call of the driver with its inputs in memory (sequences) / on disk (folder); prep is NumPy on one host "
+                   "core plus the library's host helpers for the serial chains (vba_host_*); replicas over GPUs and several workers "
+                   "per GPU (errors_eval.run_folder(gpus=N, workers_per_gpu=K)) run the prep of different sequences in parallel")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ launcher (N > 1)
@@ -742,6 +804,15 @@ def run_rank(args):
         except Exception as exc:
             configs = {"error": repr(exc)[:300]}
 
+    # ---- the drop-in pipeline end to end
+    driver = None
+    if rank == 0 and world == 1 and not force_dist and not args.no_driver:
+        try:
+            from vinsat_amd import errors_eval
+            driver = driver_series(od_pipe, synth, errors_eval, device)
+        except Exception as exc:
+            driver = {"error": repr(exc)[:300]}
+
     # ---- accuracy: the 20-call schedule once more from the initial guess, against the reference's final states
     accuracy = None
     gpath = os.path.join(ROOT, "tests", "golden", f"{cfg.name.lower()}.npz")
@@ -832,6 +903,7 @@ def run_rank(args):
         "batched_sweep": batched_sweep,
         "python_BA_batch": python_batch,
         "configs": configs,
+        "driver": driver,
         "schur_addon": schur,
     }
 

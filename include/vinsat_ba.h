@@ -393,6 +393,24 @@ int vba_sh_set_protocol(vba_handle h, int carried_keys);
 int vba_sh_stats(vba_handle h, int64_t* bytes_first_exchange, int64_t* fallbacks_miss, int64_t* fallbacks_lm);
 int vba_sh_comm_destroy(vba_handle h);
 
+/* ---- host-side helpers of the driver around BA() (streaming_version, od_pipe.py:911-1062).  No device is
+ * involved and no handle is needed: the serial recurrences of the driver's data preparation, which as interpreted loops cost more
+ * than the BA calls they sit between.
+ *   vba_host_orbit_chain:   `steps` one-second RK4 steps of the J2 orbit dynamics from x0 = [p (km), v (km/s)] -- the dead
+ *                           reckoning across the gap between two batches (propagate_dynamics_init, BA_utils.py:114-129; RK4 :901-912;
+ *                           driver od_pipe.py:1011, 1052); out[k] = the state after k + 1 steps.
+ *   vba_host_quat_chain:    running Hamilton product (scalar last, BA_utils.py:992-1000) out[k] = q0 (x) r[0] (x) ... (x) r[k]
+ *                           (q0 NULL: out[k] = r[0] (x) ... (x) r[k]) -- the attitude of the same dead reckoning
+ *                           (propagate_rotation_dynamics_init, BA_utils.py:105-112).  Every product and sum is rounded on its own in
+ *                           the order of the reference's expression: the bits of the array code.
+ *   vba_host_gap_rotations: the attitude increment accumulated over the gap after each pose, cum[i] = r[t_i] (x) ... (x)
+ *                           r[t_{i+1} - 1] with r[N,4] the per-second increments exp(dt * omega) and cum[T - 1] the identity
+ *                           (precompute_cum_rotations, BA_utils.py:278-288, of which only [..., -1] is read, :295; driver
+ *                           od_pipe.py:945-961).  Same rounding rule. */
+int vba_host_orbit_chain(const double* x0 /*[6]*/, int steps, double* out /*[steps,6]*/);
+int vba_host_quat_chain(const double* q0 /*[4] or NULL*/, const double* r /*[K,4]*/, int K, double* out /*[K,4]*/);
+int vba_host_gap_rotations(const double* r /*[N,4]*/, int64_t N, const int64_t* time_idx /*[T]*/, int T, double* cum /*[T,4]*/);
+
 /* ---- free-landmark Schur-complement BA: ADD-ON, PARITY UNPINNED ------------------------------------------
  * The reference keeps its landmarks fixed (BA_filtering.py:32-37) and has nothing to marginalise; this mode is the
  * variant BASELINE.json's north_star describes on top of it and has NO counterpart in the reference.  Unknowns: 6 per

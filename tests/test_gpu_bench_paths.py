@@ -621,6 +621,102 @@ def test_BA_sees_in_place_edits_of_any_of_seven_numpy_arguments_between_resident
     ba_mod.release()
 
 
+@pytest.mark.parametrize("which", ["imu", "uv", "xyz", "ii", "t", "K", "conf"])
+def test_BA_window_sees_in_place_edits_of_its_numpy_arguments(c2, which):
+    """``BA_window`` goes set_states -> vba_run_schedule, which does not evaluate the library's host watch: an ndarray argument
+    edited in place between two calls (same Python object) is compared with the uploaded copy in front of the device call.  All
+    seven array arguments as ndarrays, one of them edited."""
+    from conftest import golden_inputs
+    from vinsat_amd import ba as ba_mod
+    g, inp = c2, golden_inputs(c2)
+    n = inp["K"].shape[0]
+    imu = np.zeros((1, n, 1, 10))
+    imu[0, :, 0, 6:] = inp["cumrot"]
+    a = dict(imu=imu, uv=inp["uv"][None].copy(), xyz=inp["xyz"][None].copy(), ii=inp["ii"].copy(), t=inp["time_idx"].copy(),
+             K=inp["K"][None].copy(), conf=inp["conf"].copy())
+    iters, inits = [0, 1, 10, 11], [True, True, False, False]
+
+    def call(w):
+        return ba_mod.BA_window(iters, inits, g["states0"].copy(), None, w["imu"], w["uv"], w["xyz"], w["ii"], w["t"], w["K"], w["conf"], 1e-4)[0].numpy().copy()
+
+    ba_mod.release()
+    base = call(a)
+    assert np.array_equal(call(a), base)
+    if which == "imu":
+        a["imu"][0, 3:9, 0, 6:] = a["imu"][0, 4:10, 0, 6:].copy()
+    elif which == "uv":
+        a["uv"][0, 100:200] += 3.0
+    elif which == "xyz":
+        a["xyz"][0, 777] += 0.5
+    elif which == "ii":
+        a["ii"][1234] += 1
+        a["ii"].sort()
+    elif which == "t":
+        a["t"][-1] += 3
+    elif which == "K":
+        a["K"][0, :, 0] *= 1.001
+    else:
+        a["conf"][::2] *= 0.5
+    edited = call(a)
+    assert not np.array_equal(edited, base)
+    fresh = {k: np.array(v) for k, v in a.items()}
+    ba_mod.release()
+    assert np.array_equal(call(fresh), edited)
+    ba_mod.release()
+
+
+def test_strict_mode_sees_a_torch_argument_edited_through_its_numpy_alias(c2):
+    """``tensor.numpy()[...] = x`` does not bump ``_version``: by default the drop-in trusts address / shape / version of torch
+    arguments (``invalidate()`` is the documented way out); ``configure(strict=True)`` content-checks torch CPU arguments like
+    ndarrays -- between resident calls of the driver's loop (library-side comparison) and in front of ``BA_window``."""
+    import torch
+    from conftest import golden_inputs
+    from vinsat_amd import ba as ba_mod
+    g, inp = c2, golden_inputs(c2)
+    n = inp["K"].shape[0]
+    a = _ba_args(inp, n)
+    assert isinstance(a["conf"], torch.Tensor) and isinstance(a["uv"], torch.Tensor)
+    sched = [(0, True), (1, True), (2, True)]
+
+    def loop(args, edit_before=None, window=False):
+        ba_mod.release()
+        st, lam = torch.from_numpy(g["states0"].copy()), 1e-4
+        outs = []
+        for k, (it, init) in enumerate(sched):
+            if k == edit_before:
+                args["conf"].numpy()[::2] *= 0.5
+            if window:
+                st, _, lam, _ = ba_mod.BA_window([it], [init], st, None, args["imu"], args["uv"], args["xyz"], args["ii"], args["t"], args["K"],
+                                                 args["conf"], lam)
+            else:
+                st, _, lam, _ = ba_mod.BA(it, st, None, args["imu"], args["uv"], args["xyz"], args["ii"], args["t"], args["K"], args["conf"],
+                                          1e-3, 1e-3, lam, None, initialize=init)
+            outs.append(st.numpy().copy())
+        return outs
+
+    try:
+        ba_mod.configure(strict=True)
+        for window in (False, True):
+            b = dict(a, conf=a["conf"].clone())
+            base = loop(b, window=window)
+            ver = b["conf"]._version
+            edited = loop(b, edit_before=2, window=window)
+            assert b["conf"]._version == ver                                # the edit was invisible to the version counter ...
+            assert np.array_equal(edited[1], base[1]) and not np.array_equal(edited[2], base[2]), window   # ... and seen all the same
+            # what a caller gets who never edits in place: calls 0, 1 on the original tensor, call 2 on a fresh copy of the edited one
+            fresh = dict(b, conf=b["conf"].clone())
+            ba_mod.release()
+            st_in, lam_in = torch.from_numpy(g["states0"].copy()), 1e-4
+            for k, (it, init) in enumerate(sched):
+                w = a if k < 2 else fresh
+                st_in, _, lam_in, _ = ba_mod.BA(it, st_in, None, w["imu"], w["uv"], w["xyz"], w["ii"], w["t"], w["K"], w["conf"], 1e-3, 1e-3, lam_in,
+                                                None, initialize=init)
+            assert rel_err(edited[2], st_in.numpy()) < 1e-12, window
+    finally:
+        ba_mod.configure(strict=False)
+        ba_mod.release()
+
+
 def test_pipeline_predictor_does_not_learn_across_window_boundaries(c2):
     """Six windows in a row through the driver's loop (call 0 with uploaded states, calls 1 .. 19 resident): the speculated calls
     that are dropped stay at one per boundary at most (the call guessed behind iter 19) plus the one wrong guess at the first

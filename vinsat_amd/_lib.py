@@ -77,6 +77,10 @@ SIGNATURES = {
     "vba_sh_set_protocol": (c_int, [c_void_p, c_int]),
     "vba_sh_stats": (c_int, [c_void_p, PI64, PI64, PI64]),
     "vba_sh_comm_destroy": (c_int, [c_void_p]),
+    # host-side helpers of the driver (no device)
+    "vba_host_orbit_chain": (c_int, [PD, c_int, PD]),
+    "vba_host_quat_chain": (c_int, [PD, PD, c_int, PD]),
+    "vba_host_gap_rotations": (c_int, [PD, c_int64, PI64, c_int, PD]),
     # free-landmark Schur add-on (parity unpinned: no counterpart in the reference)
     "vba_schur_last_error": (c_char_p, []),
     "vba_schur_create": (c_int, [c_int, c_int, c_int64, c_int, c_int, c_int64, POINTER(c_void_p)]),
@@ -130,6 +134,15 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def as_pd(a):
+    """A C-contiguous float64 ndarray as ``double*`` (the array must outlive the call)."""
+    return a.ctypes.data_as(PD)
+
+
+def as_pi64(a):
+    return a.ctypes.data_as(PI64)
 
 
 def check(rc, lib=None):

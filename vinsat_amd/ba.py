@@ -105,15 +105,33 @@ def _same_bytes(a, c):
     return np.array_equal(a, c)
 
 
+def _watchable(a):
+    """The host buffer of an argument whose CONTENT is compared with the uploaded copy: an ndarray itself; with
+    ``configure(strict=True)`` also a torch CPU tensor (as the ndarray view of its storage: a write through ``.numpy()`` or any
+    other alias does not bump ``_version`` and would otherwise go unseen); None for everything else."""
+    if isinstance(a, np.ndarray):
+        return a
+    if _cache.get("strict") and getattr(a, "_version", None) is not None:
+        try:
+            if a.device.type == "cpu" and not a.requires_grad:
+                return a.detach().numpy()
+        except (RuntimeError, TypeError):
+            pass
+    return None
+
+
 def _numpy_unchanged(args):
-    """True if every ndarray among ``args`` still holds the bytes of the private copy taken when it was uploaded."""
+    """True if every watchable argument (:func:`_watchable`) still holds the bytes of the private copy taken when it was uploaded."""
     for a, c in zip(args, _cache.get("np_copies", ())):
-        if c is not None and not (a.shape == c.shape and a.dtype == c.dtype and _same_bytes(a, c)):
+        if c is None:
+            continue
+        a = _watchable(a)
+        if a is None or not (a.shape == c.shape and a.dtype == c.dtype and _same_bytes(a, c)):
             return False
     return True
 
 
-def configure(integrator=None, lanes=None, fusion=None, solver=None, mode=None):
+def configure(integrator=None, lanes=None, fusion=None, solver=None, mode=None, strict=None):
     """Settings of the cached engines that the reference's call surface has no argument for.
 
     ``integrator``: ``"rk4"`` (default) = one-second RK4 steps, the reference's CPU branch ``predict``
@@ -125,7 +143,14 @@ def configure(integrator=None, lanes=None, fusion=None, solver=None, mode=None):
     pose of the accumulation (``vba_set_accumulate_lanes``: the shape of its reduction tree), the kernel-fusion mask
     (``vba_set_fusion``), the chain partition ``(chunk, chunk2)`` (``vba_set_solver2``; ``0`` = sequential walk) and the kernel
     set (``vba_create_mode``) -- so that a window gets the same bits alone and in a batch of any size.  ``"auto"`` returns
-    one of them to the handle's choice.  The cached engines are rebuilt."""
+    one of them to the handle's choice.  The cached engines are rebuilt.
+
+    ``strict=True``: torch CPU arguments are content-checked like ndarrays (private copy at the upload, compared by the library
+    while the device works) instead of being trusted on address / shape / ``_version`` -- a write through ``tensor.numpy()`` or
+    another alias is then seen by itself; costs one more copy of the window's arguments at every upload."""
+    if strict is not None and bool(strict) != bool(_cache.get("strict")):
+        _cache["strict"] = bool(strict)
+        invalidate()
     if integrator is not None:
         if integrator not in ("rk4", "hop"):
             raise ValueError("integrator must be 'rk4' or 'hop'")
@@ -172,11 +197,18 @@ def _new_engine(n_max, m_max, windows, device):
 def invalidate():
     """Forget what is on the device: the next call uploads its window again (needed after a torch argument was written
     through an alias that does not bump its ``_version``; edits of NumPy arguments are seen by themselves)."""
+    # the watch slots first: clearing them waits for the library's comparison helper, which may still be reading the live
+    # buffers and the copies that are dropped below
+    eng = _cache.get("eng")
+    if eng is not None and getattr(eng, "h", None):
+        for k in range(_WATCH_SLOTS):
+            eng.set_host_watch(k)
     _cache.pop("key", None)
     _cache.pop("refs", None)
     _cache.pop("vers", None)
     _cache.pop("nm", None)
     _cache.pop("np_copies", None)
+    _cache.pop("views", None)
     _cache.pop("all_watched", None)
     _cache.pop("bkey", None)
     _cache.pop("bleaves", None)
@@ -186,10 +218,6 @@ def invalidate():
     _cache.pop("bns", None)
     _cache["resident"] = None
     _cache["bresident"] = None
-    eng = _cache.get("eng")
-    if eng is not None and getattr(eng, "h", None):
-        for k in range(_WATCH_SLOTS):
-            eng.set_host_watch(k)
 
 
 def release():
@@ -201,9 +229,10 @@ def release():
     invalidate()
 
 
-def _engine_for(args, n, m, device):
+def _engine_for(args, n, m, device, compare_now=False):
     """The cached engine with the window given by ``args`` = (imu_meas, landmarks, landmarks_xyz, ii, time_idx,
-    intrinsics, confidences) on the device."""
+    intrinsics, confidences) on the device.  ``compare_now``: the caller's device call does not evaluate the library's host
+    watch (``vba_run_schedule``: :func:`BA_window`), so the watched buffers are compared here, before it."""
     eng = _cache.get("eng")
     if eng is None or eng.n_max < n or eng.m_max < m or eng.device != device:
         if eng is not None:
@@ -214,7 +243,7 @@ def _engine_for(args, n, m, device):
     if _cache.get("nm") == (n, m) and _same_objects(args):
         # ndarray contents: compared by the library while the device works (resident calls) -- if every ndarray has a watch slot
         # (contiguous, at most 8 of them); else here and now
-        if _cache.get("all_watched") or _numpy_unchanged(args):
+        if (_cache.get("all_watched") and not compare_now) or _numpy_unchanged(args):
             return eng
     key = (n, m) + tuple(_token(a) for a in args)
     if _cache.get("key") != key or not _numpy_unchanged(args):
@@ -233,22 +262,25 @@ def _engine_for(args, n, m, device):
         eng.upload_observations(xyz, uv, conf, ii_, n)
         eng.upload_window(K, cum, t)
         _cache["key"] = key
-        _cache["np_copies"] = tuple(a.copy() if isinstance(a, np.ndarray) else None for a in args)
+        _cache["np_copies"] = tuple(w.copy() if w is not None else None for w in map(_watchable, args))
         _cache["resident"] = None
     # (also when only the Python objects are new -- fresh slices of the same buffers, as the reference's driver makes them)
     _cache["nm"] = (n, m)
     _cache["refs"] = args               # keeps the buffers alive: their addresses cannot be reused while cached
     _cache["vers"] = tuple(getattr(a, "_version", None) for a in args)
     # the library compares the live ndarrays with the copies that were uploaded during every resident call
-    slot, all_watched = 0, True
+    slot, all_watched, views = 0, True, []
     for a, c in zip(args, _cache["np_copies"]):
         if c is None:
             continue
+        a = _watchable(a)
+        views.append(a)
         if slot < _WATCH_SLOTS and a.flags.c_contiguous and c.flags.c_contiguous:
             eng.set_host_watch(slot, a, c)
             slot += 1
         else:
             all_watched = False         # (a strided view: compared on the Python side before every call instead)
+    _cache["views"] = views             # (the ndarray views of watched torch tensors stay alive with the watch)
     for k in range(slot, _WATCH_SLOTS):
         eng.set_host_watch(k)
     _cache["all_watched"] = all_watched
@@ -591,7 +623,8 @@ def BA_window(iters, initializes, states, velocities, imu_meas, landmarks, landm
         BA_window.last = dict(n_trials=ntr, flags=flags)
         return (st, velocities, lams, hs)
     n = _shape_of(states)
-    eng = _engine_for((imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences), n, _rows(landmarks), device)
+    # (vba_run_schedule does not evaluate the host watch: an ndarray edited in place since the upload is looked for here)
+    eng = _engine_for((imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences), n, _rows(landmarks), device, compare_now=True)
     if not _take_resident(states, lamda_init, False):
         eng.set_states(_np(states)[0], float(lamda_init))
     eng.run_schedule(list(iters), list(initializes))

@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import frames, quat
-from .synth import INTRINSICS, project
+from .synth import INTRINSICS, quat_to_matrix
 
 NUM_ITERS = 20          # od_pipe.py:918
 KNOT_PERIOD = 1000      # od_pipe.py:216-225
@@ -101,8 +101,14 @@ def prepare_window(detections, orbit_np, intrinsics=None, dt=1.0) -> Window:
     uv = np.asarray(f["uv"], dtype=np.float64)
     conf = np.asarray(f["confidence"], dtype=np.float64)
     intr_rows = np.repeat(intr[None], len(pos_gt), axis=0)
-    # outlier mask from the reprojection at ground truth (od_pipe.py:928-930)
-    proj = project(pos_gt[ii], quat_gt[ii], xyz, intr)
+    # outlier mask from the reprojection at ground truth (od_pipe.py:928-930): the rotation of a pose is formed once per pose and
+    # gathered per row (the same operations per element as forming it per row -- ~100 rows share a pose)
+    R = quat_to_matrix(quat_gt / np.linalg.norm(quat_gt, axis=-1, keepdims=True))
+    pc = np.einsum("kji,kj->ki", R[ii], xyz - pos_gt[ii])
+    z = np.maximum(pc[:, 2], 0.1)
+    proj = np.empty((len(ii), 2))
+    proj[:, 0] = intr[0] * pc[:, 0] / z + intr[2]
+    proj[:, 1] = intr[1] * pc[:, 1] / z + intr[3]
     mask = ((proj[:, 0] > 0) & (proj[:, 1] > 0) & (proj[:, 0] < 4700) & (proj[:, 1] < 2600)
             & (np.linalg.norm(proj - uv, axis=-1) < 1000) & (conf > 0.8))
     # remove_elems (od_pipe.py:253-288): keep poses that still own an observation, and knots
@@ -118,17 +124,31 @@ def prepare_window(detections, orbit_np, intrinsics=None, dt=1.0) -> Window:
     T = len(pos_gt)
     gaps = np.diff(time_idx)
     max_gap = int(gaps.max()) if T > 1 else 1
+    # The per-second increments exp(dt * omega) are formed for every second at once; their product over each gap is a serial
+    # recurrence per pose (up to 1000 factors) and runs in the library's host code (vba_host_gap_rotations: every product and sum
+    # rounded as the array expression rounds it -- the bits of the reference's cum_rots[:, :, -1]).
     omega = quat.omega_from_quats(quat_full, dt)
-    cum = np.zeros((T, 4))
-    cum[:, 3] = 1.0
-    for j in range(max_gap):
-        act = np.nonzero(gaps > j)[0]
-        step = quat.qexp(dt * omega[time_idx[act] + j])
-        cum[act] = step if j == 0 else quat.qmul(cum[act], step)
+    cum = gap_rotations(quat.qexp(dt * omega), time_idx)
     return Window(time_idx=time_idx, ii=ii_new, landmarks_uv=uv[mask], landmarks_xyz=xyz[mask],
                   confidences=conf[mask], intrinsics=intr_rows, poses_gt=np.concatenate([pos_gt, quat_gt], 1),
                   vel_gt_full=vel_full, quat_gt_full=quat_full, omega_gt=omega, cumrot_last=cum,
                   max_gap=max_gap, mask=mask, extras=dict(proj_gt=proj[mask]))
+
+
+def _lib_host():
+    from . import _lib
+    return _lib, _lib.load()
+
+
+def gap_rotations(rot, time_idx):
+    """cum[i] = rot[t_i] (x) rot[t_i + 1] (x) ... (x) rot[t_{i+1} - 1], identity for the last pose (reference
+    ``precompute_cum_rotations`` BA_utils.py:278-288 as the driver uses it, od_pipe.py:945-961; only ``[..., -1]`` is read)."""
+    _lib, lib = _lib_host()
+    rot = np.ascontiguousarray(rot, dtype=np.float64)
+    t = np.ascontiguousarray(time_idx, dtype=np.int64)
+    cum = np.empty((t.size, 4))
+    _lib.check(lib.vba_host_gap_rotations(_lib.as_pd(rot), rot.shape[0], _lib.as_pi64(t), t.size, _lib.as_pd(cum)), lib)
+    return cum
 
 
 def initial_guess(win: Window, seed=0):
@@ -157,18 +177,16 @@ def next_batch(ii, time_idx, i):
     Reference ``identify_next_batch_new`` od_pipe.py:898-905.  Returns
     ``(t_final, i_final, seq_end)``.
     """
-    t_obs = time_idx[ii]
-    contiguous = 0
-    for j in range(i + 1, len(ii)):
-        gap = t_obs[j] - t_obs[j - 1]
-        if gap < 100:
-            contiguous += 1
-        if gap > 200 and contiguous > 4:
-            return int(ii[j - 1]) + 1, j, False
+    gaps = np.diff(time_idx[ii[i:]])                    # gaps[k] = t_obs[i + 1 + k] - t_obs[i + k]
+    contiguous = np.cumsum(gaps < 100)                  # (a gap cannot be both < 100 and > 200: counting first is the loop's order)
+    cut = np.flatnonzero((gaps > 200) & (contiguous > 4))
+    if cut.size:
+        j = i + 1 + int(cut[0])
+        return int(ii[j - 1]) + 1, j, False
     return int(ii[-1]) + 1, len(ii), True
 
 
-def propagate_between_batches(state, velocity, omega, tdiff, duration, rk4_step):
+def propagate_between_batches(state, velocity, omega, tdiff, duration, rk4_step=None):
     """Dead-reckon the last estimate across a gap (reference ``propagate_dynamics_init``
     BA_utils.py:114-129): ``tdiff`` steps to reach the first new frame, then ``duration``
     more, returning the per-second states from the first new frame on, [duration+1, 10].
@@ -177,15 +195,30 @@ def propagate_between_batches(state, velocity, omega, tdiff, duration, rk4_step)
     tensor the driver carries beside the states (od_pipe.py:1011), which ``BA`` hands back untouched
     (BA_filtering.py:98) -- not from the velocity inside the state vector.
     """
-    x = np.concatenate([state[:3], velocity])
-    q = state[3:7].copy()
-    out = []
-    for k in range(tdiff + duration):
-        x = rk4_step(x)
-        q = quat.qmul(q, quat.qexp(1.0 * omega[k]))
-        if k >= tdiff - 1:
-            out.append(np.concatenate([x[:3], q, x[3:]]))
-    return np.stack(out)
+    K = tdiff + duration
+    if rk4_step is not None:        # the interpreted loop (kept for the comparison in tests/test_od_pipe_host.py)
+        x = np.concatenate([state[:3], velocity])
+        q = state[3:7].copy()
+        out = []
+        for k in range(K):
+            x = rk4_step(x)
+            q = quat.qmul(q, quat.qexp(1.0 * omega[k]))
+            if k >= tdiff - 1:
+                out.append(np.concatenate([x[:3], q, x[3:]]))
+        return np.stack(out)
+    # both chains are serial recurrences of up to ~1000 steps: in the library's host code (vba_host_orbit_chain: the RK4 of the
+    # device path's host build; vba_host_quat_chain: the bits of the array expression)
+    _lib, lib = _lib_host()
+    x0 = np.ascontiguousarray(np.concatenate([state[:3], velocity]), dtype=np.float64)
+    xs = np.empty((K, 6))
+    _lib.check(lib.vba_host_orbit_chain(_lib.as_pd(x0), K, _lib.as_pd(xs)), lib)
+    rot = np.ascontiguousarray(quat.qexp(1.0 * np.asarray(omega[:K], dtype=np.float64)))
+    q0 = np.ascontiguousarray(state[3:7], dtype=np.float64)
+    qs = np.empty((K, 4))
+    _lib.check(lib.vba_host_quat_chain(_lib.as_pd(q0), _lib.as_pd(rot), K, _lib.as_pd(qs)), lib)
+    out = np.empty((duration + 1, 10))
+    out[:, :3], out[:, 3:7], out[:, 7:] = xs[tdiff - 1:, :3], qs[tdiff - 1:], xs[tdiff - 1:, 3:]
+    return out
 
 
 class SequenceRun:
@@ -220,7 +253,6 @@ class SequenceRun:
     def next_patch(self):
         """Arguments of the next batch's BA calls, or None when the sequence has ended."""
         import torch
-        from .synth import rk4_step
         if self.seq_end:
             return None
         win, time_idx, ii = self.win, self.time_idx, self.ii
@@ -235,7 +267,7 @@ class SequenceRun:
             omega = win.omega_gt[time_idx[t_init - 1]:time_idx[t - 1]]
             tdiff = int(time_idx[t_init] - time_idx[t_init - 1])
             duration = int(time_idx[t - 1] - time_idx[t_init])
-            prop = propagate_between_batches(self.states_t[0, -1].numpy(), self.vel_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
+            prop = propagate_between_batches(self.states_t[0, -1].numpy(), self.vel_t[0, -1].numpy(), omega, tdiff, duration)
             sel = time_idx[t_init:t] - time_idx[t_init]
             prop = torch.from_numpy(prop[sel])[None]
             self.states_t = torch.cat([self.states_t, prop], dim=1)
@@ -250,7 +282,6 @@ class SequenceRun:
     def finish_patch(self, states_t, vel_t):
         """The estimate after the batch's BA calls: bookkeeping behind the loop (od_pipe.py:1041-1060)."""
         import torch
-        from .synth import rk4_step
         win, time_idx, t, T = self.win, self.time_idx, self.t, self.T
         self.states_t, self.vel_t = states_t, vel_t
         self.patch += 1
@@ -261,7 +292,7 @@ class SequenceRun:
             omega = win.omega_gt[time_idx[t_init - 1]:time_idx[t - 1]]
             tdiff = int(time_idx[t_init] - time_idx[t_init - 1])
             duration = int(time_idx[t - 1] - time_idx[t_init])
-            prop = propagate_between_batches(states_t[0, -1].numpy(), vel_t[0, -1].numpy(), omega, tdiff, duration, rk4_step)
+            prop = propagate_between_batches(states_t[0, -1].numpy(), vel_t[0, -1].numpy(), omega, tdiff, duration)
             prop = torch.from_numpy(prop[time_idx[t_init:t] - time_idx[t_init]])
             self.errors.append((prop[:, :3] - self.poses_gt[t_init:t, :3]).norm(dim=-1))
             self.times.append(time_idx[-prop.shape[0]:])
@@ -279,22 +310,46 @@ def _load_sequence(detections, orbit_np, orbit_file_name, detections_file_name):
     return detections, orbit_np
 
 
+class _Clock:
+    """Wall time by phase of a driver run (``timing`` argument of the drivers): seconds added to ``prep`` (data preparation of a
+    sequence: read, ground truth, mask, IMU, initial guess), ``ba`` (inside the BA calls, uploads and result copies included) and
+    ``bookkeeping`` (batch cut, dead reckoning across the gap, error records), plus the number of ``ba_calls``."""
+
+    def __init__(self, timing):
+        import time
+        self.t, self.now = timing, time.perf_counter
+        if timing is not None:
+            for k in ("prep", "ba", "bookkeeping", "ba_calls"):
+                timing.setdefault(k, 0)
+
+    def __call__(self, key, t0, calls=0):
+        if self.t is not None:
+            self.t[key] += self.now() - t0
+            self.t["ba_calls"] += calls
+        return self.now()
+
+
 def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, detections_file_name=None,
-                      ba=None, num_iters=NUM_ITERS, record=None):
+                      ba=None, num_iters=NUM_ITERS, record=None, timing=None):
     """Drop-in for the reference's ``streaming_version`` (od_pipe.py:911-1062).
 
     ``ba`` defaults to the HIP-backed :func:`vinsat_amd.ba.BA`; tests may inject another
     callable with the reference signature.  With the default ``ba`` and no ``record`` list the ``num_iters`` calls
     of a batch are issued as one chained device call (:func:`vinsat_amd.ba.BA_window`, same bits).
+    ``timing`` (a dict) receives the wall time by phase (:class:`_Clock`).
     """
     ba_window = None
     if ba is None:
         from .ba import BA as ba
         if record is None:
             from .ba import BA_window as ba_window
+    clk = _Clock(timing)
+    t0 = clk.now()
     run = SequenceRun(*_load_sequence(detections, orbit_np, orbit_file_name, detections_file_name))
+    t0 = clk("prep", t0)
     while True:
         p = run.next_patch()
+        t0 = clk("bookkeeping", t0)
         if p is None:
             break
         states_t, vel_t, lam = p["states"], p["velocities"], p["lam"]
@@ -308,26 +363,34 @@ def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, dete
                                               p["poses_gt"], initialize=inits[it])
             if record is not None:
                 record.append(dict(patch=run.patch, iter=it, states=states_t.clone(), lamda=lam))
+        t0 = clk("ba", t0, num_iters)
         run.finish_patch(states_t, vel_t)
-    return run.result()
+    out = run.result()
+    clk("bookkeeping", t0)
+    return out
 
 
-def streaming_batched(sequences, num_iters=NUM_ITERS, ba_window=None, record=None):
+def streaming_batched(sequences, num_iters=NUM_ITERS, ba_window=None, record=None, timing=None):
     """Many sequences at once -- the reference's outer loop over sequence files (od_pipe.py:1069-1077) turned into the batch
     dimension of ``BA``: round r runs batch r of EVERY sequence that still has one as the windows of ONE ragged handle
     (:func:`vinsat_amd.ba.BA_window` on lists: every kernel launch covers all of them), sequences that have ended drop out.
 
     ``sequences``: list of ``(detections, orbit_np)`` pairs.  Returns the list of ``streaming_version`` results.  With equal
     handle settings (``vinsat_amd.ba.configure``) every sequence gets the bits of its own ``streaming_version`` run.
-    ``record`` (a list) receives ``dict(round, sequence, states, lamda)`` after every round.
+    ``record`` (a list) receives ``dict(round, sequence, states, lamda)`` after every round; ``timing`` (a dict) the wall time
+    by phase (:class:`_Clock`).
     """
     if ba_window is None:
         from .ba import BA_window as ba_window
+    clk = _Clock(timing)
+    t0 = clk.now()
     runs = [SequenceRun(det, orb) for det, orb in sequences]
+    t0 = clk("prep", t0)
     rnd = 0
     while True:
         live = [(k, r, r.next_patch()) for k, r in enumerate(runs)]
         live = [(k, r, p) for k, r, p in live if p is not None]
+        t0 = clk("bookkeeping", t0)
         if not live:
             break
         # batch 0 of a sequence is the only one with landmark-only calls (od_pipe.py:1038): all sequences are in the same
@@ -346,9 +409,12 @@ def streaming_batched(sequences, num_iters=NUM_ITERS, ba_window=None, record=Non
                                       [p["imu"] for p in ps], [p["uv"] for p in ps], [p["xyz"] for p in ps], [p["ii"] for p in ps],
                                       [p["time_idx"] for p in ps], [p["intr"] for p in ps], [p["conf"] for p in ps],
                                       [p["lam"] for p in ps])
+        t0 = clk("ba", t0, num_iters * len(ps))
         for (k, r, p), s_new, l_new in zip(live, st, lam):
             if record is not None:
                 record.append(dict(round=rnd, sequence=k, states=s_new.clone(), lamda=l_new))
             r.finish_patch(s_new, p["velocities"])
         rnd += 1
-    return [r.result() for r in runs]
+    out = [r.result() for r in runs]
+    clk("bookkeeping", t0)
+    return out
