@@ -223,6 +223,96 @@ def test_chained_schedule_replayed_as_a_graph_gives_the_bits_of_kernel_by_kernel
     _close_to_reference(got[4][0][0], g["states_out_19"][0], 19)
 
 
+def test_long_gap_window_chained_and_replayed_has_the_bits_of_call_by_call_steps():
+    """The second batch of the two-pass sequence (25 poses, gaps of 935 and 510 s: the long edges are propagated parallel in time by
+    kernels of their own, vba_long.hip) through vba_run_schedule -- first pass captured, second replayed as a graph -- against a
+    handle that steps call by call, and against the reference's own run of that batch (gap.npz, calls 20 .. 39)."""
+    from vinsat_amd import od_pipe, synth
+    from vinsat_amd.engine import BAEngine
+    g = load_golden("gap")
+    win = od_pipe.prepare_window(*synth.make_two_pass_sequence())
+    n, m = win.time_idx.size, win.ii.size
+    # the driver's input of the second batch: the first batch's result + dead reckoning across the gap
+    from vinsat_amd import ba as ba_mod
+    run = od_pipe.SequenceRun(*synth.make_two_pass_sequence())
+    p = run.next_patch()
+    st, vel, lam, _ = ba_mod.BA_window(range(20), [k < 10 for k in range(20)], p["states"], p["velocities"], p["imu"], p["uv"], p["xyz"],
+                                       p["ii"], p["time_idx"], p["intr"], p["conf"], p["lam"])
+    run.finish_patch(st, vel)
+    st0 = run.next_patch()["states"][0].numpy().copy()
+    ba_mod.release()
+    assert st0.shape == (n, 10)
+    iters, inits = [int(x) for x in g["iters"][20:]], [bool(x) for x in g["initialize"][20:]]
+    assert not any(inits) and len(iters) == 20
+
+    def engine():
+        e = BAEngine(n, m)
+        e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+        e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+        return e
+    e = engine()
+    outs = []
+    for rep in range(3):
+        e.set_states(st0, float(g["lamda_in"][20]))
+        e.run_schedule(iters, inits)
+        outs.append(e.get_states())
+    assert e.schedule_graph_stats() == (1, 2)
+    e.close()
+    e = engine()
+    e.set_states(st0, float(g["lamda_in"][20]))
+    for it, init in zip(iters, inits):
+        e.step(it, init)
+    ref = e.get_states()
+    e.close()
+    for o in outs:
+        assert np.array_equal(o[0], ref[0]) and o[1] == ref[1] and np.array_equal(o[2], ref[2])
+    assert rel_err(ref[0], g["states_out_39"][0]) < 1e-6 and ref[1] == g["lamda_out"][39]
+    # the chain through a long gap is carried from the trial kernel to the next call's factor when it started from the very bits of
+    # that call's state; a handle that has never seen the states finds the chain itself -- same function, same bits: every call
+    # of a short chained run against a FRESH handle fed the states and damping the call in front left
+    e = engine()
+    e.set_states(st0, float(g["lamda_in"][20]))
+    st, lam = st0, float(g["lamda_in"][20])
+    for it in iters[:4]:
+        e.step(it, False)
+        want = e.get_states()
+        f = engine()
+        got = f.iterate(it, False, lam, st)
+        f.close()
+        assert np.array_equal(got[0], want[0]) and got[1] == want[1] and np.array_equal(got[2], want[2]), it
+        st, lam = want[0], want[1]
+    e.close()
+
+
+@pytest.mark.parametrize("step", [1, 2, 3], ids=["end-capture", "instantiate", "first-launch"])
+def test_a_graph_that_cannot_be_made_falls_back_to_kernel_by_kernel_launches(step):
+    """A capture that cannot be ended, instantiated or launched has executed nothing: the handle gives up on graphs and enqueues
+    the pass again for real (VBA_GRAPH_FAIL_INJECT pretends the failure; read once per process, hence the child process)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "from conftest import load_golden, golden_inputs\n"
+        "from vinsat_amd.engine import BAEngine\n"
+        "g = load_golden('c2'); inp = golden_inputs(g)\n"
+        "n, m = inp['K'].shape[0], inp['xyz'].shape[0]\n"
+        "e = BAEngine(n, m)\n"
+        "e.upload_observations(inp['xyz'], inp['uv'], inp['conf'], inp['ii'], n); e.upload_window(inp['K'], inp['cumrot'], inp['time_idx'])\n"
+        "its, ins = [int(x) for x in g['iters']], [bool(x) for x in g['initialize']]\n"
+        "outs = []\n"
+        "for rep in range(2):\n"
+        "    e.set_states(g['states0'][0], 1e-4); e.run_schedule(its, ins); outs.append(e.get_states()[0])\n"
+        "assert e.schedule_graph_stats() == (0, 0), e.schedule_graph_stats()\n"
+        "ref = g['states_out_19'][0]\n"
+        "assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0] - ref).max() / np.abs(ref).max() < 1e-6\n"
+        "print('fallback ok')\n" % (ROOT, ROOT))
+    env = dict(os.environ, VBA_GRAPH_FAIL_INJECT=str(step))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "fallback ok" in p.stdout, p.stderr[-2000:]
+
+
 @pytest.mark.parametrize("fusion", [14, 12])
 def test_trial_kernel_tiles_per_block_do_not_change_a_bit(fusion):
     """vba_set_trial_tiles: an observation block of the plain latency-mode trial kernel takes 1, 2, 4 or 8 tiles of 256 rows and

@@ -104,6 +104,30 @@ def test_more_long_edges_than_slots_fall_back_to_the_serial_walk():
     eng.close()
 
 
+def test_a_window_of_a_big_handle_runs_out_of_chain_room_and_walks_the_rest():
+    """Handles of more than 256 windows keep 512 chain states per window and parity: four 1000 s gaps fit, the fifth and sixth take
+    the ordinary serial lanes.  Same factor either way (against the oracle)."""
+    from vinsat_amd.engine import BAEngine
+    n = 8
+    win = _window(n)
+    steps = np.array([1000, 1000, 1000, 1000, 1000, 1000, 5], dtype=np.int64)
+    t = np.concatenate([[10], 10 + np.cumsum(steps)]).astype(np.int64)
+    eng = BAEngine(n, win.ii.size, windows=257, mode=0)
+    small = _window(n, seed=6)
+    for w in range(257):
+        src = win if w == 0 else small
+        eng.upload_observations(src.landmarks_xyz, src.landmarks_uv, src.confidences, src.ii, n, window=w)
+        eng.upload_window(src.intrinsics, src.cumrot_last, t if w == 0 else src.time_idx, window=w)
+        eng.set_states(src.states_gt, 1e-3, window=w)
+    eng.step(12, False)
+    r, E, F = O.orbit_factor(win.states_gt, t, jacobian=True)
+    Phi = eng.debug("Phi")[:-1]
+    for i in range(n - 1):
+        assert rel_err(D[:, None] * Phi[i], np.concatenate([E[i][:, 0:3], E[i][:, 6:9]], -1)) < 1e-11, i
+    assert np.abs(eng.debug("r_pred")[:, :6] - r).max() < 1e-9
+    eng.close()
+
+
 @pytest.mark.parametrize("mode", [1, 0], ids=["latency-kernels", "bandwidth-kernels"])
 def test_long_edges_in_a_batch_have_the_bits_of_the_window_alone(mode):
     """Windows with different numbers of long edges on one handle (the extra blocks of a window without one write zeros),

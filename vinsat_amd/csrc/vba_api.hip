@@ -14,6 +14,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>      // types only: the library is resolved at run time (vba_sh_comm_init), never linked
 
 #include "../../include/vinsat_ba.h"
@@ -62,7 +63,7 @@ struct vba_context {
     DevView V{};
     // mutable device pointers (DevView holds const views of some)
     int *d_n = nullptr, *d_m = nullptr, *d_steps = nullptr;
-    int *d_long_idx = nullptr, *d_n_long = nullptr;     // long edges of every window (vba_long.hip)
+    int *d_long_idx = nullptr, *d_n_long = nullptr, *d_long_off = nullptr;     // long edges of every window (vba_long.hip)
     std::vector<int> n_long;                // ... and how many each window has (host copy; DevView::nblk_long is their maximum)
     // per-observation weights and per-pose normal equations exist per call parity (DevView points at the slot of the call):
     // the accumulation of call c + 1 starts before the accept test of call c is known, whose later trials still read them
@@ -137,7 +138,9 @@ struct vba_context {
     bool fusion_auto = true;                // the mask is the library's own choice (vba_set_fusion not called)
     // the first passes of the last few chained schedules as graphs (vba_run_schedule), each with what it was made for; most recently
     // used first, at most kGraphCache of them (a driver alternates between a handful of schedules: the 20-call loop, its two phases)
-    struct GraphEntry { std::vector<unsigned long long> key; hipGraphExec_t exec = nullptr; };
+    // key: a hash per call's view (the quick reject); views: the bytes of those views, compared exactly on a key match (a 64-bit hash
+    // collision would replay another schedule's launches silently; ncalls x sizeof(DevView) of memcmp is ~1 us)
+    struct GraphEntry { std::vector<unsigned long long> key; std::vector<unsigned char> views; hipGraphExec_t exec = nullptr; };
     std::vector<GraphEntry> graphs;
     bool graph_broken = false;              // capture or launch failed once: kernel by kernel from then on
     bool graph_enabled = true;              // vba_set_schedule_graph
@@ -168,6 +171,7 @@ struct vba_context {
         std::atomic<unsigned long long> done_seq{0};    // the request `changed` answers
         bool changed = false;
         bool started = false;
+        pid_t owner = 0;                    // the process the helper thread lives in (a forked child inherits `started`, not the thread)
     } ww;
     // vba_set_chain_profile: HIP events at the class boundaries (accumulate | solve | trial) of every call of a chained schedule
     struct ChainProf {
@@ -378,7 +382,8 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     const int nblk_pred = (int)((N * kDynLanes + 255) / 256);
     const int pred_stride = nblk_pred + kLongCap;
     need(W * 2 * pred_stride * 8); need(W * 2 * pred_stride * 8); need(W * 81 * 8);
-    need(W * kLongCap * 4); need(W * 4);
+    const size_t long_pool_cap = windows <= kLongPoolFewWindows ? kLongPoolFew : kLongPool;
+    need(W * kLongCap * 4); need(W * 4); need(W * kLongCap * 4); need(W * 2 * long_pool_cap * 6 * 8);
     need(W * N * 36 * 8); need(W * N * 6 * 8);
     need(W * 2 * M * 8); need(2 * W * M * 8); need(W * 2 * M * 8); need(W * nblk_obs * 8); need(W * trial_stride * 8); need(W * nblk_obs * 8);
     need(W * kHistStride * 4);
@@ -433,6 +438,9 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     V.pred_stride = pred_stride;
     V.long_idx = h->d_long_idx = A.take<int>(W * kLongCap); V.n_long = h->d_n_long = A.take<int>(W);
     V.nblk_long = 0;
+    V.long_off = h->d_long_off = A.take<int>(W * kLongCap);
+    V.long_pool = A.take<double>(W * 2 * long_pool_cap * 6);
+    V.long_pool_cap = (int)long_pool_cap;
     V.lastD = A.take<double>(W * 81);
     V.intr = h->d_intr = A.take<double>(W * N * 4);
     V.cumrot = h->d_cumrot = A.take<double>(W * N * 4);
@@ -479,7 +487,7 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
     {   // every device array a kernel may touch must have been carved: a null here would fault on the GPU
         const void* must[] = {V.n, V.m, V.sc, V.ox, V.oy, V.oz, V.ou, V.ov, V.oconf, V.opose, V.pose_ptr, V.states,
                               V.states_new, V.states_prev, V.intr, V.cumrot, V.steps, V.prior_H, V.prior_x, V.absr, V.wraw, V.ckeys, V.part_init, V.part_next,
-                              V.part_pred, V.part_prior, V.lastD, V.long_idx, V.n_long,
+                              V.part_pred, V.part_prior, V.lastD, V.long_idx, V.n_long, V.long_off, V.long_pool,
                               V.part_trial, V.hist, V.Hraw, V.braw, V.xhat, V.Phi, V.rorb, V.fatt, V.qgrad, V.Hd, V.Hu, V.Hl,
                               V.bands, V.rhs, V.Xs, V.zs, V.dpose, V.csol, V.cL, V.cR, V.rXs, V.rzs, V.rx, V.csol2, V.cL2, V.cR2, V.rx2, V.res_flags};
         bool ok = A.used <= A.size;
@@ -507,8 +515,8 @@ int vba_create_mode(int device, int windows, int n_max, int64_t m_max, int mode,
         hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_up[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_up[1], hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_up[0], std::max(obs_stride, 9 * N + 96) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_up[1], std::max(obs_stride, 9 * N + 96) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_up[0], std::max(obs_stride, 9 * N + 160) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_up[1], std::max(obs_stride, 9 * N + 160) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_stage, ((size_t)n_max * 10 + 1) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_back, (size_t)n_max * 10 * sizeof(double) + sizeof(WinScalars), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&h->h_head, W * sizeof(WinHead), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -873,10 +881,19 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
     // long gaps (vba_long.hip): the first kLongCap edges of more than kLongGap steps are marked by a NEGATIVE step count and
     // listed; the kernels that walk the chain leave them to k_long_factor / k_long_trial (with the hop integrator the sign is
     // ignored and nothing is long)
-    int long_list[kLongCap + 1];
-    int nl = 0;
+    // ... each with room for its chain (header + G sub-chunk start states) in the window's pool; a gap the pool has no room for
+    // stays an ordinary edge
+    int long_list[2 * kLongCap + 1];
+    int nl = 0, pool_used = 0;
     for (int i = 0; i + 1 < n && nl < kLongCap; ++i)
-        if (steps[i] > kLongGap) { long_list[nl++] = i; steps[i] = -steps[i]; }
+        if (steps[i] > kLongGap) {
+            const int need_states = 2 + long_plan(steps[i]).G;
+            if (pool_used + need_states > h->V.long_pool_cap) continue;
+            long_list[kLongCap + 1 + nl] = pool_used;
+            pool_used += need_states;
+            long_list[nl++] = i;
+            steps[i] = -steps[i];
+        }
     long_list[kLongCap] = nl;
     const size_t pb = (size_t)window * h->n_max;
     const int ub = h->up_next;
@@ -886,13 +903,22 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
     std::memcpy(blk, intrinsics, (size_t)n * 32);
     std::memcpy(blk + (size_t)n * 4, cumrot_last, (size_t)n * 32);
     std::memcpy(blk + (size_t)n * 8, steps.data(), (size_t)n * 4);
-    double* lblk = blk + (size_t)n * 8 + (size_t)(n + 1) / 2;      // (the staging block holds max(obs_stride, 9 n_max + 96) doubles)
+    double* lblk = blk + (size_t)n * 8 + (size_t)(n + 1) / 2;      // (the staging block holds max(obs_stride, 9 n_max + 160) doubles)
     std::memcpy(lblk, long_list, sizeof(long_list));
     HIPCHK(hipMemcpyAsync(h->d_intr + pb * 4, blk, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_cumrot + pb * 4, blk + (size_t)n * 4, (size_t)n * 32, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_steps + pb, blk + (size_t)n * 8, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    if (nl) HIPCHK(hipMemcpyAsync(h->d_long_idx + (size_t)window * kLongCap, lblk, (size_t)nl * 4, hipMemcpyHostToDevice, h->stream));
+    if (nl) {
+        HIPCHK(hipMemcpyAsync(h->d_long_idx + (size_t)window * kLongCap, lblk, (size_t)nl * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_long_off + (size_t)window * kLongCap, reinterpret_cast<const int*>(lblk) + kLongCap + 1, (size_t)nl * 4,
+                              hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(hipMemcpyAsync(h->d_n_long + window, reinterpret_cast<const int*>(lblk) + kLongCap, 4, hipMemcpyHostToDevice, h->stream));
+    // (the carried chains of the window's long edges belong to the steps that were just replaced: all ones = NaN start states, which
+    // no state ever equals)
+    if (nl || h->n_long[window])
+        HIPCHK(hipMemsetAsync(h->V.long_pool + (size_t)window * 2 * h->V.long_pool_cap * 6, 0xFF,
+                              (size_t)2 * h->V.long_pool_cap * 6 * sizeof(double), h->stream));
     HIPCHK(hipEventRecord(h->ev_up[ub], h->stream));
     h->n_long[window] = nl;
     h->V.nblk_long = h->V.hop ? 0 : *std::max_element(h->n_long.begin(), h->n_long.end());     // (the <= 100 s hops of predict_gpu: no gap is long)
@@ -1474,12 +1500,16 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     for (int guard = 0; guard <= ncalls; ++guard) {
         bool capturing = false, replayed = false;
         std::vector<unsigned long long> gkey;
+        std::vector<unsigned char> gviews;
         // (latency-mode handles only: with the second stream of the bandwidth mode forked inside it the replay measured 1 .. 2.5 % SLOWER
         // than the launches one by one, 40 .. 1024 windows)
         // (... and not while the chain profile records its events: event records inside a capture fail on this runtime, "invalid resource
         // handle" -- the class times of vba_chain_profile are those of the kernel-by-kernel launches)
-        if (!no_graph && h->graph_enabled && guard == 0 && !prof_pass && h->V.lat && !h->graph_broken && next == 0) {
+        // (... nor with the resident solve of the comparison build, vba_set_fusion bits 5 / 6: its kernels take the epoch of the launch as
+        // an argument, which a replay would freeze -- the consumers' flags would read as already set)
+        if (!no_graph && h->graph_enabled && guard == 0 && !prof_pass && h->V.lat && !h->graph_broken && next == 0 && (h->fusion & 96) == 0) {
             gkey.reserve(8 + 3 * (size_t)ncalls);
+            gviews.resize((size_t)ncalls * sizeof(DevView));
             gkey.push_back((unsigned long long)ncalls); gkey.push_back((unsigned long long)par0); gkey.push_back((unsigned long long)carry0);
             gkey.push_back((unsigned long long)emit_kind); gkey.push_back((unsigned long long)h->pivot_mode);
             gkey.push_back((unsigned long long)h->inline_select | ((unsigned long long)h->fold_enabled << 1));
@@ -1491,6 +1521,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
                 if (fold) fill_params(Vc.prev, iters[c - 1], inits[c - 1]);
                 unsigned long long hsh = 1469598103934665603ull;
                 const unsigned char* bytes = reinterpret_cast<const unsigned char*>(&Vc);
+                std::memcpy(gviews.data() + (size_t)c * sizeof(DevView), bytes, sizeof(DevView));
                 for (size_t o = 0; o + 8 <= sizeof(DevView); o += 8) {
                     unsigned long long wd;
                     std::memcpy(&wd, bytes + o, 8);
@@ -1501,7 +1532,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             }
             size_t hit = h->graphs.size();
             for (size_t k = 0; k < h->graphs.size(); ++k)
-                if (h->graphs[k].key == gkey) { hit = k; break; }
+                if (h->graphs[k].key == gkey && h->graphs[k].views == gviews) { hit = k; break; }
             if (hit < h->graphs.size()) {
                 if (hit != 0) std::rotate(h->graphs.begin(), h->graphs.begin() + hit, h->graphs.begin() + hit + 1);     // most recently used first
                 if (hipGraphLaunch(h->graphs[0].exec, s) == hipSuccess) { replayed = true; h->graph_replays++; }
@@ -1523,6 +1554,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             }
         } capture_guard{s, &capturing};
         // speculative part: calls next .. ncalls-1, one trial each
+        auto enqueue_pass = [&]() -> int {
         for (int c = next; c < ncalls && !replayed; ++c) {
             const bool fold = c > next && emit_kind == 2 && h->fold_enabled;       // call c-1 of this pass left its decision to this call's warm select
             const CallSpec q = spec(c, fold);
@@ -1545,14 +1577,27 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             const bool next_folds = c + 1 < ncalls && emit_kind == 2 && h->fold_enabled;
             if (!next_folds) launch_decide(C.V, nullptr, 0, s);
         }
+        return VBA_OK;
+        };
+        if (int rc = enqueue_pass()) return rc;
         if (capturing) {
+            // A capture that cannot be ended, instantiated or launched has executed NOTHING (its kernels were only recorded): the
+            // handle gives up on graphs (graph_broken: kernel by kernel from then on) and this pass is enqueued again, for real.
+            // VBA_GRAPH_FAIL_INJECT = 1 / 2 / 3 pretends that step failed (tests/test_gpu_bench_paths.py).
+            static const int inject = std::getenv("VBA_GRAPH_FAIL_INJECT") ? std::atoi(std::getenv("VBA_GRAPH_FAIL_INJECT")) : 0;
             hipGraph_t g = nullptr;
             capturing = false;
-            HIPCHK(hipStreamEndCapture(s, &g));
             hipGraphExec_t exec = nullptr;
-            const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (ei != hipSuccess) return fail(VBA_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+            bool ok = hipStreamEndCapture(s, &g) == hipSuccess && g != nullptr && inject != 1;
+            if (ok) ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess && inject != 2;
+            if (g) (void)hipGraphDestroy(g);
+            if (ok && (inject == 3 || hipGraphLaunch(exec, s) != hipSuccess)) ok = false;
+            if (!ok) {
+                (void)hipGetLastError();
+                if (exec) (void)hipGraphExecDestroy(exec);
+                h->graph_broken = true;
+                if (int rc = enqueue_pass()) return rc;
+            } else {
             constexpr size_t kGraphCache = 8;
             if (h->graphs.size() >= kGraphCache) {
                 // (the evicted graph may still be executing: the stream is idle here only if the caller made it so -- wait)
@@ -1562,10 +1607,11 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
             }
             vba_context::GraphEntry ge;
             ge.key = gkey;
+            ge.views = std::move(gviews);
             ge.exec = exec;
             h->graphs.insert(h->graphs.begin(), std::move(ge));
             h->graph_captures++;
-            HIPCHK(hipGraphLaunch(exec, s));
+            }
         }
         HIPCHK(hipGetLastError());
         if (int rc = read_heads(h)) return rc;
@@ -1721,8 +1767,10 @@ static size_t host_watch_bytes(vba_handle h) {
 static bool watch_begin(vba_handle h) {
     if (host_watch_bytes(h) < 65536) return false;
     auto& W = h->ww;
+    if (W.started && W.owner != getpid()) return false;     // forked child: no helper here, the caller compares in place
     if (!W.started) {
         W.started = true;
+        W.owner = getpid();
         W.th = std::thread([h]() {
             auto& Q = h->ww;
             unsigned long long taken = 0;
@@ -1761,12 +1809,17 @@ static bool watch_end(vba_handle h, bool begun) {
 // the helper has answered every request (a wait that gave up after 20 ms may have left it comparing): before the watch list changes
 static void watch_quiesce(vba_handle h) {
     auto& W = h->ww;
-    if (!W.started) return;
+    if (!W.started || W.owner != getpid()) return;          // (a forked child has no helper to wait for)
     while (W.done_seq.load(std::memory_order_acquire) != W.seq) std::this_thread::yield();
 }
 static void watch_stop(vba_handle h) {
     auto& W = h->ww;
     if (!W.started) return;
+    if (W.owner != getpid()) {      // forked child: the thread object refers to a thread of the parent -- let go of it, never join
+        W.th.detach();
+        W.started = false;
+        return;
+    }
     {
         std::lock_guard<std::mutex> lk(W.m);
         W.quit = true;

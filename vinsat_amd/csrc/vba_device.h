@@ -19,6 +19,11 @@ constexpr int kDynLanes = 8;            // lanes per pose in the dynamics kernel
 // that walk the chain leave such an edge alone; the block sums of its residuals go into slots of their own behind the ordinary ones.
 constexpr int kLongGap = 64;
 constexpr int kLongCap = 64;
+// chain states per window and call parity: 512 (24 kB: four 1000 s edges, or more shorter ones), 4096 (196 kB: ~37 such edges) for
+// handles of up to kLongPoolFewWindows windows; a long gap the pool has no room for takes the ordinary serial walk
+constexpr int kLongPool = 512;
+constexpr int kLongPoolFew = 4096;
+constexpr int kLongPoolFewWindows = 256;
 constexpr int kHistStride = (kSelPasses + 1) * kSelBins;    // per window: digit 0 twice (call parity), digits 1..5
 constexpr int kWarmCount = 192;         // warm select: up to this many keys are ranked by counting, longer lists by radix digits
 
@@ -155,6 +160,13 @@ struct DevView {
     const int* long_idx;            // [W][kLongCap]
     const int* n_long;              // [W]
     int nblk_long;                  // largest n_long over the windows of the handle = extra blocks / slots per window; 0 with the hop integrator
+    // carried chunk states of the long edges: the trial kernel's propagation of an edge passes through the states the next call's
+    // factor needs (an accepted trial is evaluated at exactly the states the next call starts from -- the carried-keys argument,
+    // applied to dynamics): [W][2 (parity of the call that READS)][kLongPool][6]; an edge's slot = two states of header (x_hat and
+    // the start state the chain belongs to, which the reader checks) followed by its G sub-chunk start states, at long_off[w][k] (-1: no room, the factor finds its own)
+    double* long_pool;
+    const int* long_off;            // [W][kLongCap]
+    int long_pool_cap;              // states per window and parity (kLongPool, or kLongPoolFew for handles of few windows)
     // BA_reg (BA_filtering.py:100-210): per-pose prior, active when reg != 0 and the call is not landmark-only
     const double* prior_H;          // [36] hessian_state_t
     const double* prior_x;          // [6]  prior position, velocity

@@ -19,8 +19,11 @@
 // -- both kernels below call the same long_states().
 // Cost of a 935 s edge: 2 P + 2 L = 2 * 26 + 2 * 37 step times instead of 935.
 //
-// The transition matrix of a long edge is the ORDERED PRODUCT of the chunks' transition matrices (each from its converged
-// chunk-start state, six tangent lanes per chunk as in dynamics_block), multiplied pairwise in a fixed tree.
+// The transition matrix of a long edge is the ORDERED PRODUCT of the transition matrices of G <= 128 sub-chunks of ~10 steps (each
+// from its start state on the converged chain, six tangent lanes per sub-chunk as in dynamics_block), multiplied pairwise in a
+// fixed tree.  The start states are a by-product of the last fine pass -- and of the TRIAL kernel's: an accepted trial is evaluated
+// at exactly the states the next call starts from, so its chain is carried (DevView::long_pool, the carried-keys argument applied
+// to dynamics) and the next call's factor is the tangent pass and the product alone.
 //
 // Edges of at most kLongGap steps never come here: their arithmetic (and the bits of every window without a long gap) is
 // what it was.  With the hop integrator (predict_gpu's <= 100 s steps) no edge is long.
@@ -30,20 +33,6 @@
 namespace vba {
 
 namespace {
-
-struct LongPlan { int L, P; };
-
-// chunk length and count for a gap of s steps: a function of s alone (so that every kernel cuts an edge alike)
-__device__ __forceinline__ LongPlan long_plan(int s) {
-    LongPlan p;
-    // a sweep step costs ~1.7 fine steps and there are two fine passes per sweep: L ~ sqrt(1.4 s) balances them
-    int L = 1;
-    while (5 * L * L < 7 * s) ++L;
-    if (32 * L < s) L = (s + 31) / 32;
-    p.L = L;
-    p.P = (s + L - 1) / L;             // <= 32
-    return p;
-}
 
 __device__ __forceinline__ double readlane_f64(double v, int lane /*wave-uniform*/) {
     const unsigned long long b = f64_bits(v);
@@ -82,7 +71,9 @@ constexpr double kLongTol = 0x1p-45;    // a chunk's fine end state and the next
 // The iteration ends when the DEFECT of the chain is below tolerance: every chunk's fine propagation from its start state
 // lands on the next chunk's start state, i.e. the U_j are the serial chain up to that tolerance -- checked right behind the
 // fine pass, so a converged iterate costs no sweep of its own (one sweep, two fine passes for gaps up to ~1000 s).
-__device__ __forceinline__ void long_states(const double* x0, int s, const LongPlan pl, int lane, double* U /*[6]*/, double* xh /*[6]*/) {
+// subs: receives the states at the sub-chunk starts of the LAST fine pass -- subs[g * 6 .. ], g in chain order.
+__device__ __forceinline__ void long_states(const double* x0, int s, const LongPlan pl, int lane, double* U /*[6]*/, double* xh /*[6]*/,
+                                            double* subs) {
     const int P = pl.P;
     const int last_len = s - (P - 1) * pl.L;
     const int my_len = lane < P - 1 ? pl.L : (lane == P - 1 ? last_len : 0);
@@ -107,7 +98,19 @@ __device__ __forceinline__ void long_states(const double* x0, int s, const LongP
         // fine: every chunk from its current start state, in parallel
 #pragma unroll
         for (int c = 0; c < 6; ++c) F[c] = U[c];
-        for (int q = 0; q < my_len; ++q) rk4_step<false>(F, nullptr, 1.0);
+        {
+            double* rec = it > 0 ? subs + (size_t)lane * pl.nsubL * 6 : nullptr;    // (the pass behind the coarse chain is never the last)
+            int until = 0;
+            for (int q = 0; q < my_len; ++q) {
+                if (rec && q == until) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) rec[c] = F[c];
+                    rec += 6;
+                    until += pl.sub;
+                }
+                rk4_step<false>(F, nullptr, 1.0);
+            }
+        }
         if (it > 0) {       // (the coarse chain alone is never close enough)
             const double np = fmax(fmax(fabs(N[0]), fabs(N[1])), fabs(N[2])) * kLongTol;
             const double nv = fmax(fmax(fabs(N[3]), fabs(N[4])), fabs(N[5])) * kLongTol;
@@ -139,9 +142,17 @@ __device__ __forceinline__ void long_states(const double* x0, int s, const LongP
 
 }  // namespace
 
+// where the chain of long edge k of window w lives for the call of parity `par` (every long edge has a slot: an edge the window's
+// pool has no room for is not marked long, vba_upload_window)
+__device__ __forceinline__ double* long_slot(const DevView& V, int w, int par, int k) {
+    const int off = V.long_off[(size_t)w * kLongCap + k];
+    return V.long_pool + (((size_t)w * 2 + par) * V.long_pool_cap + off) * 6;
+}
+
 // The orbit residual of the long edges at the TRIAL states (BA_filtering.py:63-67): sqrt(Sigma) sum |[x_hat - p', 100 (v_hat - v')]|
 // of edge long_idx[k] into slot nblk_obs + nblk_dyn + k of part_trial (k_trial's pose-chain lanes left that edge's orbit part out
-// and kept its attitude part).  One wavefront per long edge; gated as k_trial is.
+// and kept its attitude part).  One wavefront per long edge; gated as k_trial is.  The chain it walked is left for the next call
+// (slot of the parity that reads it): x_hat, then the sub-chunk start states.
 __global__ __launch_bounds__(64) void k_long_trial(DevView V) {
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
@@ -158,22 +169,54 @@ __global__ __launch_bounds__(64) void k_long_trial(DevView V) {
     const double* sn = st + 10;
     const double x0[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
     const int s = -V.steps[sb + i];
+    double* carry = long_slot(V, w, V.par ^ 1, k);
     double U[6], x[6];
-    long_states(x0, s, long_plan(s), lane, U, x);
+    long_states(x0, s, long_plan(s), lane, U, x, carry + 12);
     if (lane == 0) {
+        // header: x_hat, then the start state this chain belongs to (what the reader checks)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { carry[c] = x[c]; carry[6 + c] = x0[c]; }
         const double r = fabs(x[0] - sn[0]) + fabs(x[1] - sn[1]) + fabs(x[2] - sn[2]) +
                          fabs((x[3] - sn[7]) * kVelCoeff) + fabs((x[4] - sn[8]) * kVelCoeff) + fabs((x[5] - sn[9]) * kVelCoeff);
         *slot = r * V.prm.sqrt_sigma;
     }
 }
 
+// The chain of the long edges at the INPUT states of a call, where the pool does not hold it already.  The slot of the call's
+// parity was written by the previous call's trial kernel; IF that chain started from the very bits of this call's state (the header
+// says which state it belongs to; a chain is a function of that state and the step count alone, and an upload of the window clears
+// the pool) there is nothing to do -- otherwise (fresh states from the host, a landmark-only call in front) one wavefront finds it.
+__global__ __launch_bounds__(64) void k_long_chain(DevView V) {
+    const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k >= V.n_long[w]) return;
+    const int i = V.long_idx[(size_t)w * kLongCap + k];
+    const size_t pb = (size_t)w * V.n_max + i;
+    const double* st = V.states + pb * 10;
+    const double x0[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
+    double* chain = long_slot(V, w, V.par, k);
+    bool same = true;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) same = same && f64_bits(chain[6 + c]) == f64_bits(x0[c]);
+    if (same) return;       // (every lane takes the same decision from the same six words)
+    const int s = -V.steps[pb];
+    double U[6], x[6];
+    long_states(x0, s, long_plan(s), lane, U, x, chain + 12);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { chain[c] = x[c]; chain[6 + c] = x0[c]; }
+    }
+}
+
 // The dynamics factor of the long edges at the INPUT states: transition matrix Phi, prediction x_hat, residual r_orbit of pose
-// long_idx[k], and sum |r_orbit| into slot nblk_pred + k of part_pred (parity of the call).  One workgroup of 256 per long edge:
-// wave 0 finds the chunk-start states, then 8 lanes per chunk (6 tangents, as dynamics_block) carry the chunk's transition matrix,
-// and the P matrices are multiplied in order, pairwise: Phi = M_{P-1} ... M_1 M_0.
-__global__ __launch_bounds__(256) void k_long_factor(DevView V) {
-    __shared__ double Us[32][6];
-    __shared__ double M[2][32][36];
+// long_idx[k], and sum |r_orbit| into slot nblk_pred + k of part_pred (parity of the call).  One workgroup of 1024 per long edge,
+// behind k_long_chain: the chain through the gap -- x_hat and the sub-chunk start states -- is in the pool; 8 lanes per sub-chunk
+// (6 tangents, as dynamics_block) carry the sub-chunk's transition matrix over ~10 steps, and the G matrices are multiplied in
+// order, pairwise, in place: Phi = M_{G-1} ... M_1 M_0.
+__global__ __launch_bounds__(1024) void k_long_factor(DevView V) {
+    __shared__ double Ssub[129][6];         // [0] = x_hat, [1 + g] = start state of sub-chunk g
+    __shared__ double M[128][36];
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
     const int k = blockIdx.x, tid = threadIdx.x;
@@ -187,71 +230,70 @@ __global__ __launch_bounds__(256) void k_long_factor(DevView V) {
     const double* st = V.states + pb * 10;
     const int s = -V.steps[pb];
     const LongPlan pl = long_plan(s);
-    if (tid < 64) {
-        const double x0[6] = {st[0], st[1], st[2], st[7], st[8], st[9]};
-        double U[6], x[6];
-        long_states(x0, s, pl, tid, U, x);
-        if (tid < pl.P) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) Us[tid][c] = U[c];
-        }
-        if (tid == 0) {
-            const double* sn = st + 10;
-            double* xh = V.xhat + pb * 6;
-            double* ro = V.rorb + pb * 6;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) xh[r] = x[r];
-            ro[0] = x[0] - sn[0];
-            ro[1] = x[1] - sn[1];
-            ro[2] = x[2] - sn[2];
-            ro[3] = (x[3] - sn[7]) * kVelCoeff;
-            ro[4] = (x[4] - sn[8]) * kVelCoeff;
-            ro[5] = (x[5] - sn[9]) * kVelCoeff;
-            *slot = fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]);
-        }
-    }
+    const double* chain = long_slot(V, w, V.par, k);
+    for (int e = tid; e < (1 + pl.G) * 6; e += 1024) (&Ssub[0][0])[e] = chain[e < 6 ? e : e + 6];
     __syncthreads();
-    {   // the chunks' transition matrices
-        const int j = tid >> 3, c = tid & 7;
-        if (j < pl.P && c < 6) {
+    if (tid == 0) {
+        const double* x = Ssub[0];
+        const double* sn = st + 10;
+        double* xh = V.xhat + pb * 6;
+        double* ro = V.rorb + pb * 6;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) xh[r] = x[r];
+        ro[0] = x[0] - sn[0];
+        ro[1] = x[1] - sn[1];
+        ro[2] = x[2] - sn[2];
+        ro[3] = (x[3] - sn[7]) * kVelCoeff;
+        ro[4] = (x[4] - sn[8]) * kVelCoeff;
+        ro[5] = (x[5] - sn[9]) * kVelCoeff;
+        *slot = fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]);
+    }
+    {   // the sub-chunks' transition matrices
+        const int g = tid >> 3, c = tid & 7;
+        if (g < pl.G && c < 6) {
+            const int j = g / pl.nsubL < pl.P - 1 ? g / pl.nsubL : pl.P - 1;      // the chunk of this sub-chunk (the tail chunk may hold fewer)
+            const int q = g - j * pl.nsubL;
+            const int clen = j < pl.P - 1 ? pl.L : s - (pl.P - 1) * pl.L;
+            const int len = clen - q * pl.sub < pl.sub ? clen - q * pl.sub : pl.sub;
             double x[6], t[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int r = 0; r < 6; ++r) x[r] = Us[j][r];
+            for (int r = 0; r < 6; ++r) x[r] = Ssub[1 + g][r];
             t[c] = 1.0;
-            const int len = j < pl.P - 1 ? pl.L : s - (pl.P - 1) * pl.L;
-            for (int q = 0; q < len; ++q) rk4_step<true>(x, t, 1.0);
+            for (int e = 0; e < len; ++e) rk4_step<true>(x, t, 1.0);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) M[0][j][6 * r + c] = t[r];
+            for (int r = 0; r < 6; ++r) M[g][6 * r + c] = t[r];
         }
     }
     __syncthreads();
-    int cnt = pl.P, cur = 0;
-    while (cnt > 1) {
-        const int half = (cnt + 1) >> 1;
-        for (int e = tid; e < half * 36; e += 256) {
+    // ordered product, in place: at stride d the matrix at 2 a d takes M[2 a d + d] * M[2 a d] (a matrix without a partner stays)
+    for (int d = 1; d < pl.G; d <<= 1) {
+        const int pairs = (pl.G + 2 * d - 1) / (2 * d);
+        double v[5];
+        int cnt = 0;
+        for (int e = tid; e < pairs * 36; e += 1024, ++cnt) {
             const int a = e / 36, rc = e % 36, r = rc / 6, c = rc % 6;
-            double v;
-            if (2 * a + 1 < cnt) {
-                const double* hi = M[cur][2 * a + 1];
-                const double* lo = M[cur][2 * a];
-                v = hi[6 * r] * lo[c];
+            const int lo = 2 * a * d, hi = lo + d;
+            if (hi < pl.G) {
+                double acc = M[hi][6 * r] * M[lo][c];
 #pragma unroll
-                for (int q = 1; q < 6; ++q) v = fma(hi[6 * r + q], lo[6 * q + c], v);
+                for (int q = 1; q < 6; ++q) acc = fma(M[hi][6 * r + q], M[lo][6 * q + c], acc);
+                v[cnt] = acc;
             } else {
-                v = M[cur][2 * a][rc];
+                v[cnt] = M[lo][rc];
             }
-            M[cur ^ 1][a][rc] = v;
         }
         __syncthreads();
-        cur ^= 1;
-        cnt = half;
+        cnt = 0;
+        for (int e = tid; e < pairs * 36; e += 1024, ++cnt) M[2 * (e / 36) * d][e % 36] = v[cnt];
+        __syncthreads();
     }
-    if (tid < 36) V.Phi[pb * 36 + tid] = M[cur][0][tid];
+    if (tid < 36) V.Phi[pb * 36 + tid] = M[0][tid];
 }
 
 void launch_long_factor(const DevView& V, hipStream_t s) {
     if (V.nblk_long <= 0 || V.hop) return;
-    hipLaunchKernelGGL(k_long_factor, dim3(V.nblk_long, V.W), dim3(256), 0, s, V);
+    hipLaunchKernelGGL(k_long_chain, dim3(V.nblk_long, V.W), dim3(64), 0, s, V);
+    hipLaunchKernelGGL(k_long_factor, dim3(V.nblk_long, V.W), dim3(1024), 0, s, V);
 }
 
 void launch_long_trial(const DevView& V, hipStream_t s) {

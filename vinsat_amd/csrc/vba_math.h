@@ -287,6 +287,26 @@ VBA_HD void propagate_gap_multi(double* x, double (*t)[6], int steps, int hop) {
     if (rem) rk4_step_multi<NT>(x, t, (double)rem);
 }
 
+// How a LONG gap of s one-second steps is cut for the parallel-in-time propagation (vba_long.hip) -- a function of s alone, so
+// that the host (which sizes the carried chunk states) and every kernel cut an edge alike.  P chunks of L steps (the last one
+// shorter): a sweep step of the iteration costs ~1.7 fine steps and there are two fine passes per sweep, L ~ sqrt(1.4 s) balances
+// them; at most 32 chunks.  Each chunk is cut again into sub-chunks of `sub` steps (at most four per chunk) whose start states
+// the last fine pass leaves behind: the transition matrix of the edge is the ordered product of the G <= 128 sub-chunk matrices.
+struct LongPlan { int L, P, sub, nsubL, G; };
+VBA_HD LongPlan long_plan(int s) {
+    LongPlan p;
+    int L = 1;
+    while (5 * L * L < 7 * s) ++L;
+    if (32 * L < s) L = (s + 31) / 32;
+    p.L = L;
+    p.P = (s + L - 1) / L;             // <= 32
+    p.sub = (L + 3) / 4 > 8 ? (L + 3) / 4 : 8;
+    p.nsubL = (L + p.sub - 1) / p.sub; // <= 4
+    const int last = s - (p.P - 1) * L;
+    p.G = (p.P - 1) * p.nsubL + (last + p.sub - 1) / p.sub;
+    return p;
+}
+
 // ------------------------------------------------------------------------------------------------ attitude
 VBA_HD void quat_mul(const double* a, const double* b, double* o) {   // BA_utils.py:992-1000
     const double x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3];

@@ -2834,6 +2834,9 @@ static bool walk_forms_blocks(const DevView& V) { return !V.lat && V.fuse_walk &
 static bool walk_forms_blocks(const DevView& V) { return !V.lat && V.fuse_walk && !V.prm.initialize && V.chunk <= 0 && V.pack == 2; }
 #endif
 bool solve_forms_blocks(const DevView& V) {
+    // (latency-mode handles only.  Round 5 measured the forming chunk elimination on bandwidth-mode handles, chunks of 12: 260 / 324 /
+    // 337 k it/s at 64 / 256 / 512 C3 windows against 270 / 347 / 367 with k_assemble_rows + k_solve_chunks_ts -- its 256-thread
+    // blocks with the staged inputs in LDS leave fewer chunks resident than the assembly launch costs)
     return walk_forms_blocks(V) || (V.lat && V.fuse_blocks && !V.prm.initialize && V.chunk >= 2 && V.chunk <= kFusedChunkMax);
 }
 
