@@ -569,7 +569,7 @@ def run_rank(args):
     dt200 = timed_region(lambda: run_steps(eng, st0, 200), barrier, torch.cuda.synchronize, reduce_max)
 
     # ---- class times of the CHAINED schedule (the one `value` is timed on), HIP events on the library's stream at the class
-    # boundaries of every call (vba_set_chain_profile): accumulate (select and the previous call's accept test folded in),
+    # boundaries of every call (VBA_OPT_CHAIN_PROFILE): accumulate (select and the previous call's accept test folded in),
     # solve (chunk elimination + cyclic reduction), trial.  The markers cost ~1 us each, so this pass follows the timed one.
     eng.set_chain_profile(True)
     eng.chain_profile(reset=True)
@@ -624,7 +624,7 @@ def run_rank(args):
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
                 "avg_launch_ms": classes_ms[dom], "launches_timed": class_calls[dom],
-                "timing_source": "HIP events on the library's stream at the class boundaries of the chained schedule (vba_set_chain_profile); "
+                "timing_source": "HIP events on the library's stream at the class boundaries of the chained schedule (VBA_OPT_CHAIN_PROFILE); "
                                  "recorded on a pass that launches kernel by kernel with ~1 us of marker per boundary -- events cannot be recorded "
                                  "inside the graph replay that `value` is timed on, whose kernels run ~0.5 us shorter each "
                                  "(profiles/r04_w1_kernel_stats.csv: 14.7 + 7.9 + 14.5 us for the three kernels of the class)",
@@ -674,7 +674,7 @@ def run_rank(args):
                      "note": "vinsat_amd.ba.BA called as the reference's driver calls BA (for iter in range(20): states, ... = "
                              "BA(iter, states, ...)): window uploaded once (identity check; ndarray arguments compared byte for byte "
                              "by the library while the device works), states fed back stay on the device, and behind every call the "
-                             "next one is enqueued speculatively (vba_set_pipeline): the host waits for the kernel that decides the "
+                             "next one is enqueued speculatively (VBA_OPT_PIPELINE): the host waits for the kernel that decides the "
                              "call and reads the result from mapped host memory"}
 
     # ---- batched windows: W independent windows per launch

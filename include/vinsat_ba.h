@@ -69,7 +69,7 @@ enum {
 int vba_version(void);
 /* 1 if the library was built with -DVBA_VARIANTS (make VARIANTS=1 -> libvinsat_ba_variants.so): the solver variants that were
  * measured slower and are kept for comparison only -- three windows per wavefront (vba_set_solver -3), one window per wavefront
- * forming its own blocks, one cyclic-reduction level in front (vba_set_fusion bit 4), the solve as one grid of waiting blocks
+ * forming its own blocks, one cyclic-reduction level in front (VBA_OPT_FUSION bit 4), the solve as one grid of waiting blocks
  * (bits 5, 6).  The default build does not carry them: those settings return VBA_EINVAL. */
 int vba_has_variants(void);
 const char* vba_last_error(void);
@@ -125,16 +125,47 @@ int vba_set_solver2(vba_handle h, int chunk, int chunk2);
  * GPU (`predict_gpu`, BA_filtering.py:16-17); results differ from mode 0 by the integration error. */
 int vba_set_integrator(vba_handle h, int hop100);
 
-/* Lanes per pose of the per-pose accumulation kernel (4, 8, 16, 32 or 64; 0 = choose from the handle geometry:
- * ~12 observations per lane, more lanes when few windows leave the GPU idle).  The value fixes the shape of the
- * reduction tree, i.e. results are bit-reproducible for equal settings. */
-int vba_set_accumulate_lanes(vba_handle h, int lanes);
 
-/* Tiles of 256 observation rows per block of the latency-mode trial kernel where it runs in its plain geometry (vba_set_fusion
- * bit 0 off): 0 = automatic (by the number of tiles of the handle: 4 from 600 tiles, 2 from 150), 1, 2, 4 or 8.  A block's keys
- * share one pass of bin reservations, so a window of 10^6 keys does not queue ~2000 returning atomics on each of the central
- * bins.  A performance knob only: block sums stay per tile, results are bit-identical for every value. */
-int vba_set_trial_tiles(vba_handle h, int tiles);
+
+/* ---- settings a caller of BA() never needs: ONE entry point.  Every option keeps results identical to rounding (most: bit for
+ * bit); defaults are chosen from the handle's geometry by measured sweeps (docs/NOTEBOOK.md).  A value an
+ * option does not take returns VBA_EINVAL.  The tests and the A/B tools are the users of these. */
+enum {
+    VBA_OPT_ACCUMULATE_LANES = 1,   /* lanes per pose of the accumulation (4, 8, 16, 32, 64; 0 = from the geometry, ~12 rows per lane):
+                                       the shape of its reduction tree -- equal settings give equal bits */
+    VBA_OPT_TRIAL_TILES = 2,        /* tiles of 256 rows per observation block of the plain latency-mode trial kernel (0 = automatic, 1, 2,
+                                       4, 8): one pass of bin reservations per block; block sums stay per tile: bit-identical for every value */
+    VBA_OPT_KEY_CARRY = 3,          /* 1 (default): an accepted trial leaves the next call's |r| keys, histogram and sum |r| behind (it is
+                                       evaluated at exactly the states the next call starts from, BA_filtering.py:61-66 / :12-21); 0: every
+                                       call recomputes them (same bits) */
+    VBA_OPT_WARM_SELECT = 4,        /* exact lower median (torch.median, BA_filtering.py:23) of carried keys: 1 (default) from the warm bins
+                                       the producing trial binned them into (latency mode: the bucket of one bin, ranked inside the
+                                       accumulation, which also evaluates the accept test of the call in front; else one compaction pass), a
+                                       rank outside the bins repeats the select with the exact digits (vba_warm_select_misses); 0: exact digit
+                                       passes and a decide launch per call; 2: every warm select misses (test); 3: the select stays a kernel */
+    VBA_OPT_WARM_SHIFT = 5,         /* log2 of a warm bin's width in bit patterns (52 = a binade; defaults 44 / 43 latency, 46 bandwidth
+                                       mode); the median is exact for every width */
+    VBA_OPT_BUCKET_CAP = 6,         /* test knob: keys a bin bucket holds (8 .. allocated; 0 = default): a fuller bin is a miss */
+    VBA_OPT_FUSION = 7,             /* bit mask: 0 the trial kernel forms the step of each pose (latency mode), 1 the chunk elimination
+                                       forms the blocks of its chunk (latency mode), 2 the sequential walk forms its blocks (bandwidth mode),
+                                       3 full-phase assembly in uniform passes; bits 4 .. 6 (one cyclic-reduction level in front; the solve as
+                                       one grid of waiting blocks: measured slower) exist in the comparison build only (vba_has_variants).
+                                       Default 15, latency-mode handles of many rows 14 / 12 */
+    VBA_OPT_CHUNK_WAVES = 8,        /* partitioned solve: 2 (default) = a chunk is eliminated from both ends by two waves, 1 = one wave
+                                       left to right (another rounding, ~1e-9 on the step; each deterministic) */
+    VBA_OPT_PIVOTING = 9,           /* 0 (default): 9x9 blocks eliminated without row exchanges, every pivot checked against the diagonal
+                                       entry it started from, a failed check repeats that solve with pivoting (vba_solver_fallbacks);
+                                       1: pivot from the start */
+    VBA_OPT_PIPELINE = 10,          /* 1 (default, one-window handles): vba_iterate_resident returns call k once its accept test is known
+                                       and has enqueued call k + 1 speculatively (a wrong guess is dropped with the carried keys); bits of
+                                       vba_step; vba_debug_fetch refuses after a pipelined call */
+    VBA_OPT_SCHEDULE_GRAPH = 11,    /* 1 (default, latency mode): vba_run_schedule replays the launches of its first pass as a hipGraph while
+                                       nothing that goes into them has changed (per-call kernel arguments compared exactly); a capture that
+                                       fails switches it off for the handle and the pass is launched kernel by kernel; also VBA_NO_GRAPH */
+    VBA_OPT_CHAIN_PROFILE = 12      /* 1: vba_run_schedule records HIP events at the class boundaries of every call (~1 us each, no graph
+                                       replay meanwhile): vba_chain_profile */
+};
+int vba_set_option(vba_handle h, int option, int value);
 
 /* BA_reg (BA_filtering.py:100-210): the BA call with a propagated-covariance prior per pose.
  * vba_upload_prior: states_prior [n,10] (arguments states_prior / velocity_prior of BA_reg: positions and the velocity
@@ -148,82 +179,13 @@ int vba_set_trial_tiles(vba_handle h, int tiles);
 int vba_upload_prior(vba_handle h, int window, int n, const double* states_prior, const double* hessian_state);
 int vba_set_prior(vba_handle h, int on);
 
-/* Carried keys (default on).  The trial residual of an accepted LM trial (BA_filtering.py:61-66) is evaluated at
- * exactly the states the next BA call starts from (BA_filtering.py:12-21), so the trial kernel also leaves the |r|
- * keys, their histogram (see vba_set_warm_select) and sum |r| of the next call on the device, and a call that follows another one
- * without vba_set_states / uploads in between starts at the median select instead of re-reading every observation.
- * on == 0: every call recomputes them (same bits; for comparison). */
-int vba_set_key_carry(vba_handle h, int on);
 
-/* Warm select (default: on).  The exact lower median of the 2m keys |r| (torch.median, BA_filtering.py:23) is found by
- * radix select.  On carried keys the trial that produced them has already binned them into 2046 narrow bins around the
- * median of its own call (consecutive calls move the median by a factor 0.3 .. 2.5), so ONE pass over the keys -- the
- * compaction of the bin that holds the wanted rank -- replaces the two digit passes; the short list is ranked exactly as
- * before.  If the wanted rank falls outside the binned range the call repeats its select with the exact digits (a
- * "miss": counted by vba_warm_select_misses, same result either way).  In a chained schedule (vba_run_schedule) the
- * warm pass of call c + 1 also evaluates the LM accept test of call c in its prologue, which removes the decide launch
- * from the chain.  on == 0: every select takes the exact digit passes and every accept test its own launch (same bits).
- * on == 2 (test knob): every warm select reports a miss, i.e. every carried call takes the repeat path.
- * Latency mode (vba_create_mode) goes one step further: the trial kernel drops every key into the bucket of its warm
- * bin (capacity ~6x the densest bin; a longer bin is a miss), so the bin of the wanted rank needs no pass over the keys --
- * the accumulation kernel resolves the histogram, ranks that bucket and evaluates the folded accept test in its own
- * prologue, and a chained landmark-only call is two kernels.  on == 3: keep the select as its own kernel (comparison). */
-int vba_set_warm_select(vba_handle h, int on);
-/* Tuning / test knob: log2 of the width of a warm bin in bit patterns (52 = one binade).  Defaults: 44 (1/256 binade; 43 for
- * more than 300 000 keys) in latency mode, where the bin of the median must be a short bucket; 49 (1/8 binade) for handles
- * in bandwidth mode, where a block's histogram flush costs one global atomic per bin it touched and the few per cent of
- * the keys in the median's bin are compacted by one pass.  The median is exact for every width. */
-int vba_set_warm_shift(vba_handle h, int shift);
+/* Carried-key selects that fell outside the warm bins and were repeated with the exact digits (VBA_OPT_WARM_SELECT). */
 int vba_warm_select_misses(vba_handle h, int* count);
-/* Test knob: capacity of a bin bucket (latency mode), 8 .. the allocated one; 0 restores the default.  A bin that holds more
- * keys than that overflows -- its bucket is incomplete -- and a call whose median falls into it takes the miss path. */
-int vba_set_bucket_cap(vba_handle h, int cap);
 
-/* Kernel fusion, a bit mask (bits 0 and 1: latency mode); same results to rounding.
- *   bit 0: the trial kernel forms the step of each pose itself (landmark-only phase: the 6x6 solve; full phase: the
- *          recovery of the partitioned solve) -- no recovery launch and, in the landmark-only phase, no assembly + solve launch;
- *   bit 1: the chunk elimination forms the blocks of its chunk in LDS itself -- no assembly launch in the full phase, the
- *          bands never go through memory.  With the generic formation it gained nothing (rounds 1, 2); formed by column
- *          (asm_form_columns, a row of 16 lanes per pose row) it takes 1.1 us off the average call: default since round 3.
- *   bit 2: (bandwidth mode, sequential driver) the solve of the full phase forms each block from the per-pose inputs
- *          itself -- no assembly launch, the bands never go through memory.  Bit-exact.  With one window per wavefront
- *          (k_solve_forming) it measured slower than assembly + walk (the walk was bound by instruction issue); since the
- *          walk packs four windows into a wavefront (k_solve_quad) it is the faster form and the default.
- *   bit 3: the full-phase assembly forms each pose row with one wave in seven uniform passes (vba_asm_fast.h) instead of one
- *          entry per thread.  Bit-exact; 0.8 us off the average call of a single window (the per-entry form is a serial
- *          ~600 instructions per thread there), on par at 4096 windows (1.77 vs 1.85 ms).
- *   bit 4: only ONE cyclic-reduction level of the reduced system runs on its own CUs in front of the one-workgroup kernel
- *          (k_cr_level0) instead of two (k_cr_level01, default).  Same bits; 0.9 us per call slower.  Comparison / tests.
- *   bit 5: (latency mode, partitioned solve with two split-off levels) chunk elimination and the two cyclic-reduction levels
- *          run as ONE grid (k_solve_resident): the consumer blocks are resident from the start and wait for their producers
- *          on flags in device memory -- bounded: a consumer that gives up flags its window and the call returns VBA_ESTATE.
- *   bit 6: ... and the one-workgroup tail as well (one launch for the whole solve).
- *          Same bits as three launches.  Measured SLOWER (C3, one window: +2.5 and +6.5 us per call): a hop over a flag is two
- *          round trips to device memory plus the write-back / invalidate of the per-XCD L2s, 4.7 us from the last producer's
- *          last store to the consumer's first load, against ~3.2 us for a kernel boundary.  Comparison / tests only.
- *   bits 4 .. 6 exist in the comparison build only (vba_has_variants); the default build answers VBA_EINVAL.
- * Default: 15 (bits 0 .. 3) for one window of fewer than 150 000 rows and 1500 poses (a bigger one: 14, with the trial kernel's
- * observation blocks of several tiles, vba_set_trial_tiles -- C4 17.4 against 15.4 k it/s, C5 12.2 against 10.1; the pipelined
- * vba_iterate_resident works with either) and for bandwidth mode; latency-mode handles of several windows drop the fusions that
- * trade instructions for launches once launches are no longer what a call costs -- 15 up to 175 000 rows per launch, 14 (the trial
- * kernel reads a step that its own launch formed) up to 450 000, 12 (the assembly is a launch as well) beyond: from the round-4
- * sweep, DESIGN.md section 3.  Measured on MI355X (C3, one window): bit 0 takes 2.7 us off the average call once the step of a pose is
- * formed by 16 lanes together (formed redundantly by every thread it was 6 us SLOWER: instruction issue of a single wave
- * is the time in this mode); bit 1, see above (48.0 against 49.1 us per call).  All masks are covered by the parity tests. */
-int vba_set_fusion(vba_handle h, int mask);
 
-/* Partitioned solve: waves per chunk.  2 (default): every chunk of 4 or more blocks is eliminated from both ends by two
- * waves that meet at its middle block -- half the dependent block steps of the kernel that is the longest of a
- * full-phase call in latency mode.  1: one wave walks the chunk left to right.  The two orders round differently
- * (~1e-9 relative on the step, the order of the difference to the reference's dense LU); each is deterministic. */
-int vba_set_chunk_waves(vba_handle h, int waves);
 
-/* Row pivoting inside the 9x9 diagonal blocks.  always == 0 (default): the blocks are eliminated without row
- * exchanges (the damped normal equations are positive definite up to a ~1e-6 non-symmetric term) while every pivot
- * is checked against the diagonal entry it started from; a failed check repeats that solve with pivoting, so the
- * result is never taken from an unchecked elimination.  always != 0: pivot from the start.
- * vba_solver_fallbacks reports how many solves were repeated (diagnostic). */
-int vba_set_pivoting(vba_handle h, int always);
+/* Solves repeated with row pivoting after a failed pivot check (VBA_OPT_PIVOTING). */
 int vba_solver_fallbacks(vba_handle h, int* count);
 
 /* Observation rows of window `window`: landmarks_xyz [m,3] (ECI km), landmarks (uv) [m,2] px,
@@ -273,31 +235,24 @@ int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const d
 /* The same call when the states argument IS the result of the previous vba_iterate / vba_iterate_resident /
  * vba_run_schedule on this handle (the driver loop `states = BA(iter, states, ...)`, od_pipe.py:1036-1040) and lamda_in
  * the lamda it returned: nothing is uploaded, the device-resident states and damping are used, and the call starts
- * from the keys the last accepted trial left behind (vba_set_key_carry).  Same bits as vba_iterate. */
+ * from the keys the last accepted trial left behind (VBA_OPT_KEY_CARRY).  Same bits as vba_iterate. */
 int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out,
                          double* last_hessian, int* n_trials, unsigned* flags);
 
 /* vba_iterate as the FIRST call of a driver loop whose following calls are vba_iterate_resident (a new window, or states the caller
  * changed): the states go up and the call is served like a resident one -- returned as soon as its accept test is known, the next
- * call enqueued behind it (vba_set_pipeline); the watched host buffers are compared as in a resident call (VBA_FLAG_HOST_CHANGED).
+ * call enqueued behind it (VBA_OPT_PIPELINE); the watched host buffers are compared as in a resident call (VBA_FLAG_HOST_CHANGED).
  * Same bits as vba_iterate.  A caller that replaces the states before every call
  * should use vba_iterate: there the speculated call would be waited for and dropped each time. */
 int vba_iterate_open(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in, double* states_out,
                      double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags);
 
-/* Pipelining of the driver loop (default on; handles of one window).  vba_iterate_resident returns call k as soon as its
- * accept test is known and has by then enqueued call k + 1 speculatively (iter + 1 / the same phase until the caller has
- * been seen doing something else after that iter), so the device works through the caller's host-side turnaround; a call
- * that was not asked for after all is waited for and dropped, at the price of the carried keys.  Results are bit-identical
- * to vba_step.  The call speculated behind a pipelined call reuses its scratch (maximum weight, step, trial states), so
- * vba_debug_fetch refuses (VBA_ESTATE) after a pipelined call: switch the pipeline off to inspect intermediates.
- * vba_pipeline_stats: speculated calls that were used / dropped. */
-int vba_set_pipeline(vba_handle h, int on);
 /* Host buffers of the caller whose content was uploaded (e.g. the ndarray arguments ii / time_idx of BA()) and that the caller
  * might edit in place: every vba_iterate_resident compares `live` with the reference `copy` (bytes each, both must stay valid;
  * 8 slots -- one per array argument of BA() --, live == NULL clears one) while the device works -- from 64 kB of watched bytes on a helper
  * thread of the handle, beside the enqueue of the speculated call -- and reports a difference as VBA_FLAG_HOST_CHANGED. */
 int vba_set_host_watch(vba_handle h, int slot, const void* live, const void* copy, int64_t bytes);
+/* Speculated calls of the pipelined driver loop that were used / dropped (VBA_OPT_PIPELINE). */
 int vba_pipeline_stats(vba_handle h, int* hits, int* discards);
 
 /* Copy an intermediate of the last step of `window` to host memory; *count receives the number of
@@ -316,24 +271,12 @@ enum { VBA_K_BEGIN = 0, VBA_K_RESIDUAL, VBA_K_SELECT, VBA_K_ACCUMULATE, VBA_K_DY
        VBA_K_TRIAL, VBA_K_DECIDE, VBA_NKERNELS };
 int vba_step_profiled(vba_handle h, int iter, int initialize, float* ms);
 
-/* vba_run_schedule on a latency-mode handle captures the launches of its first pass (~70 dependent kernels for the driver's 20 calls)
- * as a hipGraph and replays it while nothing that goes into those launches has changed (the per-call kernel arguments are compared by
- * hash, the schedule and the host-side switches by value): 45.2 -> 42.6 us per call at C3.  Same kernels, same arguments, same bits;
- * calls that stall (rejected trial, missed select) are finished by the host afterwards as without a graph.  Default on; off = kernel by
- * kernel (comparison, debugging; also the environment variable VBA_NO_GRAPH).  A capture or launch that fails once switches it off for
- * the handle.  vba_schedule_graph_stats: graphs captured / replays so far. */
-int vba_set_schedule_graph(vba_handle h, int on);
+/* Graphs captured / replays of vba_run_schedule so far (VBA_OPT_SCHEDULE_GRAPH). */
 int vba_schedule_graph_stats(vba_handle h, int* captures, int* replays);
 
-/* Class times of the CHAINED schedule (what vba_run_schedule really runs, as opposed to vba_step_profiled's serialised one).
- * on != 0: every vba_run_schedule records HIP events on the handle's stream at three boundaries of each call -- in front of
- * the call's first kernel, behind its accumulation (+ assembly, where that is a launch), behind its solve kernels, behind its
- * trial kernel -- and, if every call of the schedule was accepted at its first trial, adds the three intervals to the sums.
- * vba_chain_profile: ms[3] = summed milliseconds of the classes {accumulate (with the select / accept test folded into it, or
- * launched in front of it), solve, trial}, launches[3] = how many intervals each sum holds (a landmark-only call whose step the
- * trial kernel forms has no solve interval); reset != 0 clears the sums.  The markers cost ~1 us each on the chain: use a
- * profiled schedule for class times, an unprofiled one for throughput. */
-int vba_set_chain_profile(vba_handle h, int on);
+/* Class times of the CHAINED schedule (VBA_OPT_CHAIN_PROFILE on): ms[3] = summed milliseconds of the classes {accumulate (with
+ * the select / accept test folded into it, or launched in front of it), solve, trial}, launches[3] = how many intervals each sum
+ * holds (a landmark-only call whose step the trial kernel forms has no solve interval); reset != 0 clears the sums. */
 int vba_chain_profile(vba_handle h, double* ms, int64_t* launches, int reset);
 
 /* ---- observation-sharded multi-GPU operation (one rank per GPU, window 0 only) -------------------------
@@ -370,7 +313,7 @@ int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done)
  *   vba_sh_comm_destroy: leaves the communicator (vba_destroy does it as well).
  * Protocol of the library-issued form (vba_sh_set_protocol; default 1):
  *   1  carried keys.  An accepted trial is evaluated at the states the next call starts from, so the trial kernel of every rank
- *      leaves the |r| keys of ITS rows behind in per-bin buckets, with their warm histogram (vba_set_warm_select) and block sums,
+ *      leaves the |r| keys of ITS rows behind in per-bin buckets, with their warm histogram (VBA_OPT_WARM_SELECT) and block sums,
  *      written straight into the exchange buffer.  Per call: all-gather A [histogram | block sums] (~12 kB per rank at 500 / 50k;
  *      the next call's first kernel evaluates the accept test on it and resolves the bin of the global median from the summed
  *      histograms), all-gather B [this rank's bucket of that bin] (<= 8 kB), all-gather C [per-pose normal equations, written

@@ -178,7 +178,7 @@ def test_first_windows_of_a_large_handle_keep_what_was_uploaded_right_after_crea
 
 def test_chained_schedule_replayed_as_a_graph_gives_the_bits_of_kernel_by_kernel_launches():
     """vba_run_schedule captures the launches of a latency-mode handle's first pass as a hipGraph and replays it while nothing that
-    goes into them has changed (vba_set_schedule_graph).  Same kernels, same arguments: every window of every schedule must end
+    goes into them has changed (VBA_OPT_SCHEDULE_GRAPH).  Same kernels, same arguments: every window of every schedule must end
     on the bits of a handle that launches kernel by kernel -- on the replay, after a setting that changes kernel arguments (the
     graph is captured again), after another window was uploaded (only device data changed: the graph stays), with a window that
     rejects trials (the host finishes its calls behind the replay) and after the schedule itself changed."""
@@ -315,7 +315,7 @@ def test_a_graph_that_cannot_be_made_falls_back_to_kernel_by_kernel_launches(ste
 
 @pytest.mark.parametrize("fusion", [14, 12])
 def test_trial_kernel_tiles_per_block_do_not_change_a_bit(fusion):
-    """vba_set_trial_tiles: an observation block of the plain latency-mode trial kernel takes 1, 2, 4 or 8 tiles of 256 rows and
+    """VBA_OPT_TRIAL_TILES: an observation block of the plain latency-mode trial kernel takes 1, 2, 4 or 8 tiles of 256 rows and
     reserves its share of the bin buckets once.  Block sums stay per tile, the histogram is integers, a bucket is a set -- so
     nothing may depend on the value: three C3-sized windows on one handle (window 1 with confidences of 3: its LM loop
     rejects trials; window 2 from another initial guess), call by call with a tight bucket capacity (overflowing buckets:

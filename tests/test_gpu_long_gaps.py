@@ -105,7 +105,7 @@ def test_more_long_edges_than_slots_fall_back_to_the_serial_walk():
 
 
 def test_a_window_of_a_big_handle_runs_out_of_chain_room_and_walks_the_rest():
-    """Handles of more than 256 windows keep 512 chain states per window and parity: four 1000 s gaps fit, the fifth and sixth take
+    """Handles of more than 256 windows keep 512 chain states per window and parity: three 1000 s gaps fit (157 states each), the others take
     the ordinary serial lanes.  Same factor either way (against the oracle)."""
     from vinsat_amd.engine import BAEngine
     n = 8

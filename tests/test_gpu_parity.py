@@ -1213,7 +1213,7 @@ def test_many_windows_per_launch_agree_with_single_window_runs():
 
 @pytest.mark.parametrize("mask", [1, 2, 3])
 def test_latency_mode_fusions_vs_reference(c2, mask):
-    """vba_set_fusion: the trial kernel forming the step itself (bit 0) and the chunk elimination forming its own blocks
+    """VBA_OPT_FUSION: the trial kernel forming the step itself (bit 0) and the chunk elimination forming its own blocks
     (bit 1).  Off by default (slower on MI355X); same arithmetic in another place, so: every call of the C2 chain against the
     reference's states, trial counts and lamda exact, and the rejection window against the unfused run."""
     from vinsat_amd.engine import BAEngine
@@ -1265,7 +1265,7 @@ def test_torch_cuda_initialises_after_the_library_has_used_the_gpu():
 @pytest.mark.parametrize("solver", [0], ids=["four-per-wave"])
 @pytest.mark.parametrize("reg", [False, True])
 def test_batched_walk_forming_its_own_blocks_gives_the_bits_of_the_assembled_path(c2, reg, solver):
-    """vba_set_fusion bit 2 (default for 16 windows and more, sequential driver -- itself the default from 128 windows on):
+    """VBA_OPT_FUSION bit 2 (default for 16 windows and more, sequential driver -- itself the default from 128 windows on):
     in the full phase the sequential solve (k_solve_quad, four windows per wavefront; k_solve_forming with one) forms each block
     from the per-pose inputs itself and the assembly launch is gone.  Same entries, same elimination: 16 windows -- the
     golden one, one that rejects trials and exhausts lamda, one whose blocks send the unpivoted path to the pivoted
@@ -1309,7 +1309,7 @@ def test_batched_walk_forming_its_own_blocks_gives_the_bits_of_the_assembled_pat
 @pytest.mark.parametrize("chunk", [4, 5, 8, 13])
 @pytest.mark.parametrize("pivot", [False, True])
 def test_two_sided_chunk_elimination_vs_one_wave(c2, chunk, pivot):
-    """vba_set_chunk_waves: chunks eliminated from both ends by two waves that meet in the middle (default) against one
+    """VBA_OPT_CHUNK_WAVES: chunks eliminated from both ends by two waves that meet in the middle (default) against one
     wave walking them left to right -- every chunk length the sizes produce (even, odd, the short last chunk that falls
     back to one wave), unpivoted and pivoted blocks, plain BA and the rejection window.  Same system, another
     elimination order: the step agrees to rounding, trial counts and lamda exactly, and each order repeats its own bits."""
@@ -1341,7 +1341,7 @@ def test_two_sided_chunk_elimination_vs_one_wave(c2, chunk, pivot):
 @pytest.mark.parametrize("reg", [False, True])
 @pytest.mark.parametrize("windows", [1, 16])
 def test_uniform_pass_assembly_gives_the_bits_of_the_per_entry_form(c2, reg, windows):
-    """Full-phase assembly: one wave per pose in seven uniform passes (vba_asm_fast.h, vba_set_fusion bit 3) against the
+    """Full-phase assembly: one wave per pose in seven uniform passes (vba_asm_fast.h, VBA_OPT_FUSION bit 3) against the
     per-entry form (band_entry / rhs_entry per thread, default): every band entry, the right-hand side and the result of
     the call, bit for bit -- latency and batched geometry, plain BA and BA_reg (prior terms)."""
     from vinsat_amd.engine import BAEngine

@@ -53,7 +53,7 @@ def test_packed_sequential_solve_three_windows_per_wave(pivot):
 @pytest.mark.parametrize("chunk", [4, 5, 6, 7, 8, 13])
 def test_two_cyclic_reduction_levels_in_front_give_the_bits_of_one(chunk):
     """The reduced system's first TWO cyclic-reduction levels on their own CUs (k_cr_level01, default) against one level in
-    front (k_cr_level0; vba_set_fusion bit 4): the same eliminations and folds in another place, so the same bits -- for
+    front (k_cr_level0; VBA_OPT_FUSION bit 4): the same eliminations and folds in another place, so the same bits -- for
     separator counts of every residue mod 4 (a 300-pose window cut into chunks of 4 .. 13: 74, 59, 49, 42, 37, 23 separators,
     the last one below the size from which the levels are split off at all), unpivoted and pivoted."""
     from vinsat_amd.engine import BAEngine
@@ -83,7 +83,7 @@ def test_two_cyclic_reduction_levels_in_front_give_the_bits_of_one(chunk):
 
 @pytest.mark.parametrize("chunk", [4, 6, 8])
 def test_resident_solve_gives_the_bits_of_three_launches(chunk):
-    """vba_set_fusion bits 5 / 6 (k_solve_resident): chunk elimination, the two split-off cyclic-reduction levels and -- bit 6
+    """VBA_OPT_FUSION bits 5 / 6 (k_solve_resident): chunk elimination, the two split-off cyclic-reduction levels and -- bit 6
     -- the one-workgroup tail as ONE grid whose consumer blocks wait for their producers on flags.  The same bodies run, so
     the bits are those of the three launches, unpivoted and pivoted; and every block publishes its flag whatever it did, so a
     handle whose windows differ in length (one of them below the size from which the levels are split off at all, one
@@ -139,7 +139,7 @@ def test_resident_solve_gives_the_bits_of_three_launches(chunk):
 @pytest.mark.parametrize("solver", [-2], ids=["one-per-wave"])
 @pytest.mark.parametrize("reg", [False, True])
 def test_one_window_per_wave_walk_forming_its_own_blocks_gives_the_bits_of_the_assembled_path(c2, reg, solver):
-    """vba_set_fusion bit 2 (default for 16 windows and more, sequential driver -- itself the default from 128 windows on):
+    """VBA_OPT_FUSION bit 2 (default for 16 windows and more, sequential driver -- itself the default from 128 windows on):
     in the full phase the sequential solve (k_solve_quad, four windows per wavefront; k_solve_forming with one) forms each block
     from the per-pose inputs itself and the assembly launch is gone.  Same entries, same elimination: 16 windows -- the
     golden one, one that rejects trials and exhausts lamda, one whose blocks send the unpivoted path to the pivoted

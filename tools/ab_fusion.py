@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One C3 window: us per call of the chained 20-call schedule for several vba_set_fusion masks, and whether the final states
+"""One C3 window: us per call of the chained 20-call schedule for several VBA_OPT_FUSION masks, and whether the final states
 are bit-equal to the first mask's."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

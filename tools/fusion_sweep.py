@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time of the 20-call schedule of one window for the fusion masks of the latency mode (vba_set_fusion; diagnostic)."""
+"""Time of the 20-call schedule of one window for the fusion masks of the latency mode (VBA_OPT_FUSION; diagnostic)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -27,24 +27,14 @@ SIGNATURES = {
     "vba_get_mode": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "vba_destroy": (c_int, [c_void_p]),
     "vba_set_stream": (c_int, [c_void_p, c_void_p, c_int]),
+    "vba_set_option": (c_int, [c_void_p, c_int, c_int]),
     "vba_set_solver": (c_int, [c_void_p, c_int]),
     "vba_set_solver2": (c_int, [c_void_p, c_int, c_int]),
-    "vba_set_key_carry": (c_int, [c_void_p, c_int]),
     "vba_upload_prior": (c_int, [c_void_p, c_int, c_int, PD, PD]),
     "vba_set_prior": (c_int, [c_void_p, c_int]),
-    "vba_set_fusion": (c_int, [c_void_p, c_int]),
-    "vba_set_chunk_waves": (c_int, [c_void_p, c_int]),
-    "vba_set_warm_select": (c_int, [c_void_p, c_int]),
-    "vba_set_warm_shift": (c_int, [c_void_p, c_int]),
-    "vba_set_pipeline": (c_int, [c_void_p, c_int]),
     "vba_set_host_watch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64]),
     "vba_pipeline_stats": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
-    "vba_set_bucket_cap": (c_int, [c_void_p, c_int]),
     "vba_warm_select_misses": (c_int, [c_void_p, POINTER(c_int)]),
-    "vba_set_pivoting": (c_int, [c_void_p, c_int]),
-    "vba_set_accumulate_lanes": (c_int, [c_void_p, c_int]),
-    "vba_set_trial_tiles": (c_int, [c_void_p, c_int]),
-    "vba_set_schedule_graph": (c_int, [c_void_p, c_int]),
     "vba_schedule_graph_stats": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "vba_set_integrator": (c_int, [c_void_p, c_int]),
     "vba_solver_fallbacks": (c_int, [c_void_p, POINTER(c_int)]),
@@ -63,7 +53,6 @@ SIGNATURES = {
     "vba_debug_fetch": (c_int, [c_void_p, c_int, c_int, PD, c_int64, PI64]),
     "vba_last_step_ms": (c_int, [c_void_p, POINTER(c_float)]),
     "vba_step_profiled": (c_int, [c_void_p, c_int, c_int, POINTER(c_float)]),
-    "vba_set_chain_profile": (c_int, [c_void_p, c_int]),
     "vba_chain_profile": (c_int, [c_void_p, PD, PI64, c_int]),
     "vba_sh_partial_count": (c_int64, [c_int]),
     "vba_sh_stage1": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p]),
@@ -93,6 +82,10 @@ SIGNATURES = {
     "vba_schur_last_ms": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float)]),
     "vba_schur_debug_fetch": (c_int, [c_void_p, c_int, PD, c_int64]),
 }
+
+# VBA_OPT_* of include/vinsat_ba.h (vba_set_option)
+OPT = dict(accumulate_lanes=1, trial_tiles=2, key_carry=3, warm_select=4, warm_shift=5, bucket_cap=6, fusion=7, chunk_waves=8,
+           pivoting=9, pipeline=10, schedule_graph=11, chain_profile=12)
 
 _lib = None
 

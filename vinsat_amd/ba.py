@@ -140,8 +140,8 @@ def configure(integrator=None, lanes=None, fusion=None, solver=None, mode=None, 
     (``BA_filtering.py:16-17``).  Takes effect from the next call on.
 
     ``lanes`` / ``fusion`` / ``solver`` / ``mode`` pin what a handle otherwise chooses from its own geometry -- lanes per
-    pose of the accumulation (``vba_set_accumulate_lanes``: the shape of its reduction tree), the kernel-fusion mask
-    (``vba_set_fusion``), the chain partition ``(chunk, chunk2)`` (``vba_set_solver2``; ``0`` = sequential walk) and the kernel
+    pose of the accumulation (``VBA_OPT_ACCUMULATE_LANES``: the shape of its reduction tree), the kernel-fusion mask
+    (``VBA_OPT_FUSION``), the chain partition ``(chunk, chunk2)`` (``vba_set_solver2``; ``0`` = sequential walk) and the kernel
     set (``vba_create_mode``) -- so that a window gets the same bits alone and in a batch of any size.  ``"auto"`` returns
     one of them to the handle's choice.  The cached engines are rebuilt.
 

@@ -284,8 +284,8 @@ extern "C" {
 
 static void watch_stop(vba_handle h);
 static void watch_quiesce(vba_handle h);
-int vba_set_accumulate_lanes(vba_handle h, int lanes);
-int vba_set_trial_tiles(vba_handle h, int tiles);
+static int vba_set_accumulate_lanes(vba_handle h, int lanes);
+static int vba_set_trial_tiles(vba_handle h, int tiles);
 int vba_set_solver(vba_handle h, int chunk);
 
 int vba_version(void) { return 210; }     // 2.1: vba_set_chunk_waves, fusion bits 2..4, warm select mode 3
@@ -668,7 +668,7 @@ int vba_set_integrator(vba_handle h, int hop100) {
     return VBA_OK;
 }
 
-int vba_set_accumulate_lanes(vba_handle h, int lanes) {
+static int vba_set_accumulate_lanes(vba_handle h, int lanes) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     if (lanes == 0) {
@@ -690,7 +690,7 @@ int vba_set_accumulate_lanes(vba_handle h, int lanes) {
 // chained 20-call schedule (k it/s, tiles 1 / 2 / 4 / 8): one C4 window (782 tiles) 15.3 / 16.4 / 17.4 / 16.2, one C5 window
 // (1954 tiles) 9.8 / 11.5 / 12.2 / 12.1, 8 C3 windows (1568) 113.9 / 120.6 / 121.9, 22 C3 windows (4312) 185 / 197 / 195; one C3
 // window (196, with that fusion mask) 19.7 / 20.6 / 19.8.  Results do not depend on it (see k_trial).
-int vba_set_trial_tiles(vba_handle h, int tiles) {
+static int vba_set_trial_tiles(vba_handle h, int tiles) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     if (tiles == 0) {
@@ -702,7 +702,7 @@ int vba_set_trial_tiles(vba_handle h, int tiles) {
     return VBA_OK;
 }
 
-int vba_set_key_carry(vba_handle h, int on) {
+static int vba_set_key_carry(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     h->carry_enabled = on != 0;
@@ -710,7 +710,7 @@ int vba_set_key_carry(vba_handle h, int on) {
     return VBA_OK;
 }
 
-int vba_set_fusion(vba_handle h, int mask) {
+static int vba_set_fusion(vba_handle h, int mask) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     if (mask < 0 || mask > 127) return fail(VBA_EINVAL, "mask must be in [0, 127]");
@@ -722,7 +722,7 @@ int vba_set_fusion(vba_handle h, int mask) {
     return VBA_OK;
 }
 
-int vba_set_chunk_waves(vba_handle h, int waves) {
+static int vba_set_chunk_waves(vba_handle h, int waves) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     if (waves != 1 && waves != 2) return fail(VBA_EINVAL, "waves must be 1 or 2");
@@ -730,7 +730,7 @@ int vba_set_chunk_waves(vba_handle h, int waves) {
     return VBA_OK;
 }
 
-int vba_set_warm_select(vba_handle h, int on) {
+static int vba_set_warm_select(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     h->warm_enabled = on == 2 ? 2 : (on != 0);
@@ -738,7 +738,7 @@ int vba_set_warm_select(vba_handle h, int on) {
     return VBA_OK;
 }
 
-int vba_set_warm_shift(vba_handle h, int shift) {
+static int vba_set_warm_shift(vba_handle h, int shift) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     if (shift < 42 || shift > 51) return fail(VBA_EINVAL, "shift must be in [42, 51]");
@@ -747,7 +747,7 @@ int vba_set_warm_shift(vba_handle h, int shift) {
     return VBA_OK;
 }
 
-int vba_set_bucket_cap(vba_handle h, int cap) {
+static int vba_set_bucket_cap(vba_handle h, int cap) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     if (!h->bucket_cap_alloc) return fail(VBA_ESTATE, "this handle has no bin buckets (16 windows or more)");
@@ -767,7 +767,7 @@ int vba_set_host_watch(vba_handle h, int slot, const void* live, const void* cop
     return VBA_OK;
 }
 
-int vba_set_pipeline(vba_handle h, int on) {
+static int vba_set_pipeline(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc = settle(h)) return rc;
     h->pipeline = on != 0;
@@ -787,7 +787,7 @@ int vba_warm_select_misses(vba_handle h, int* count) {
     return VBA_OK;
 }
 
-int vba_set_pivoting(vba_handle h, int always) {
+static int vba_set_pivoting(vba_handle h, int always) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc_settle = settle(h)) return rc_settle;
     h->pivot_mode = always ? 1 : 0;
@@ -887,7 +887,7 @@ int vba_upload_window(vba_handle h, int window, int n, const double* intrinsics,
     int nl = 0, pool_used = 0;
     for (int i = 0; i + 1 < n && nl < kLongCap; ++i)
         if (steps[i] > kLongGap) {
-            const int need_states = 2 + long_plan(steps[i]).G;
+            const int need_states = 3 + long_plan(steps[i]).G + 48;     // header, sub-chunk start states, eight 6x6 partial products (vba_long.hip)
             if (pool_used + need_states > h->V.long_pool_cap) continue;
             long_list[kLongCap + 1 + nl] = pool_used;
             pool_used += need_states;
@@ -1669,7 +1669,7 @@ int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* init
     return VBA_OK;
 }
 
-int vba_set_schedule_graph(vba_handle h, int on) {
+static int vba_set_schedule_graph(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc = settle(h)) return rc;
     h->graph_enabled = on != 0;
@@ -1683,11 +1683,30 @@ int vba_schedule_graph_stats(vba_handle h, int* captures, int* replays) {
     return VBA_OK;
 }
 
-int vba_set_chain_profile(vba_handle h, int on) {
+static int vba_set_chain_profile(vba_handle h, int on) {
     if (!h) return fail(VBA_EINVAL, "null handle");
     if (int rc = settle(h)) return rc;
     h->cprof.on = on != 0;
     return VBA_OK;
+}
+
+// the settings a caller of BA() never needs, behind one entry point (include/vinsat_ba.h: VBA_OPT_*)
+int vba_set_option(vba_handle h, int option, int value) {
+    switch (option) {
+        case VBA_OPT_ACCUMULATE_LANES: return vba_set_accumulate_lanes(h, value);
+        case VBA_OPT_TRIAL_TILES: return vba_set_trial_tiles(h, value);
+        case VBA_OPT_KEY_CARRY: return vba_set_key_carry(h, value);
+        case VBA_OPT_WARM_SELECT: return vba_set_warm_select(h, value);
+        case VBA_OPT_WARM_SHIFT: return vba_set_warm_shift(h, value);
+        case VBA_OPT_BUCKET_CAP: return vba_set_bucket_cap(h, value);
+        case VBA_OPT_FUSION: return vba_set_fusion(h, value);
+        case VBA_OPT_CHUNK_WAVES: return vba_set_chunk_waves(h, value);
+        case VBA_OPT_PIVOTING: return vba_set_pivoting(h, value);
+        case VBA_OPT_PIPELINE: return vba_set_pipeline(h, value);
+        case VBA_OPT_SCHEDULE_GRAPH: return vba_set_schedule_graph(h, value);
+        case VBA_OPT_CHAIN_PROFILE: return vba_set_chain_profile(h, value);
+        default: return fail(VBA_EINVAL, "unknown option (VBA_OPT_*)");
+    }
 }
 
 int vba_chain_profile(vba_handle h, double* ms, int64_t* launches, int reset) {

@@ -10,7 +10,7 @@
 // vs per-entry assembly, every band entry).
 // Measured (MI355X): one window, 0.8 us off the average call (the per-entry form has every thread form its entry of four
 // poses in turn, ~600 serial instructions); 4096 windows, k_assemble_rows 1.77 ms against k_assemble's 1.85 ms -- there the
-// assembly is not bound by its instruction count.  Default (vba_set_fusion bit 3); the block-forming walk built on the
+// assembly is not bound by its instruction count.  Default (VBA_OPT_FUSION bit 3); the block-forming walk built on the
 // same rows (bit 2) stays slower than assembly + walk and is opt-in.  Both bit-exact and under test.
 //
 // Slot layout of the staged inputs of a pose (vba_asm.h): Hraw 0, braw 21, Phi 27, rorb 63, qgrad 69, Hd 72, Hu 81, Hl 90,

@@ -116,9 +116,9 @@ struct DevView {
     int pending_only;               // k_decide: only windows whose trial of this call is evaluated and not yet decided (sc.pending)
     int redo;                       // 1: this launch repeats the call for the windows whose warm select missed (sc.miss), others skip
     int lat;                        // latency mode (few windows): fused kernels, see vba_api.hip
-    int fuse_blocks;                // latency mode: the chunk elimination forms the blocks of its chunk itself (vba_set_fusion bit 1)
+    int fuse_blocks;                // latency mode: the chunk elimination forms the blocks of its chunk itself (VBA_OPT_FUSION bit 1)
     int resident;                   // latency mode: the solve is one grid of producer and waiting consumer blocks (k_solve_resident;
-                                    // vba_set_fusion bit 5: chunks + cyclic-reduction groups, bit 6: + the one-workgroup tail)
+                                    // VBA_OPT_FUSION bit 5: chunks + cyclic-reduction groups, bit 6: + the one-workgroup tail)
     int res_stride;                 // flags per window
     unsigned* res_flags;            // [W][res_stride] epoch of the launch that last completed the block
     double* wbucket;                // [W][2 (parity)][kSelBins][bucket_cap] carried keys by warm bin (latency mode; null: none)
@@ -126,9 +126,9 @@ struct DevView {
     int median_ready;               // many windows: k_select_finish has left the median in sc.c_obs
     int sel_inline;                 // this call's accumulation starts the call: inline warm select on the buckets (+ folded accept test)
     int cr_levels;                  // cyclic-reduction levels that run as their own multi-CU kernel in front of the one-workgroup kernel (1 or 2)
-    int chunk_waves;                // partitioned solve: waves per chunk (2: eliminated from both ends, vba_set_chunk_waves)
-    int asm_rows;                   // full-phase assembly in uniform passes (vba_asm_fast.h; vba_set_fusion bit 3)
-    int fuse_walk;                  // batched mode: the sequential walk forms the blocks itself (vba_set_fusion bit 2)
+    int chunk_waves;                // partitioned solve: waves per chunk (2: eliminated from both ends, VBA_OPT_CHUNK_WAVES)
+    int asm_rows;                   // full-phase assembly in uniform passes (vba_asm_fast.h; VBA_OPT_FUSION bit 3)
+    int fuse_walk;                  // batched mode: the sequential walk forms the blocks itself (VBA_OPT_FUSION bit 2)
     int warm_shift;                 // log2 of the bit-pattern width of a warm bin
     int warm_force_miss;            // test knob: every warm select reports a miss (exercises the repeat with the exact digits)
     int fused_trial;                // k_trial forms the step itself (0 no, 1 landmark-only 6x6 solve, 2 recovery of the partitioned solve)
@@ -162,8 +162,9 @@ struct DevView {
     int nblk_long;                  // largest n_long over the windows of the handle = extra blocks / slots per window; 0 with the hop integrator
     // carried chunk states of the long edges: the trial kernel's propagation of an edge passes through the states the next call's
     // factor needs (an accepted trial is evaluated at exactly the states the next call starts from -- the carried-keys argument,
-    // applied to dynamics): [W][2 (parity of the call that READS)][kLongPool][6]; an edge's slot = two states of header (x_hat and
-    // the start state the chain belongs to, which the reader checks) followed by its G sub-chunk start states, at long_off[w][k] (-1: no room, the factor finds its own)
+    // applied to dynamics): [W][2 (parity of the call that READS)][kLongPool][6]; an edge's slot = three states of header (x_hat,
+    // the start state the chain belongs to, which the reader checks, one spare), its G sub-chunk start states, and room for the
+    // eight partial products of its transition matrix, at long_off[w][k] (-1: no room, the factor finds its own)
     double* long_pool;
     const int* long_off;            // [W][kLongCap]
     int long_pool_cap;              // states per window and parity (kLongPool, or kLongPoolFew for handles of few windows)

@@ -142,6 +142,11 @@ __device__ __forceinline__ void long_states(const double* x0, int s, const LongP
 
 }  // namespace
 
+// A slot of the pool, in states of six doubles: [0] x_hat, [1] the start state the chain belongs to, [2] spare, [3, 3 + G) the
+// sub-chunk start states, then kLongSplit partial products of the transition matrix (36 doubles each).
+constexpr int kLongHead = 3;
+constexpr int kLongSplit = 8;           // workgroups that share the tangent pass of one edge (16 sub-chunks each)
+
 // where the chain of long edge k of window w lives for the call of parity `par` (every long edge has a slot: an edge the window's
 // pool has no room for is not marked long, vba_upload_window)
 __device__ __forceinline__ double* long_slot(const DevView& V, int w, int par, int k) {
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(64) void k_long_trial(DevView V) {
     const int s = -V.steps[sb + i];
     double* carry = long_slot(V, w, V.par ^ 1, k);
     double U[6], x[6];
-    long_states(x0, s, long_plan(s), lane, U, x, carry + 12);
+    long_states(x0, s, long_plan(s), lane, U, x, carry + kLongHead * 6);
     if (lane == 0) {
         // header: x_hat, then the start state this chain belongs to (what the reader checks)
 #pragma unroll
@@ -202,21 +207,80 @@ __global__ __launch_bounds__(64) void k_long_chain(DevView V) {
     if (same) return;       // (every lane takes the same decision from the same six words)
     const int s = -V.steps[pb];
     double U[6], x[6];
-    long_states(x0, s, long_plan(s), lane, U, x, chain + 12);
+    long_states(x0, s, long_plan(s), lane, U, x, chain + kLongHead * 6);
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) { chain[c] = x[c]; chain[6 + c] = x0[c]; }
     }
 }
 
-// The dynamics factor of the long edges at the INPUT states: transition matrix Phi, prediction x_hat, residual r_orbit of pose
-// long_idx[k], and sum |r_orbit| into slot nblk_pred + k of part_pred (parity of the call).  One workgroup of 1024 per long edge,
-// behind k_long_chain: the chain through the gap -- x_hat and the sub-chunk start states -- is in the pool; 8 lanes per sub-chunk
-// (6 tangents, as dynamics_block) carry the sub-chunk's transition matrix over ~10 steps, and the G matrices are multiplied in
-// order, pairwise, in place: Phi = M_{G-1} ... M_1 M_0.
-__global__ __launch_bounds__(1024) void k_long_factor(DevView V) {
-    __shared__ double Ssub[129][6];         // [0] = x_hat, [1 + g] = start state of sub-chunk g
-    __shared__ double M[128][36];
+// The transition matrices of the sub-chunks of the long edges and their ordered product, first part.  kLongSplit workgroups of 128
+// per long edge (on as many compute units: sixteen waves of fp64 arithmetic on ONE compute unit took 38 us for what is 6 us of
+// instructions per wave), behind k_long_chain: a workgroup takes 16 consecutive sub-chunks -- 8 lanes each, 6 tangents as in
+// dynamics_block, ~10 steps from the sub-chunk's start state in the pool -- and multiplies their matrices in order, pairwise, in
+// place: its partial product M_{g0 + 15} ... M_{g0} goes behind the chain in the edge's slot.
+__global__ __launch_bounds__(128) void k_long_tangent(DevView V) {
+    __shared__ double M[16][36];
+    const int w = blockIdx.y;
+    VBA_SKIP_CALL(V, w);
+    const int k = blockIdx.x / kLongSplit, part = blockIdx.x % kLongSplit, tid = threadIdx.x;
+    if (k >= V.n_long[w]) return;
+    const int i = V.long_idx[(size_t)w * kLongCap + k];
+    const size_t pb = (size_t)w * V.n_max + i;
+    const int s = -V.steps[pb];
+    const LongPlan pl = long_plan(s);
+    const int g0 = part * 16;
+    if (g0 >= pl.G) return;
+    const int cnt = pl.G - g0 < 16 ? pl.G - g0 : 16;
+    double* chain = long_slot(V, w, V.par, k);
+    {
+        const int g = g0 + (tid >> 3), c = tid & 7;
+        if (g < pl.G && c < 6) {
+            const int j = g / pl.nsubL < pl.P - 1 ? g / pl.nsubL : pl.P - 1;      // the chunk of this sub-chunk (the tail chunk may hold fewer)
+            const int q = g - j * pl.nsubL;
+            const int clen = j < pl.P - 1 ? pl.L : s - (pl.P - 1) * pl.L;
+            const int len = clen - q * pl.sub < pl.sub ? clen - q * pl.sub : pl.sub;
+            const double* sg = chain + (size_t)(kLongHead + g) * 6;
+            double x[6], t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 6; ++r) x[r] = sg[r];
+            t[c] = 1.0;
+            for (int e = 0; e < len; ++e) rk4_step<true>(x, t, 1.0);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) M[tid >> 3][6 * r + c] = t[r];
+        }
+    }
+    __syncthreads();
+    // ordered product, in place: at stride d the matrix at 2 a d takes M[2 a d + d] * M[2 a d] (a matrix without a partner stays)
+    for (int d = 1; d < cnt; d <<= 1) {
+        const int pairs = (cnt + 2 * d - 1) / (2 * d);
+        double v[3];
+        int n = 0;
+        for (int e = tid; e < pairs * 36; e += 128, ++n) {
+            const int a = e / 36, rc = e % 36, r = rc / 6, c = rc % 6;
+            const int lo = 2 * a * d, hi = lo + d;
+            if (hi < cnt) {
+                double acc = M[hi][6 * r] * M[lo][c];
+#pragma unroll
+                for (int q = 1; q < 6; ++q) acc = fma(M[hi][6 * r + q], M[lo][6 * q + c], acc);
+                v[n] = acc;
+            } else {
+                v[n] = M[lo][rc];
+            }
+        }
+        __syncthreads();
+        n = 0;
+        for (int e = tid; e < pairs * 36; e += 128, ++n) M[2 * (e / 36) * d][e % 36] = v[n];
+        __syncthreads();
+    }
+    if (tid < 36) chain[(size_t)(kLongHead + pl.G) * 6 + (size_t)part * 36 + tid] = M[0][tid];
+}
+
+// ... second part: the partial products of an edge multiplied in order -- Phi = M_{G-1} ... M_1 M_0 --, and with x_hat from the
+// chain's header the prediction, the residual r_orbit of pose long_idx[k] and sum |r_orbit| into slot nblk_pred + k of part_pred
+// (parity of the call).  One wavefront per long edge.
+__global__ __launch_bounds__(64) void k_long_finish(DevView V) {
+    __shared__ double M[kLongSplit][36];
     const int w = blockIdx.y;
     VBA_SKIP_CALL(V, w);
     const int k = blockIdx.x, tid = threadIdx.x;
@@ -231,10 +295,10 @@ __global__ __launch_bounds__(1024) void k_long_factor(DevView V) {
     const int s = -V.steps[pb];
     const LongPlan pl = long_plan(s);
     const double* chain = long_slot(V, w, V.par, k);
-    for (int e = tid; e < (1 + pl.G) * 6; e += 1024) (&Ssub[0][0])[e] = chain[e < 6 ? e : e + 6];
-    __syncthreads();
+    const int cnt = (pl.G + 15) / 16;
+    for (int e = tid; e < cnt * 36; e += 64) (&M[0][0])[e] = chain[(size_t)(kLongHead + pl.G) * 6 + e];
     if (tid == 0) {
-        const double* x = Ssub[0];
+        const double* x = chain;
         const double* sn = st + 10;
         double* xh = V.xhat + pb * 6;
         double* ro = V.rorb + pb * 6;
@@ -248,43 +312,26 @@ __global__ __launch_bounds__(1024) void k_long_factor(DevView V) {
         ro[5] = (x[5] - sn[9]) * kVelCoeff;
         *slot = fabs(ro[0]) + fabs(ro[1]) + fabs(ro[2]) + fabs(ro[3]) + fabs(ro[4]) + fabs(ro[5]);
     }
-    {   // the sub-chunks' transition matrices
-        const int g = tid >> 3, c = tid & 7;
-        if (g < pl.G && c < 6) {
-            const int j = g / pl.nsubL < pl.P - 1 ? g / pl.nsubL : pl.P - 1;      // the chunk of this sub-chunk (the tail chunk may hold fewer)
-            const int q = g - j * pl.nsubL;
-            const int clen = j < pl.P - 1 ? pl.L : s - (pl.P - 1) * pl.L;
-            const int len = clen - q * pl.sub < pl.sub ? clen - q * pl.sub : pl.sub;
-            double x[6], t[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < 6; ++r) x[r] = Ssub[1 + g][r];
-            t[c] = 1.0;
-            for (int e = 0; e < len; ++e) rk4_step<true>(x, t, 1.0);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) M[g][6 * r + c] = t[r];
-        }
-    }
     __syncthreads();
-    // ordered product, in place: at stride d the matrix at 2 a d takes M[2 a d + d] * M[2 a d] (a matrix without a partner stays)
-    for (int d = 1; d < pl.G; d <<= 1) {
-        const int pairs = (pl.G + 2 * d - 1) / (2 * d);
-        double v[5];
-        int cnt = 0;
-        for (int e = tid; e < pairs * 36; e += 1024, ++cnt) {
+    for (int d = 1; d < cnt; d <<= 1) {
+        const int pairs = (cnt + 2 * d - 1) / (2 * d);
+        double v[3];
+        int n = 0;
+        for (int e = tid; e < pairs * 36; e += 64, ++n) {
             const int a = e / 36, rc = e % 36, r = rc / 6, c = rc % 6;
             const int lo = 2 * a * d, hi = lo + d;
-            if (hi < pl.G) {
+            if (hi < cnt) {
                 double acc = M[hi][6 * r] * M[lo][c];
 #pragma unroll
                 for (int q = 1; q < 6; ++q) acc = fma(M[hi][6 * r + q], M[lo][6 * q + c], acc);
-                v[cnt] = acc;
+                v[n] = acc;
             } else {
-                v[cnt] = M[lo][rc];
+                v[n] = M[lo][rc];
             }
         }
         __syncthreads();
-        cnt = 0;
-        for (int e = tid; e < pairs * 36; e += 1024, ++cnt) M[2 * (e / 36) * d][e % 36] = v[cnt];
+        n = 0;
+        for (int e = tid; e < pairs * 36; e += 64, ++n) M[2 * (e / 36) * d][e % 36] = v[n];
         __syncthreads();
     }
     if (tid < 36) V.Phi[pb * 36 + tid] = M[0][tid];
@@ -293,7 +340,8 @@ __global__ __launch_bounds__(1024) void k_long_factor(DevView V) {
 void launch_long_factor(const DevView& V, hipStream_t s) {
     if (V.nblk_long <= 0 || V.hop) return;
     hipLaunchKernelGGL(k_long_chain, dim3(V.nblk_long, V.W), dim3(64), 0, s, V);
-    hipLaunchKernelGGL(k_long_factor, dim3(V.nblk_long, V.W), dim3(1024), 0, s, V);
+    hipLaunchKernelGGL(k_long_tangent, dim3(V.nblk_long * kLongSplit, V.W), dim3(128), 0, s, V);
+    hipLaunchKernelGGL(k_long_finish, dim3(V.nblk_long, V.W), dim3(64), 0, s, V);
 }
 
 void launch_long_trial(const DevView& V, hipStream_t s) {

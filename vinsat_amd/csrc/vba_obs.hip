@@ -995,7 +995,7 @@ __global__ __launch_bounds__(256) void k_obs_accumulate(DevView V) {
 // histogram again if it is not).  EMIT 2: warm histogram (bins around this call's median: the next call selects in one
 // pass); EMIT 1: the 10 exponent bits = digit 0 of the exact select (many windows per launch: the ~1 global atomic per
 // key that a 2048-bin histogram costs is dearer there than the second pass over the keys it saves).
-// FUSED (latency mode, vba_set_fusion bit 0): 0 = the trial states are in memory, pose-chain blocks of 256 edges;
+// FUSED (latency mode, VBA_OPT_FUSION bit 0): 0 = the trial states are in memory, pose-chain blocks of 256 edges;
 // 1 / 2 = the trial states do not exist yet and are formed here (vba_step.h: 1 landmark-only 6x6 solve, 2 recovery of the
 // partitioned solve), 16 lanes per pose: an observation block for the poses its rows belong to (a handful), a pose-chain
 // block for 16 poses = 15 edges, which also writes states_new / dpose for everybody after this kernel; 3 = the geometry

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64) void k_solve(DevView V) {
 }
 
 #ifdef VBA_VARIANTS   // measured dead ends kept for comparison builds (make VARIANTS=1): k_solve_forming, k_solve_packed
-// Batched windows, full phase (vba_set_fusion bit 2): the walk forms the blocks itself.  The assembly kernel wrote 2 kB
+// Batched windows, full phase (VBA_OPT_FUSION bit 2): the walk forms the blocks itself.  The assembly kernel wrote 2 kB
 // per pose that this kernel read straight back -- 8 GB per call at 4096 windows of 500 poses; here the wave keeps the
 // inputs of three consecutive poses (141 doubles each, BA_reg 183) in an LDS ring, loads the next pose's while it
 // eliminates, and every lane forms the four entries of the next block it used to load.  Same band_entry / rhs_entry,
@@ -675,7 +675,7 @@ __device__ __forceinline__ void quad_pivots(const double (&baseA)[9], double (&A
     }
 }
 
-// FORM (vba_set_fusion bit 2, default): the walk forms its blocks itself from the per-pose inputs (asm_form_row, the uniform
+// FORM (VBA_OPT_FUSION bit 2, default): the walk forms its blocks itself from the per-pose inputs (asm_form_row, the uniform
 // passes of vba_asm_fast.h: the same system to the bit) -- no assembly launch, and the bands (2 kB per pose written and read
 // back) never go through memory: per pose 0.8 kB of inputs instead.  The inputs of three consecutive poses of each window
 // live in an LDS ring, the loads run kFwdDepth poses ahead in registers.
@@ -2123,7 +2123,7 @@ __device__ __forceinline__ void cr_fill(const DevView& V, int w, int s, int n1, 
     }
 }
 
-#ifdef VBA_VARIANTS   // one cyclic-reduction level in front instead of two (vba_set_fusion bit 4): 0.9 us per call slower, comparison builds
+#ifdef VBA_VARIANTS   // one cyclic-reduction level in front instead of two (VBA_OPT_FUSION bit 4): 0.9 us per call slower, comparison builds
 // First level of the cyclic reduction as its own kernel, one wave (one CU) per pair of separators: wave t builds the
 // blocks 2t, 2t+1, 2t+2, eliminates the two even ones (each even block is eliminated by both of its odd neighbours'
 // waves: redundant work instead of communication), folds them into block 2t+1 and leaves
@@ -2510,11 +2510,11 @@ __global__ __launch_bounds__(kCrThreads) void k_solve_reduced_cr(DevView V, int 
     reduced_cr_body<PIVOT, PRE, kCrThreads>(V, s, blockIdx.x, smem);
 }
 
-#ifdef VBA_VARIANTS   // the solve as ONE grid of producer and waiting consumer blocks (vba_set_fusion bits 5, 6): measured slower, comparison builds
+#ifdef VBA_VARIANTS   // the solve as ONE grid of producer and waiting consumer blocks (VBA_OPT_FUSION bits 5, 6): measured slower, comparison builds
 // ------------------------------------------------------------------------------------------------ resident solve
 // The three launches of the latency-mode solve (chunk elimination -> cyclic-reduction levels 0 + 1 -> the remaining levels
 // in one workgroup) as ONE grid whose consumer blocks are resident from the start and wait for their producers on flags
-// (vba_set_fusion bit 5).  Block x of window y is
+// (VBA_OPT_FUSION bit 5).  Block x of window y is
 //   x <  P          : chunk x                        (produces flag x)
 //   x <  P + G      : cyclic-reduction group x - P   (waits for chunks 4t .. 4t + 7, produces flag x)
 //   x == P + G      : the one-workgroup tail         (TAIL; waits for all groups)
@@ -2827,7 +2827,7 @@ __global__ __launch_bounds__(256) void k_decide(DevView V, const double* trial_a
 
 // latency mode with a partitioned chain whose chunk (blocks + staged inputs + elimination scratch) fits the LDS of a CU:
 // the chunk kernel forms its blocks itself and k_assemble is not launched (vba_api.hip asks the same question)
-// ... and the sequential walk of the batched mode forms them pose by pose (vba_set_fusion bit 2)
+// ... and the sequential walk of the batched mode forms them pose by pose (VBA_OPT_FUSION bit 2)
 #ifdef VBA_VARIANTS
 static bool walk_forms_blocks(const DevView& V) { return !V.lat && V.fuse_walk && !V.prm.initialize && V.chunk <= 0 && V.pack != 1; }
 #else   // (one window per wavefront forming its own blocks -- k_solve_forming -- is a comparison variant)

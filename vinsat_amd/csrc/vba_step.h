@@ -1,6 +1,6 @@
 // vba_step.h -- the step of ONE pose from the solved system and its retraction (A7 tail + A8 head), as device functions.
 //
-// Latency mode (few windows) can do without a kernel of its own for this (vba_set_fusion bit 0): the trial kernel forms
+// Latency mode (few windows) can do without a kernel of its own for this (VBA_OPT_FUSION bit 0): the trial kernel forms
 // the step of every pose it needs itself -- each observation block for the handful of poses its rows belong to, the
 // pose-chain blocks for the poses of their edges (16 lanes per pose either way) -- so the solve's recovery launch (full
 // phase) and the assembly + solve launch (landmark-only phase, a 6x6 system per pose) disappear from the chain.  Both

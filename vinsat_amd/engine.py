@@ -52,6 +52,10 @@ class BAEngine:
         except Exception:
             pass
 
+    def _option(self, name, value):
+        """``vba_set_option``: the settings a caller of ``BA`` never needs (``include/vinsat_ba.h`` ``VBA_OPT_*``)."""
+        _lib.check(self.lib.vba_set_option(self.h, _lib.OPT[name], int(value)), self.lib)
+
     def mode(self):
         """(kernel set: 1 latency / 0 bandwidth, chunk size of the solver partition: 0 = sequential walk)."""
         a, b = c_int(), c_int()
@@ -72,15 +76,15 @@ class BAEngine:
 
     def set_accumulate_lanes(self, lanes):
         """Lanes per pose of the accumulation kernel (0 = automatic)."""
-        _lib.check(self.lib.vba_set_accumulate_lanes(self.h, int(lanes)), self.lib)
+        self._option("accumulate_lanes", int(lanes))
 
     def set_trial_tiles(self, tiles):
         """Tiles of 256 rows per observation block of the latency-mode trial kernel (0 = automatic); results do not depend on it."""
-        _lib.check(self.lib.vba_set_trial_tiles(self.h, int(tiles)), self.lib)
+        self._option("trial_tiles", int(tiles))
 
     def set_schedule_graph(self, on):
         """Replay of a chained schedule's launches as a hipGraph (latency-mode handles; default on).  Same bits either way."""
-        _lib.check(self.lib.vba_set_schedule_graph(self.h, int(bool(on))), self.lib)
+        self._option("schedule_graph", int(bool(on)))
 
     def schedule_graph_stats(self):
         """(graphs captured, replays) of :meth:`run_schedule` so far."""
@@ -90,31 +94,31 @@ class BAEngine:
 
     def set_key_carry(self, on):
         """True (default): an accepted trial leaves the next call's |r| keys behind; False: every call recomputes them."""
-        _lib.check(self.lib.vba_set_key_carry(self.h, int(bool(on))), self.lib)
+        self._option("key_carry", int(bool(on)))
 
     def set_fusion(self, mask):
         """Kernel fusion mask (include/vinsat_ba.h: bit 0 step inside the trial kernel, bit 1 blocks formed inside the chunk
         elimination, ... bits 5 / 6 the solve as one grid of waiting blocks -- measured slower, comparison only)."""
-        _lib.check(self.lib.vba_set_fusion(self.h, int(mask)), self.lib)
+        self._option("fusion", int(mask))
 
     def set_chunk_waves(self, waves):
         """Partitioned solve: 2 (default) = every chunk is eliminated from both ends by two waves, 1 = one wave."""
-        _lib.check(self.lib.vba_set_chunk_waves(self.h, int(waves)), self.lib)
+        self._option("chunk_waves", int(waves))
 
     def set_warm_select(self, on):
         """True / 1 (default): carried keys are selected warm -- from the bucket of one warm bin inside the accumulation
         (latency mode), by one warm pass otherwise -- and chained calls fold their accept test into that; False / 0: exact
         digit passes and a decide launch per call; 2: every warm select is forced to miss (test knob); 3: the warm select
         stays a kernel of its own."""
-        _lib.check(self.lib.vba_set_warm_select(self.h, int(on) if int(on) in (2, 3) else int(bool(on))), self.lib)
+        self._option("warm_select", int(on) if int(on) in (2, 3) else int(bool(on)))
 
     def set_warm_shift(self, shift):
         """Tuning / test knob: log2 of the warm-bin width in bit patterns (52 = a binade)."""
-        _lib.check(self.lib.vba_set_warm_shift(self.h, int(shift)), self.lib)
+        self._option("warm_shift", int(shift))
 
     def set_pipeline(self, on):
         """True (default): ``iterate_resident`` overlaps the caller's turnaround with a speculatively enqueued next call."""
-        _lib.check(self.lib.vba_set_pipeline(self.h, int(bool(on))), self.lib)
+        self._option("pipeline", int(bool(on)))
 
     def pipeline_stats(self):
         """(speculated calls used, speculated calls dropped)."""
@@ -124,7 +128,7 @@ class BAEngine:
 
     def set_bucket_cap(self, cap):
         """Test knob: keys a bin bucket can hold (0 = default); a fuller bin makes the call that needs it miss."""
-        _lib.check(self.lib.vba_set_bucket_cap(self.h, int(cap)), self.lib)
+        self._option("bucket_cap", int(cap))
 
     def warm_select_misses(self):
         c = c_int()
@@ -133,7 +137,7 @@ class BAEngine:
 
     def set_pivoting(self, always):
         """False (default): unpivoted fast path with checked pivots and automatic fallback; True: always pivot."""
-        _lib.check(self.lib.vba_set_pivoting(self.h, int(bool(always))), self.lib)
+        self._option("pivoting", int(bool(always)))
 
     def solver_fallbacks(self):
         c = c_int()
@@ -253,8 +257,8 @@ class BAEngine:
     CHAIN_CLASSES = ("accumulate", "solve", "trial")
 
     def set_chain_profile(self, on):
-        """HIP events at the class boundaries of every call of the following ``run_schedule`` calls (``vba_set_chain_profile``)."""
-        _lib.check(self.lib.vba_set_chain_profile(self.h, int(bool(on))), self.lib)
+        """HIP events at the class boundaries of every call of the following ``run_schedule`` calls (``VBA_OPT_CHAIN_PROFILE``)."""
+        self._option("chain_profile", int(bool(on)))
 
     def chain_profile(self, reset=True):
         """{class: (average ms per interval, intervals)} of the chained schedules run since the last reset."""
