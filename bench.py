@@ -94,7 +94,7 @@ def parse():
     ap.add_argument("--sweep", default="1,2,4,8,15,16,22,32,64,128,256,1024", help="window counts of the batched_sweep series (the "
                     "--windows handle joins it); empty = skip")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config series (C2, C4, C5, gap window)")
-    ap.add_argument("--profile-tag", default="r04", help="profiles/<tag>_w1_traffic.json / _mfma.json supply roofline.traffic / .mfma")
+    ap.add_argument("--profile-tag", default="r05", help="profiles/<tag>_w1_traffic.json / _mfma.json supply roofline.traffic / .mfma")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = every core of this box)")
     ap.add_argument("--no-sharded", action="store_true")
@@ -624,10 +624,13 @@ def run_rank(args):
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg,
                 "avg_launch_ms": classes_ms[dom], "launches_timed": class_calls[dom],
+                # machine-readable: `value` / ms_per_step are timed on the hipGraph replay of the schedule, the class times (and with
+                # them achieved / frac) on a kernel-by-kernel pass with event markers -- ~15 % conservative, they do not sum to ms_per_step
+                "timed_on_graph_replay": False, "value_timed_on_graph_replay": True,
                 "timing_source": "HIP events on the library's stream at the class boundaries of the chained schedule (VBA_OPT_CHAIN_PROFILE); "
                                  "recorded on a pass that launches kernel by kernel with ~1 us of marker per boundary -- events cannot be recorded "
                                  "inside the graph replay that `value` is timed on, whose kernels run ~0.5 us shorter each "
-                                 "(profiles/r04_w1_kernel_stats.csv: 14.7 + 7.9 + 14.5 us for the three kernels of the class)",
+                                 "(profiles/r05_w1_kernel_stats.csv: 14.6 + 7.8 + 14.6 us for the three kernels of the class)",
                 "whole_call": {"bytes": whole, "achieved": whole / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                                "frac": whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "note": "SURVEY 8(d) B_alg = 208 m + 5000 n over the timed (chained) ms_per_step"},

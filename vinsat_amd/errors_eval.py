@@ -52,14 +52,25 @@ def _resolve(ba):
 
 def _run_share(pairs, ba, batched, timing=None):
     """The sequences of ``pairs`` through the driver on the current device; returns (errors, times) per sequence."""
-    from .od_pipe import streaming_batched, streaming_version
+    from .od_pipe import prepared_runs, streaming_batched, streaming_version
     if batched:
         if ba is not None:
             raise ValueError("batched=True drives vinsat_amd.ba.BA_window itself")
-        seqs = [(np.load(det, allow_pickle=True), np.load(orb, allow_pickle=True)) for det, orb in pairs]
-        results = streaming_batched(seqs, timing=timing) if seqs else []
+        results = streaming_batched(list(pairs), timing=timing) if pairs else []       # (files are read by the preparing threads)
     else:
-        results = [streaming_version(detections_file_name=det, orbit_file_name=orb, ba=ba, timing=timing) for det, orb in pairs]
+        # the next sequences are read and prepared on host threads while this one's BA calls run (`prep` in the timing is then
+        # what the consumer still waited for)
+        import time
+        results = []
+        it = prepared_runs(list(pairs))
+        while True:
+            t0 = time.perf_counter()
+            run = next(it, None)
+            if timing is not None:
+                timing["prep"] = timing.get("prep", 0.0) + time.perf_counter() - t0
+            if run is None:
+                break
+            results.append(streaming_version(ba=ba, timing=timing, run=run))
     errors, times = [], []
     for e, _, t in results:
         errors.append(e.detach().cpu().numpy())
