@@ -2,7 +2,7 @@
 """One C3 window: us per call of the chained 20-call schedule for several VBA_OPT_FUSION masks, and whether the final states
 are bit-equal to the first mask's."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from vinsat_amd import od_pipe, synth

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Batched chain (W windows of C3, 20 calls) for a list of accumulate lane counts (diagnostic)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vinsat_amd import od_pipe, synth
 from vinsat_amd.engine import BAEngine

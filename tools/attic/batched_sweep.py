@@ -2,7 +2,7 @@
 """Per-kernel time of one BA call for W batched C3 windows (diagnostic; prints one JSON line per W)."""
 import json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vinsat_amd import od_pipe, synth
 from vinsat_amd.engine import BAEngine

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """W batched C3 windows: ms per step of the chained 20-call schedule for several warm-bin widths (and the exact select)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vinsat_amd import od_pipe, synth
 from vinsat_amd.engine import BAEngine

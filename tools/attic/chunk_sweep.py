@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Time of the 20-call schedule of one window for the fusion masks of the latency mode (VBA_OPT_FUSION; diagnostic)."""
+"""Time of the 20-call schedule of one window for a range of chunk sizes of the partitioned solve (diagnostic)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vinsat_amd import od_pipe, synth
 from vinsat_amd.engine import BAEngine
@@ -15,15 +15,22 @@ e = BAEngine(n, m)
 e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
 e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
 iters, inits = list(range(20)), [k < 10 for k in range(20)]
-for mask in [int(x) for x in sys.argv[2:]] or [0, 1, 2, 3, 0]:
-    e.set_fusion(mask)
+if os.environ.get("VBA_LANES"):
+    e.set_accumulate_lanes(int(os.environ["VBA_LANES"]))
+if os.environ.get("VBA_FUSION"):
+    e.set_fusion(int(os.environ["VBA_FUSION"]))
+for chunk in [int(x) for x in sys.argv[2:]] or [-1, 4, 5, 6, 7, 8, 10, 12]:
+    if chunk > 0:
+        e.set_solver(chunk, -1)
+    else:
+        e.set_solver(-1)
     for rep in range(3):
         e.set_states(st0, 1e-4)
         e.run_schedule(iters, inits)
     t0 = time.perf_counter()
-    for rep in range(20):
+    for rep in range(10):
         e.set_states(st0, 1e-4)
         e.run_schedule(iters, inits)
-    dt = (time.perf_counter() - t0) / 400
-    print(f"{cfg} fusion {mask}: {1e6 * dt:7.1f} us per call, {1 / dt:8.0f} it/s, warm misses {e.warm_select_misses()}", flush=True)
+    dt = (time.perf_counter() - t0) / 200
+    print(f"{cfg} chunk {chunk:3d}: {1e6 * dt:7.1f} us per call, {1 / dt:8.0f} it/s", flush=True)
 e.close()

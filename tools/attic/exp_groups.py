@@ -3,7 +3,7 @@
 kernels) against one handle of W windows.  python tools/exp_groups.py W G [G ...]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vinsat_amd import od_pipe, synth
 from vinsat_amd.engine import BAEngine, BAEngineGroup

@@ -3,7 +3,7 @@
 (vba_iterate_resident: enqueue of the speculated next call + wait for this call's decision) against the Python around it.
 C3, the 20-call loop, per phase (landmark-only calls 0..9, full calls 10..19)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -3,7 +3,7 @@
 One C3 window, one full call through the resident solve; prints, per role (chunk / cyclic-reduction group / tail), the 100 MHz
 wall-clock stamps of wave 0 relative to the first block's entry: entry, wait over, body over, flag published."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from ctypes import byref, c_int64

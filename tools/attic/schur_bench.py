@@ -3,7 +3,7 @@
 Prints one JSON line: ms per phase of an LM trial, and the blocked Cholesky's flop rate against the fp64 matrix peak."""
 import json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vinsat_amd import synth
 from vinsat_amd.schur import SchurBA

@@ -3,7 +3,7 @@
 C3, the 20-call schedule (chained: vba_sh_run_schedule; VBA_SH_STEPPED=1: call by call; VBA_SH_PROTOCOL=0: the round-3 protocol); for A/B runs
 of two builds (VBA_LIB) and kernel traces."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 300))

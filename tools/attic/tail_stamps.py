@@ -3,7 +3,7 @@
 entry, fill done, then after every eliminate / fold of the level loop, every level of the back substitution, the level-1
 recovery and the end; us since entry.  argv[1]: fusion mask (bit 7 set = without the LDS prefetch)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from ctypes import byref, c_int64

@@ -2,7 +2,7 @@
 """Time the two-pass window (gaps of 945 / 555 s: long RK4 chains) call by call -- diagnostic."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vinsat_amd import od_pipe, synth
 from vinsat_amd.engine import BAEngine

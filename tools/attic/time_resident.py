@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-call wall time of vba_iterate_resident (C ABI through ctypes) with and without the speculative pipeline, C3."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from vinsat_amd import od_pipe, synth
 from vinsat_amd.engine import BAEngine

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """W batched C3 windows: HIP-event time of the solve class (and the others) of full-phase calls (vba_step_profiled)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from vinsat_amd import od_pipe, synth

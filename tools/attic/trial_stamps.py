@@ -4,7 +4,7 @@ a landmark-only and of a full C3 call: entry, prologue done, row leaders known, 
 rows reprojected + keys binned, bin reservations requested, first block sum, reserved bases there, keys in their buckets;
 us since entry."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from ctypes import byref, c_int64
