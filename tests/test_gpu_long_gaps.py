@@ -160,3 +160,99 @@ def test_long_edges_in_a_batch_have_the_bits_of_the_window_alone(mode):
     for k in range(3):
         alone = run([k])[0]
         assert np.array_equal(together[k], alone), k
+
+
+# ------------------------------------------------------------------------------------------------ sharded mode across long gaps
+def _second_batch_window():
+    """The second batch of the two-pass sequence (25 poses, gaps of 935 and 510 s) with the states the driver starts it from."""
+    from vinsat_amd import od_pipe, synth
+    win = od_pipe.prepare_window(*synth.make_two_pass_sequence())
+    return win, od_pipe.initial_guess(win, seed=3)
+
+
+def test_observation_sharded_window_with_long_gaps_on_three_emulated_ranks():
+    """vba_sh_stage1..4 (the caller-dispatched protocol) on the window with the long gaps: every rank propagates the long edges
+    itself (k_long_chain / k_long_tangent / k_long_finish behind the accumulation, k_long_trial behind the trial kernel), their
+    residual slots are summed with the pose-chain blocks' -- against the unsharded engine, call by call."""
+    from test_gpu_parity import _EmulatedRanks
+    from vinsat_amd.engine import BAEngine
+    win, st0 = _second_batch_window()
+    n, m = win.time_idx.size, win.ii.size
+    em = _EmulatedRanks(n, m, 3, win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, win.intrinsics, win.cumrot_last, win.time_idx)
+    single = BAEngine(n, m)
+    single.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+    single.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+    em.set_states(st0, 1e-4)
+    ref, lam_ref = st0, 1e-4
+    for it, init in [(0, True), (1, True), (10, False), (11, False), (12, False), (13, False), (14, False)]:
+        em.call(it, init)
+        ref, lam_ref, hess_ref, ntr_ref, _ = single.iterate(it, init, lam_ref, ref)
+        out = em.results()
+        assert out[3] == ntr_ref and out[1] == lam_ref, it
+        assert rel_err(out[0], ref) < 1e-9, it
+    em.close()
+    single.close()
+
+
+def _worker_native_long(rank, world, port, tmp):
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from vinsat_amd.dist import HipStageEngine, ShardedBA
+    from vinsat_amd.engine import BAEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        win, st0 = _second_batch_window()
+        n, m = win.time_idx.size, win.ii.size
+        iters, inits = list(range(20)), [False] * 20
+
+        def engine():
+            e = BAEngine(n, m)
+            e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+            e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+            return e
+        res = {}
+        for name, proto, chained in (("carried-chained", 1, True), ("carried", 1, False), ("round3", 0, False)):
+            stage = HipStageEngine(engine(), torch_stream=False)
+            stage.attach_rccl(dist)
+            stage.set_protocol(proto)
+            sb = ShardedBA(stage, n, m, m)
+            sb.set_states(st0, 1e-4)
+            if chained:
+                sb.run_schedule(iters[:7], inits[:7])
+                sb.run_schedule(iters[7:], inits[7:])
+            else:
+                for it, init in zip(iters, inits):
+                    sb.step(it, init)
+            res[name] = sb.get_states()
+            sb.close()
+        single = engine()
+        single.set_states(st0, 1e-4)
+        single.run_schedule(iters, inits)
+        ref = single.get_states()
+        single.close()
+        base = res["carried"]
+        for name, r in res.items():
+            assert np.array_equal(r[0], base[0]) and r[1] == base[1] and r[3] == base[3], name
+        assert base[1] == ref[1] and base[3] == ref[3] and np.abs(base[0] - ref[0]).max() / np.abs(ref[0]).max() < 1e-9
+        np.save(os.path.join(tmp, "ok.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_library_issued_sharded_protocols_across_long_gaps(tmp_path):
+    """The carried-keys protocol (chained and stepped) and the round-3 protocol, exchanges issued by the library over RCCL (one rank: a
+    one-GPU box), on the window with the long gaps: one set of bits, and the unsharded schedule to 1e-9."""
+    import os
+    import torch.multiprocessing as mp
+    port = 29300 + (os.getpid() % 200)
+    mp.spawn(_worker_native_long, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "ok.npy")
