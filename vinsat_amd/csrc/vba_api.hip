@@ -1,29 +1,5 @@
-// vba_api.hip -- C ABI of libvinsat_ba.so (see include/vinsat_ba.h): context, uploads, one BA() step.
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include <dlfcn.h>
-#include <unistd.h>
-#include <rccl/rccl.h>      // types only: the library is resolved at run time (vba_sh_comm_init), never linked
-
-#include "../../include/vinsat_ba.h"
-#include "vba_device.h"
-#include "vba_launch.h"
-
-using namespace vba;
-
-namespace {
+// vba_api.hip -- C ABI of libvinsat_ba.so (see include/vinsat_ba.h): context, options, uploads, states, diagnostics.
+#include "vba_context.h"
 
 thread_local std::string g_err;
 
@@ -32,159 +8,6 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess)                                                                          \
-            return fail(VBA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
-    } while (0)
-
-struct Arena {
-    char* base = nullptr;
-    size_t size = 0, used = 0;
-    template <class T>
-    T* take(size_t count) {
-        used = (used + 255) & ~size_t(255);
-        T* p = reinterpret_cast<T*>(base + used);
-        used += count * sizeof(T);
-        return p;
-    }
-};
-
-}  // namespace
-
-struct vba_context {
-    int device = 0;
-    int W = 0, n_max = 0;
-    int64_t m_max = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr, aux_stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
-    Arena arena;
-    DevView V{};
-    // mutable device pointers (DevView holds const views of some)
-    int *d_n = nullptr, *d_m = nullptr, *d_steps = nullptr;
-    int *d_long_idx = nullptr, *d_n_long = nullptr, *d_long_off = nullptr;     // long edges of every window (vba_long.hip)
-    std::vector<int> n_long;                // ... and how many each window has (host copy; DevView::nblk_long is their maximum)
-    // per-observation weights and per-pose normal equations exist per call parity (DevView points at the slot of the call):
-    // the accumulation of call c + 1 starts before the accept test of call c is known, whose later trials still read them
-    double *wraw2 = nullptr, *Hraw2 = nullptr, *braw2 = nullptr;
-    double* dyn2[8] = {};           // xhat, Phi, rorb, fatt, qgrad, Hd, Hu, Hl
-    double* d_obs = nullptr;                // observation blocks, [W][obs_stride] (layout: DevView::ox)
-    int64_t m_pad = 0;                      // doubles per observation array inside a block
-    double *d_intr = nullptr, *d_cumrot = nullptr;
-    // uploads go through pinned staging and are asynchronous on the handle's stream (ordered with the kernels that
-    // read them); two buffers, so that the host packs window w + 1 while window w is on its way
-    double* h_up[2] = {nullptr, nullptr};
-    hipEvent_t ev_up[2] = {nullptr, nullptr};
-    int up_next = 0;
-    WinHead* h_head = nullptr;              // mapped pinned host memory, [W]
-    double* h_stage = nullptr;              // pinned staging for vba_set_states: [n_max * 10 + 1]
-    double* h_back = nullptr;               // pinned staging for vba_get_states: [n_max * 10] + one WinScalars
-    bool back_valid = false;                // h_back holds window 0's states and scalars after the last step (vba_iterate)
-    double* S[2] = {nullptr, nullptr};      // the two state buffers [W][n_max][10]; S[par] is the input of the next call
-    int par = 0;                            // parity of the next call (WinScalars: what a call hands on lives in the slots of the reader's parity)
-    bool need_hist_reset = false;           // a call was abandoned half way: its histograms may be dirty
-    hipEvent_t ev_stage = nullptr;          // the last staged copy has left the staging buffer
-    std::vector<int> n, m;
-    std::vector<char> have_obs, have_win, have_state, have_prior;
-    bool reg = false;               // BA_reg semantics (per-pose prior) for the following calls
-    double *d_prior_H = nullptr, *d_prior_x = nullptr;
-    std::vector<std::vector<int64_t>> perm; // sorted position -> input row
-    float last_ms = 0.f;
-    bool stepped = false;
-    int carry_ok = 0;               // every window's keys / histogram / sum |r| for its current states are on the device: 0 no, 1 with the
-                                    // exponent histogram, 2 with the warm histogram (the kind the last trial emitted)
-    bool carry_enabled = true;
-    bool hist_dirty = false;        // a k_trial<true> has left a warm histogram (digit-0 slot of parity `par`) behind that nobody consumed
-    bool fold_enabled = true;       // chained schedule: the first kernel of call c + 1 evaluates the accept test of call c (latency mode)
-    int warm_enabled = 1;           // carried keys are selected with the one-pass warm select (vba_set_warm_select; 2: forced misses, test knob)
-    int last_iter = 0, last_init = 0;
-    int sh_pivot = 0;                       // sharded mode: solver variant of the current call (0 unpivoted, 2 mixed after a failed check)
-    bool sh_rode = false, sh_bands_ready = false;   // sharded mode: the dynamics factor rode in the accumulation; bands / rhs are in memory
-    // sharded mode with the exchanges issued by the library itself (vba_sh_comm_init / vba_sh_call): RCCL resolved at run time
-    struct ShComm {
-        void* dl = nullptr;
-        ncclComm_t comm = nullptr;
-        int nranks = 0, rank = 0;
-        ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-        ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
-        const char* (*error_string)(ncclResult_t) = nullptr;
-        double* buf = nullptr;              // one allocation: abs_local | abs_all | partial_local | partial_all | trial_local | trial_all
-        int64_t m_total = 0, m_pad = 0;     // what buf was sized for
-        int n = 0;
-        int m_local = -1;                   // rows of this rank the +inf padding of abs_local was laid out for
-        // carried-keys protocol (vba_sh_run_schedule): exchange buffers that the kernels write in place
-        int protocol = 1;                   // 1 = carried keys (default), 0 = the round-3 protocol (every call gathers all keys)
-        ncclResult_t (*group_start)() = nullptr;
-        ncclResult_t (*group_end)() = nullptr;
-        double* buf2 = nullptr;             // sendA[2] | recvA | sendB | recvB
-        int lenA = 0, lenB = 0, n2 = 0, nbo2 = 0, nbd2 = 0, cap2 = 0;
-        double *sendA[2] = {nullptr, nullptr}, *recvA = nullptr, *sendB = nullptr, *recvB = nullptr;
-        bool carried = false;               // recvA holds the exchange of the trial that produced the resident states: the next call may start from it
-        int carried_par = 0;                // ... whose parity (the parity of the call that will read it)
-        long fallbacks_miss = 0, fallbacks_lm = 0;
-        double *abs_local = nullptr, *abs_all = nullptr, *partial_local = nullptr, *partial_all = nullptr, *trial_local = nullptr, *trial_all = nullptr;
-    } shc;
-    int pack_min = 1 << 30;                 // windows from which three chains share a wavefront: never by default (measured at 1024 / 2048 / 4096
-                                            // windows: one wave per window is as fast or faster, 1.52 / 1.96 / 2.70 ms vs 1.52 / 2.06 / 2.78 ms per solve);
-                                            // vba_set_solver(h, -3) packs from 3 windows on
-    int no_pack = 0;                        // diagnostic: force one window per wavefront in the sequential driver
-    int pivot_mode = 0;                     // 0 = fast path with automatic fallback, 1 = always pivot
-    int fallbacks = 0;                      // number of solves repeated with pivoting (diagnostic)
-    int inline_select = 1;                  // latency mode: warm select inside the accumulation (bin buckets); vba_set_warm_select(h, 3) turns it off
-    int chunk_waves = 2;                    // vba_set_chunk_waves
-    int cr_levels = 2;                      // cyclic-reduction levels in front of the one-workgroup kernel (VBA_CR_LEVELS / vba_set_cr_levels: 2 or 3)
-    int fusion = 15;                        // vba_set_fusion (default: the trial kernel forms the step, the solves form their own blocks, uniform-pass assembly)
-    bool fusion_auto = true;                // the mask is the library's own choice (vba_set_fusion not called)
-    // the first passes of the last few chained schedules as graphs (vba_run_schedule), each with what it was made for; most recently
-    // used first, at most kGraphCache of them (a driver alternates between a handful of schedules: the 20-call loop, its two phases)
-    // key: a hash per call's view (the quick reject); views: the bytes of those views, compared exactly on a key match (a 64-bit hash
-    // collision would replay another schedule's launches silently; ncalls x sizeof(DevView) of memcmp is ~1 us)
-    struct GraphEntry { std::vector<unsigned long long> key; std::vector<unsigned char> views; hipGraphExec_t exec = nullptr; };
-    std::vector<GraphEntry> graphs;
-    bool graph_broken = false;              // capture or launch failed once: kernel by kernel from then on
-    bool graph_enabled = true;              // vba_set_schedule_graph
-    long graph_replays = 0, graph_captures = 0;
-    int bucket_cap_alloc = 0;               // allocated capacity of a bin bucket (vba_set_bucket_cap lowers the one in use)
-    int warm_misses = 0;                    // number of calls whose warm select missed and was repeated with the exact digits (diagnostic)
-    double* d_dbg = nullptr;                // lazily allocated scratch for debug fetch
-    size_t dbg_cap = 0;
-    // Pipelined driver loop (vba_iterate_resident, see iterate_pipelined): the call that was enqueued speculatively behind
-    // the one that has just been returned, the chain it belongs to and what has been learnt about the caller's schedule
-    struct Spec { bool valid = false; int iter = 0, init = 0; bool reg = false; int c = 0; } spec;
-    int chain_par0 = 0;                     // parity of call 0 of the open chain
-    int pred_iter[64], pred_init[64];       // what followed a resident call with iter & 63 (-1: not seen yet, -2: nothing resident)
-    int prev_res_iter = -1;                 // iter of the previous resident call (for learning), -1: none
-    int pipeline = 1;                       // vba_set_pipeline
-    bool last_pipelined = false;            // the last call went through iterate_pipelined: a speculated call has reused its scratch
-    int spec_hits = 0, spec_discards = 0;   // diagnostics (vba_pipeline_stats)
-    struct Watch { const void* live = nullptr; const void* copy = nullptr; size_t bytes = 0; } watch[8];   // vba_set_host_watch
-    // The watched buffers are compared by a helper thread of the handle while the calling thread enqueues the speculated call: the
-    // comparison of the reference driver's `ii` (400 kB at C3) is ~9 us of memcmp, and a landmark-only call leaves the host no idle
-    // time to hide it in (23 us of device work against ~29 us of host work per resident call before this).
-    struct WatchWorker {
-        std::thread th;
-        std::mutex m;
-        std::condition_variable cv;
-        unsigned long long seq = 0;         // guarded by m: number of the last request
-        bool quit = false;                  // guarded by m
-        std::atomic<unsigned long long> done_seq{0};    // the request `changed` answers
-        bool changed = false;
-        bool started = false;
-        pid_t owner = 0;                    // the process the helper thread lives in (a forked child inherits `started`, not the thread)
-    } ww;
-    // vba_set_chain_profile: HIP events at the class boundaries (accumulate | solve | trial) of every call of a chained schedule
-    struct ChainProf {
-        bool on = false;
-        std::vector<hipEvent_t> ev;         // 4 per call: before / behind the accumulation, behind the solve, behind the trial
-        double ms[3] = {0.0, 0.0, 0.0};
-        int64_t launches[3] = {0, 0, 0};
-    } cprof;
-    double* h_states_map = nullptr;         // [2][n_max][10] mapped pinned host memory (DevView::host_states), one-window handles
-    hipEvent_t ev_first = nullptr;
-};
-
-namespace {
 
 
 void fill_params(StepParams& p, int iter, int initialize) {
@@ -244,7 +67,7 @@ hipError_t create_aux_stream(hipStream_t* s) {
 // front and its first trial but nobody decided it: its input states, the result the caller holds, are intact (call
 // parity), its trial states and everything keyed to them are dropped.  `boundary`: the caller left the resident loop
 // (uploads, new states): remember not to speculate behind a call with that iter again.
-int settle(vba_handle h, bool boundary = false) {
+int settle(vba_handle h, bool boundary) {
     if (!h) return VBA_OK;
     if (!h->spec.valid) {
         // the caller left the resident loop behind a call that had speculated nothing: what it does next is not "what follows
@@ -278,12 +101,8 @@ int ready(vba_handle h) {
     return VBA_OK;
 }
 
-}  // namespace
 
-extern "C" {
 
-static void watch_stop(vba_handle h);
-static void watch_quiesce(vba_handle h);
 static int vba_set_accumulate_lanes(vba_handle h, int lanes);
 static int vba_set_trial_tiles(vba_handle h, int tiles);
 int vba_set_solver(vba_handle h, int chunk);
@@ -999,7 +818,7 @@ int vba_set_states(vba_handle h, int window, const double* states, double lamda)
 }
 
 // what a finished call left in the window's scalars, seen from the parity `par` of the NEXT call
-static void unpack_scalars(const WinScalars* sc, int par, double* lamda, double* last_hessian, int* n_trials, unsigned* flags) {
+void unpack_scalars(const WinScalars* sc, int par, double* lamda, double* last_hessian, int* n_trials, unsigned* flags) {
     if (lamda) *lamda = sc->lam[par];
     if (last_hessian) std::memcpy(last_hessian, sc->last_hessian, 81 * 8);
     if (n_trials) *n_trials = sc->n_trials;
@@ -1059,636 +878,6 @@ int vba_get_states_all(vba_handle h, double* states, double* lamda, double* last
     return VBA_OK;
 }
 
-namespace {
-
-// ---------------------------------------------------------------------------------------------- one BA() call
-// The kernels of a call, as the host enqueues them (all asynchronous on the handle's stream):
-//
-//   front   [k_obs_residual]                     only when the host replaced the states (no carried keys)
-//           [select]                             exact digits (2 passes; 3 when digit 0 is not there yet); on carried keys
-//                                                ONE warm pass (k_select_warm) -- or, latency mode, nothing: the keys lie
-//                                                in per-bin buckets and the accumulation selects in its prologue.  In a
-//                                                chained schedule the kernel that starts the call also evaluates the
-//                                                accept test of the call in front (fold)
-//           k_obs_accumulate (+ dynamics blocks) median finish, weights, per-pose normal equations [+ orbit / attitude factor]
-//           [k_assemble]                         only when something reads the bands from memory: batched windows, sharded
-//                                                mode, the sequential / always-pivoting solvers
-//   trial   [solve]                              full phase: chunk elimination (forming its own blocks in latency mode),
-//                                                cyclic reduction of the separators; landmark-only phase: nothing in
-//                                                latency mode (the trial kernel solves its 6x6 systems itself)
-//           k_trial                              step + retraction (latency mode) + trial residuals + next call's keys
-//   decide  [k_decide]                           own launch unless the next call's first kernel folds it
-//
-// Latency mode, landmark-only call: 2 kernels (accumulate, trial); full call: 6 (+ assembly, chunks, two
-// cyclic-reduction kernels).  Call parity p: input states S[p], trial states S[p ^ 1] (see WinScalars).
-struct CallSpec {
-    bool host_out = false;  // pipelined vba_iterate_resident: trial states and last_hessian also go to mapped host memory
-    int iter = 0, initialize = 0;
-    int call = -1;          // index inside a chained schedule, -1: stand-alone
-    int par = 0;
-    int carry = 0;          // the keys of the input states are on the device: 0 no, 1 with their exponent histogram, 2 with a warm one
-    int emit = 0;           // leave the next call's keys behind: 0 no, 1 with the exponent histogram, 2 with the warm one
-    bool fold = false;      // first kernel evaluates the accept test of call - 1
-    bool prof = false;      // serialised schedule with an event between kernel classes
-};
-
-struct CallCtx {
-    DevView V;
-    hipEvent_t after_first = nullptr;   // recorded behind the kernel that starts the call (the folded accept test of the call in front is in it)
-    bool fuse_assemble = false;     // first trial's landmark-only solve rides in k_assemble<true> (batched windows)
-    bool assembled = false;         // an assembly kernel ran (profile bookkeeping)
-    bool bands_ready = false;       // bands / rhs are in memory (the fused landmark-only assembly does not write them)
-};
-
-void view_for_call(vba_handle h, DevView& V, const CallSpec& c) {
-    V = h->V;
-    V.m_total = 0; V.abs_all = nullptr; V.abs_all_count = 0;
-    V.reg = h->reg ? 1 : 0;
-    V.n_min = *std::min_element(h->n.begin(), h->n.end());
-    V.call = c.call;
-    V.par = c.par;
-    V.states = h->S[c.par];
-    V.wraw = h->wraw2 + (size_t)c.par * h->W * h->V.m_max;
-    V.Hraw = h->Hraw2 + (size_t)c.par * h->W * h->n_max * 21;
-    V.braw = h->braw2 + (size_t)c.par * h->W * h->n_max * 6;
-    {
-        const size_t wn = (size_t)c.par * h->W * h->n_max;
-        V.xhat = h->dyn2[0] + wn * 6; V.Phi = h->dyn2[1] + wn * 36; V.rorb = h->dyn2[2] + wn * 6; V.fatt = h->dyn2[3] + wn;
-        V.qgrad = h->dyn2[4] + wn * 3; V.Hd = h->dyn2[5] + wn * 9; V.Hu = h->dyn2[6] + wn * 9; V.Hl = h->dyn2[7] + wn * 9;
-    }
-    V.states_new = h->S[c.par ^ 1];
-    V.states_prev = h->S[c.par];
-    if (!c.host_out) V.host_states = nullptr;
-    V.emit = c.emit;
-    V.carry = c.carry;
-    V.fold = c.fold ? 1 : 0;
-    V.sel_inline = 0;
-    V.median_ready = 0;
-    V.redo = 0;
-    V.pending_only = 0;
-    V.warm_force_miss = h->warm_enabled == 2;
-    V.pivot = h->pivot_mode;
-    // sequential driver with several windows: four chains per wavefront (k_solve_quad); vba_set_solver(h, -3) asks for the
-    // older three-chain packing (equal pose counts only), -2 for one window per wavefront
-    V.pack = 0;
-    if (V.chunk <= 0 && !h->no_pack && h->W >= 2) {
-        V.pack = 2;
-        if (h->W >= h->pack_min) {
-            V.pack = 1;
-            for (int w = 1; w < h->W; ++w) if (h->n[w] != h->n[0]) V.pack = 2;
-        }
-    }
-    fill_params(V.prm, c.iter, c.initialize);
-    // who forms the step: latency mode lets the trial kernel do it (landmark-only: 6x6 solve per pose on the unpivoted
-    // path; full phase: recovery of the partitioned solve)
-    V.fused_trial = 0;
-    if (V.lat && (h->fusion & 1)) {     // every trial kernel of such a handle uses the 16-lanes-per-pose geometry
-        if (c.initialize) V.fused_trial = h->pivot_mode == 0 ? 1 : 3;
-        else V.fused_trial = V.chunk > 0 ? 2 : 3;
-        V.nblk_dyn = (V.n_max - 1 + 14) / 15;
-    }
-    V.fuse_blocks = (h->fusion & 2) ? 1 : 0;
-    V.resident = !V.lat ? 0 : (h->fusion & 64) ? 2 : (h->fusion & 32) ? 1 : 0;
-    V.chunk_waves = h->chunk_waves;
-    V.asm_rows = (h->fusion & 8) ? 1 : 0;
-    V.cr_levels = (h->fusion & 16) ? 1 : h->cr_levels;
-    V.fuse_walk = ((h->fusion & 4) && !V.lat) ? 1 : 0;
-}
-
-// the kernels in front of the first LM trial; ev (profiled variant): events that bracket the kernel classes
-int enqueue_front(vba_handle h, CallCtx& C, const CallSpec& c, bool exact_repeat, hipEvent_t* ev) {
-    DevView& V = C.V;
-    hipStream_t s = h->stream;
-    auto mark = [&](int k) { if (ev && ev[k]) (void)hipEventRecord(ev[k], s); };
-    const bool init = c.initialize != 0;
-    V.sel_inline = 0;       // (a repeat of the front after a missed warm select takes the exact digits and the plain prologue)
-    // the dynamics factor depends only on the states: with few windows its blocks ride in the accumulation's grid (no
-    // second stream, no cross-stream join), with many it runs beside the observation kernels on a second stream
-    const bool ride = !init && !c.prof && V.lat;
-    V.dyn_in_acc = ride ? 1 : 0;
-    static const bool no_overlap = std::getenv("VBA_NO_OVERLAP") != nullptr;     // diagnostic: dynamics in line on the main stream
-    const bool overlap = !init && !c.prof && !ride && !no_overlap;
-    auto fork_dynamics = [&]() -> int {
-        HIPCHK(hipEventRecord(h->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
-        launch_dynamics(V, h->aux_stream);
-        HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
-        return VBA_OK;
-    };
-    // a folding select is what moves the window on to this call (and reads the block sums the previous call's dynamics
-    // left): the second stream forks behind it, not in front
-    const bool fork_late = overlap && c.fold;
-    if (overlap && !fork_late) { if (int rc = fork_dynamics()) return rc; }
-    mark(1);
-    if (!c.carry) {
-        launch_obs_residual(V, nullptr, s);
-        mark(2);
-        launch_select(V, false, s);
-    } else if (c.carry == 2 && !exact_repeat) {
-        mark(2);
-        // bin buckets (latency mode): the accumulation resolves the histogram and ranks the wanted bin's bucket in its own
-        // prologue -- and, in a chained schedule, evaluates the accept test of the call in front there: no select kernel
-        V.sel_inline = (V.wbucket && h->inline_select) ? 1 : 0;
-        if (!V.sel_inline) launch_select_warm(V, s);
-    } else if (c.carry == 1 && !exact_repeat) {     // the trial left digit 0 (exponent histogram) behind: two passes
-        mark(2);
-        launch_select(V, false, s);
-    } else {            // a warm select that missed: the digit-0 slot holds the warm histogram, rebuild it by exponent
-        mark(2);
-        launch_clear_hist(V, 2, s);
-        launch_select(V, true, s);
-    }
-    if (fork_late) { if (int rc = fork_dynamics()) return rc; }
-    V.median_ready = (!V.sel_inline && !V.lat) ? 1 : 0;
-    if (V.median_ready) launch_select_finish(V, s);
-    mark(3);
-    launch_obs_accumulate(V, s);
-    if (C.after_first && V.sel_inline) HIPCHK(hipEventRecord(C.after_first, s));
-    mark(4);
-    if (!init && !overlap && !ride) launch_dynamics(V, s);
-    if (overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
-    mark(5);
-    C.fuse_assemble = init && h->pivot_mode == 0 && V.fused_trial != 1;
-    C.assembled = false;
-    C.bands_ready = false;
-    const bool need_bands = init ? V.fused_trial != 1 : !solve_forms_blocks(V);
-    if (need_bands) {
-        launch_assemble(V, C.fuse_assemble, s);
-        C.assembled = true;
-        C.bands_ready = !C.fuse_assemble;
-    }
-    mark(6);
-    return VBA_OK;
-}
-
-// one LM trial: solve (unless the trial kernel or the assembly formed the step) + trial residuals; ev_solve (profiled
-// variant): recorded between the two
-void enqueue_trial(vba_handle h, CallCtx& C, const CallSpec& c, bool first, hipEvent_t ev_solve = nullptr, int solve_redo = -1) {
-    DevView& V = C.V;
-    hipStream_t s = h->stream;
-    const bool init = c.initialize != 0;
-    const int redo_all = V.redo;
-    const bool pivoted_round = V.pivot != 0;
-    // landmark-only phase: does a solve kernel run, i.e. does anything read the diagonal blocks from memory?  Not in the
-    // first trial when the trial kernel or the fused assembly formed the step -- unless some window fell back to the
-    // pivoted kernels
-    const bool init_solve = init && (V.fused_trial == 1 ? pivoted_round : !(first && C.fuse_assemble));
-    if (init_solve && !C.bands_ready) {
-        launch_assemble(V, 0, s);
-        C.assembled = C.bands_ready = true;
-    }
-    if (solve_redo >= 0) V.redo = solve_redo;       // which windows the solve kernels of this round take (see step_impl)
-    if (init) {
-        if (init_solve) launch_solve(V, 1, s);
-    } else {
-        launch_solve(V, 0, s);
-    }
-    V.redo = redo_all;
-    if (ev_solve) (void)hipEventRecord(ev_solve, s);
-    launch_trial(V, s);
-}
-
-}  // namespace
-
-// readback >= 0: the states and scalars of that window are copied to the pinned read-back buffer right behind the first
-// trial (valid if that trial ends the call: h->back_valid), so that vba_iterate needs one wait instead of two.
-static int step_impl(vba_handle h, int iter, int initialize, float* prof, bool emit = true, int readback = -1) {
-    if (!h) return fail(VBA_EINVAL, "null handle");
-    if (int rc_settle = settle(h)) return rc_settle;
-    if (int rc = ready(h)) return rc;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    CallSpec c;
-    c.iter = iter; c.initialize = initialize; c.call = -1; c.par = h->par;
-    const int emit_kind = h->warm_enabled ? 2 : 1;
-    c.emit = (h->carry_enabled && emit) ? emit_kind : 0;
-    c.carry = h->carry_enabled ? h->carry_ok : 0;
-    c.prof = prof != nullptr;
-    h->carry_ok = 0;
-    h->shc.carried = false;         // (an unsharded call on a sharded handle: the gathered exchange of the last sharded trial is stale)
-    CallCtx C;
-    view_for_call(h, C.V, c);
-    DevView& V = C.V;
-    if (h->need_hist_reset) {       // an abandoned call may have left counts in any histogram
-        DevView Q = V;
-        for (int p = 0; p < 2; ++p) { Q.par = p; launch_clear_hist(Q, 1, s); }
-        h->need_hist_reset = false;
-        h->hist_dirty = false;
-    }
-    if (!c.carry && h->hist_dirty) launch_clear_hist(V, 0, s);     // the states were replaced after the last trial
-    h->hist_dirty = c.emit != 0;
-    struct ProfEvents {         // destroyed on every exit path, error returns included
-        hipEvent_t e[VBA_NKERNELS + 1] = {};
-        ~ProfEvents() { for (hipEvent_t q : e) if (q) (void)hipEventDestroy(q); }
-    } pe;
-    hipEvent_t* ev = pe.e;
-    if (prof) {
-        for (int k = 0; k <= VBA_NKERNELS; ++k) HIPCHK(hipEventCreate(&ev[k]));
-    }
-    auto mark = [&](int k) { if (prof) (void)hipEventRecord(ev[k], s); };
-    struct Abandon {            // any error return below leaves a half-run call behind
-        vba_handle h; bool armed = true;
-        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = 0; } }
-    } abandon{h};
-    HIPCHK(hipEventRecord(h->ev0, s));
-    mark(0);
-    if (int rc = enqueue_front(h, C, c, false, prof ? ev : nullptr)) return rc;
-    // LM loop (BA_filtering.py:52-77): lamda runs 1e-4 .. 1e4 in decades (at most 9 trials), plus one repeat per window for a
-    // pivoted fallback and one for a missed warm select; a loop that is still not done after kMaxTrials means the device
-    // never reported an outcome (a fault, a skipped window)
-    constexpr int kMaxTrials = 24;
-    bool finished = false, first = true;
-    int solve_redo = -1;
-    for (int trial = 0; trial < kMaxTrials; ++trial) {
-        enqueue_trial(h, C, c, first, (first && prof) ? ev[7] : nullptr, solve_redo);
-        solve_redo = -1;
-        if (first) mark(8);
-        launch_decide(V, nullptr, 0, s);
-        if (first) {
-            mark(9);
-            HIPCHK(hipEventRecord(h->ev1, s));
-        }
-        h->back_valid = false;
-        if (readback >= 0) {    // the trial states ARE the result if this trial ends the call
-            HIPCHK(hipMemcpyAsync(h->h_back, V.states_new + (size_t)readback * h->n_max * 10, (size_t)h->n[readback] * 80, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(h->h_back + (size_t)h->n_max * 10, V.sc + readback, sizeof(WinScalars), hipMemcpyDeviceToHost, s));
-        }
-        HIPCHK(hipGetLastError());
-        if (int rc = read_heads(h)) return rc;
-        first = false;
-        bool all = true, repeat = false, miss = false;
-        for (int w = 0; w < h->W; ++w) {
-            all = all && head(h, w)->done;
-            repeat = repeat || (head(h, w)->flags & 8u);
-            miss = miss || (head(h, w)->flags & 32u);
-        }
-        if (miss) {     // the warm select missed for some window: those repeat the call's front with the exact digits
-            for (int w = 0; w < h->W; ++w) if (head(h, w)->flags & 32u) h->h_head[w].flags = 0;
-            h->warm_misses++;
-            V.redo = 1;
-            CallSpec cr = c;
-            cr.prof = false;
-            if (int rc = enqueue_front(h, C, cr, true, nullptr)) return rc;
-            V.redo = 2;             // this round: their first trial, the others' next one
-            // ... whose solve the repeating windows skip when the assembly they just ran has formed their first step already
-            solve_redo = (c.initialize && C.fuse_assemble) ? 0 : 2;
-            continue;
-        }
-        V.redo = 0;
-        if (repeat && V.pivot == 0) {   // a pivot check failed on the fast path: those windows repeat the trial with row pivoting
-            V.pivot = 2;
-            h->fallbacks++;
-            continue;
-        }
-        if (all) {
-            h->back_valid = readback >= 0;      // the copies queued behind this (final) trial hold the result
-            finished = true;
-            break;
-        }
-    }
-    if (!finished)
-        return fail(VBA_ESTATE, "LM loop did not terminate within " + std::to_string(kMaxTrials) + " trials (no outcome reported by the device)");
-    abandon.armed = false;
-    HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
-    if (prof) {
-        for (int k = 0; k < VBA_NKERNELS; ++k) {
-            prof[k] = 0.f;
-            (void)hipEventElapsedTime(&prof[k], ev[k], ev[k + 1]);
-        }
-        if (c.carry) prof[VBA_K_RESIDUAL] = 0.f;        // not launched: the previous trial left the keys behind
-        if (c.initialize && (C.fuse_assemble || V.fused_trial == 1)) prof[VBA_K_SOLVE] = 0.f;   // no solve launch: formed inside k_assemble<true> / k_trial
-        if (!C.assembled) prof[VBA_K_ASSEMBLE] = 0.f;
-        if (c.initialize) prof[VBA_K_DYNAMICS] = 0.f;
-    }
-    h->par ^= 1;                    // the trial buffer is the next call's input
-    h->carry_ok = c.emit;           // (the kind of histogram that came with the keys)
-    h->stepped = true;
-    h->last_pipelined = false;
-    h->prev_res_iter = -1;          // (not a link of the resident loop: nothing to learn from what follows it)
-    h->last_iter = iter;
-    h->last_init = initialize;
-    return VBA_OK;
-}
-
-int vba_step(vba_handle h, int iter, int initialize) { return step_impl(h, iter, initialize, nullptr); }
-
-// The first trial of call q.call has been evaluated for the windows that stand at it (stall_at[w] == q.call) but was not
-// cleanly accepted by the kernel that was to start the next call (or the call's warm select missed): finish the call the
-// ordinary way -- decide, repeat the front with the exact digits where the select missed, further LM trials, the pivoted
-// repeat -- until every such window has moved on.  Shared by vba_run_schedule and the pipelined vba_iterate_resident.
-static int finish_stalled_call(vba_handle h, const CallSpec& q, const std::vector<int>& stall_at, long& trials) {
-    hipStream_t s = h->stream;
-    const int sc_call = q.call;
-    static const bool trace = std::getenv("VBA_TRACE") != nullptr;
-    CallCtx C;
-    view_for_call(h, C.V, q);
-    DevView& V = C.V;
-    // the front of this call has run (for the windows that reached it); what is on the device of it:
-    C.fuse_assemble = q.initialize && h->pivot_mode == 0 && V.fused_trial != 1;
-    C.assembled = q.initialize ? V.fused_trial != 1 : !solve_forms_blocks(V);
-    C.bands_ready = C.assembled && !C.fuse_assemble;
-    auto at_call = [&](int w) { return stall_at[w] == sc_call && head(h, w)->call_idx == sc_call; };
-    bool any_miss = false;
-    for (int w = 0; w < h->W; ++w) any_miss = any_miss || (at_call(w) && (head(h, w)->flags & 32u));
-    // (1) the first trial of the windows that got that far has been evaluated but not decided (the decision was left
-    //     to the next call's first kernel, which found it not clean): decide it now
-    V.pending_only = 1;
-    launch_decide(V, nullptr, 0, s);
-    V.pending_only = 0;
-    // (2) windows whose warm select missed repeat the front with the exact digits and run their first trial
-    if (any_miss) {
-        for (int w = 0; w < h->W; ++w) if (at_call(w) && (head(h, w)->flags & 32u)) h->h_head[w].flags = 0;
-        h->warm_misses++;
-        V.redo = 1;
-        if (int rc = enqueue_front(h, C, q, true, nullptr)) return rc;
-        enqueue_trial(h, C, q, true);
-        launch_decide(V, nullptr, 0, s);
-        V.redo = 0;
-        ++trials;
-    }
-    HIPCHK(hipGetLastError());
-    if (int rc = read_heads(h)) return rc;
-    bool finished = false;
-    for (int trial = 0; trial <= 24; ++trial) {
-        bool repeat = false, all = true;
-        for (int w = 0; w < h->W; ++w) {
-            if (!at_call(w)) continue;
-            all = false;
-            repeat = repeat || (head(h, w)->flags & 8u);
-        }
-        if (all) { finished = true; break; }
-        if (trial == 24) break;
-        if (repeat && V.pivot == 0) { V.pivot = 2; h->fallbacks++; }
-        enqueue_trial(h, C, q, false);
-        launch_decide(V, nullptr, 0, s);
-        HIPCHK(hipGetLastError());
-        if (int rc = read_heads(h)) return rc;
-        ++trials;
-        if (trace) {
-            std::fprintf(stderr, "[vba]   call %d round %d pivot %d:", sc_call, trial, V.pivot);
-            for (int w = 0; w < h->W && w < 8; ++w)
-                std::fprintf(stderr, " w%d(call %d done %d flags %u ntr %d lam %g)", w, head(h, w)->call_idx, head(h, w)->done, head(h, w)->flags, head(h, w)->n_trials, head(h, w)->lamda);
-            std::fprintf(stderr, "\n");
-        }
-    }
-    if (!finished)
-        return fail(VBA_ESTATE, "LM loop of call " + std::to_string(sc_call) + " did not terminate (no outcome reported by the device)");
-    return VBA_OK;
-}
-
-// The 20-call loop of the driver (od_pipe.py:1036-1040) as ONE host call.  The kernels of every call are enqueued
-// back to back with a single LM trial each and, on carried keys, without a decide launch between them: the first kernel
-// of call c + 1 evaluates the accept test of call c itself.  A window whose first trial is not cleanly accepted (rejected,
-// pivot check failed) or whose warm select misses does not advance its device-side call counter, all later kernels skip
-// it, and the host finishes that call the ordinary way before re-enqueuing the rest.  Results are identical to ncalls
-// vba_step calls.
-int vba_run_schedule(vba_handle h, int ncalls, const int* iters, const int* inits, int* trials_total) {
-    if (!h || !iters || !inits || ncalls < 1) return fail(VBA_EINVAL, "bad argument");
-    if (int rc_settle = settle(h)) return rc_settle;
-    if (int rc = ready(h)) return rc;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    const int par0 = h->par;
-    const int emit_kind = h->carry_enabled ? (h->warm_enabled ? 2 : 1) : 0;
-    const int carry0 = h->carry_enabled ? h->carry_ok : 0;
-    h->carry_ok = 0;
-    h->shc.carried = false;
-    struct Abandon {
-        vba_handle h; bool armed = true;
-        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = 0; } }
-    } abandon{h};
-    auto spec = [&](int c, bool fold) {
-        CallSpec q;
-        q.iter = iters[c]; q.initialize = inits[c]; q.call = c; q.par = (par0 + c) & 1;
-        q.carry = c == 0 ? carry0 : emit_kind;              // every later call starts from a trial of this chain
-        q.emit = emit_kind;
-        q.fold = fold;
-        return q;
-    };
-    {
-        DevView V0;
-        view_for_call(h, V0, spec(0, false));
-        if (h->need_hist_reset) {
-            DevView Q = V0;
-            for (int p = 0; p < 2; ++p) { Q.par = p; launch_clear_hist(Q, 1, s); }
-            h->need_hist_reset = false;
-            h->hist_dirty = false;
-        }
-        if (!carry0 && h->hist_dirty) launch_clear_hist(V0, 0, s);
-        launch_reset_calls(V0, s);
-    }
-    h->hist_dirty = emit_kind != 0;
-    for (int w = 0; w < h->W; ++w) { h->h_head[w].call_idx = 0; h->h_head[w].done = 0; h->h_head[w].flags = 0; }
-    long trials = 0;
-    int next = 0;
-    bool complete = false;
-    const bool prof_pass = h->cprof.on;
-    if (prof_pass) {
-        while ((int)h->cprof.ev.size() < 4 * ncalls) {
-            hipEvent_t e = nullptr;
-            HIPCHK(hipEventCreate(&e));
-            h->cprof.ev.push_back(e);
-        }
-    }
-    // The first pass of a latency-mode handle -- ~70 dependent launches for the driver's 20 calls -- is captured once as a hipGraph and
-    // replayed while nothing that goes into its launches has changed: 45.2 -> 42.7 us per call at C3 (the packets of a graph reach the
-    // queue in one piece; launched one by one every kernel boundary also pays the runtime's per-launch bookkeeping on the device's
-    // clock).  What goes into the launches: the per-call views (every kernel takes its DevView by value: hashed byte for byte), the
-    // schedule, and the handful of host-side switches the enqueue functions read.  Stalled calls are finished by the host afterwards
-    // exactly as without a graph.  VBA_NO_GRAPH=1 launches kernel by kernel (comparison).
-    static const bool no_graph = std::getenv("VBA_NO_GRAPH") != nullptr;
-    for (int guard = 0; guard <= ncalls; ++guard) {
-        bool capturing = false, replayed = false;
-        std::vector<unsigned long long> gkey;
-        std::vector<unsigned char> gviews;
-        // (latency-mode handles only: with the second stream of the bandwidth mode forked inside it the replay measured 1 .. 2.5 % SLOWER
-        // than the launches one by one, 40 .. 1024 windows)
-        // (... and not while the chain profile records its events: event records inside a capture fail on this runtime, "invalid resource
-        // handle" -- the class times of vba_chain_profile are those of the kernel-by-kernel launches)
-        // (... nor with the resident solve of the comparison build, vba_set_fusion bits 5 / 6: its kernels take the epoch of the launch as
-        // an argument, which a replay would freeze -- the consumers' flags would read as already set)
-        if (!no_graph && h->graph_enabled && guard == 0 && !prof_pass && h->V.lat && !h->graph_broken && next == 0 && (h->fusion & 96) == 0) {
-            gkey.reserve(8 + 3 * (size_t)ncalls);
-            gviews.resize((size_t)ncalls * sizeof(DevView));
-            gkey.push_back((unsigned long long)ncalls); gkey.push_back((unsigned long long)par0); gkey.push_back((unsigned long long)carry0);
-            gkey.push_back((unsigned long long)emit_kind); gkey.push_back((unsigned long long)h->pivot_mode);
-            gkey.push_back((unsigned long long)h->inline_select | ((unsigned long long)h->fold_enabled << 1));
-            gkey.push_back((unsigned long long)(uintptr_t)s);
-            for (int c = 0; c < ncalls; ++c) {
-                const bool fold = c > 0 && emit_kind == 2 && h->fold_enabled;
-                DevView Vc;
-                view_for_call(h, Vc, spec(c, fold));
-                if (fold) fill_params(Vc.prev, iters[c - 1], inits[c - 1]);
-                unsigned long long hsh = 1469598103934665603ull;
-                const unsigned char* bytes = reinterpret_cast<const unsigned char*>(&Vc);
-                std::memcpy(gviews.data() + (size_t)c * sizeof(DevView), bytes, sizeof(DevView));
-                for (size_t o = 0; o + 8 <= sizeof(DevView); o += 8) {
-                    unsigned long long wd;
-                    std::memcpy(&wd, bytes + o, 8);
-                    hsh = (hsh ^ wd) * 1099511628211ull;
-                    hsh ^= hsh >> 29;
-                }
-                gkey.push_back(hsh); gkey.push_back((unsigned long long)iters[c]); gkey.push_back((unsigned long long)inits[c]);
-            }
-            size_t hit = h->graphs.size();
-            for (size_t k = 0; k < h->graphs.size(); ++k)
-                if (h->graphs[k].key == gkey && h->graphs[k].views == gviews) { hit = k; break; }
-            if (hit < h->graphs.size()) {
-                if (hit != 0) std::rotate(h->graphs.begin(), h->graphs.begin() + hit, h->graphs.begin() + hit + 1);     // most recently used first
-                if (hipGraphLaunch(h->graphs[0].exec, s) == hipSuccess) { replayed = true; h->graph_replays++; }
-                else { (void)hipGetLastError(); h->graph_broken = true; }
-            } else {
-                if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) capturing = true;
-                else { (void)hipGetLastError(); h->graph_broken = true; }
-            }
-        }
-        struct CaptureGuard {       // (an early return between begin and end must not leave the stream capturing)
-            hipStream_t s; bool* on;
-            ~CaptureGuard() {
-                if (*on) {
-                    hipGraph_t g = nullptr;
-                    (void)hipStreamEndCapture(s, &g);
-                    if (g) (void)hipGraphDestroy(g);
-                    (void)hipGetLastError();
-                }
-            }
-        } capture_guard{s, &capturing};
-        // speculative part: calls next .. ncalls-1, one trial each
-        auto enqueue_pass = [&]() -> int {
-        for (int c = next; c < ncalls && !replayed; ++c) {
-            const bool fold = c > next && emit_kind == 2 && h->fold_enabled;       // call c-1 of this pass left its decision to this call's warm select
-            const CallSpec q = spec(c, fold);
-            CallCtx C;
-            view_for_call(h, C.V, q);
-            if (fold) fill_params(C.V.prev, iters[c - 1], inits[c - 1]);
-            // chain profile (first pass only): events in front of / behind the accumulation (what runs in front of it --
-            // select kernels of the bandwidth mode -- counts as accumulate class: the first event is moved there), behind
-            // the solve and behind the trial
-            hipEvent_t marks[VBA_NKERNELS + 1] = {};
-            hipEvent_t* pe = nullptr;
-            if (prof_pass && guard == 0) {
-                pe = h->cprof.ev.data() + (size_t)4 * c;
-                marks[1] = pe[0];
-                marks[6] = pe[1];
-            }
-            if (int rc = enqueue_front(h, C, q, false, pe ? marks : nullptr)) return rc;
-            enqueue_trial(h, C, q, true, pe ? pe[2] : nullptr);
-            if (pe) HIPCHK(hipEventRecord(pe[3], s));
-            const bool next_folds = c + 1 < ncalls && emit_kind == 2 && h->fold_enabled;
-            if (!next_folds) launch_decide(C.V, nullptr, 0, s);
-        }
-        return VBA_OK;
-        };
-        if (int rc = enqueue_pass()) return rc;
-        if (capturing) {
-            // A capture that cannot be ended, instantiated or launched has executed NOTHING (its kernels were only recorded): the
-            // handle gives up on graphs (graph_broken: kernel by kernel from then on) and this pass is enqueued again, for real.
-            // VBA_GRAPH_FAIL_INJECT = 1 / 2 / 3 pretends that step failed (tests/test_gpu_bench_paths.py).
-            static const int inject = std::getenv("VBA_GRAPH_FAIL_INJECT") ? std::atoi(std::getenv("VBA_GRAPH_FAIL_INJECT")) : 0;
-            hipGraph_t g = nullptr;
-            capturing = false;
-            hipGraphExec_t exec = nullptr;
-            bool ok = hipStreamEndCapture(s, &g) == hipSuccess && g != nullptr && inject != 1;
-            if (ok) ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess && inject != 2;
-            if (g) (void)hipGraphDestroy(g);
-            if (ok && (inject == 3 || hipGraphLaunch(exec, s) != hipSuccess)) ok = false;
-            if (!ok) {
-                (void)hipGetLastError();
-                if (exec) (void)hipGraphExecDestroy(exec);
-                h->graph_broken = true;
-                if (int rc = enqueue_pass()) return rc;
-            } else {
-            constexpr size_t kGraphCache = 8;
-            if (h->graphs.size() >= kGraphCache) {
-                // (the evicted graph may still be executing: the stream is idle here only if the caller made it so -- wait)
-                HIPCHK(hipStreamSynchronize(s));
-                (void)hipGraphExecDestroy(h->graphs.back().exec);
-                h->graphs.pop_back();
-            }
-            vba_context::GraphEntry ge;
-            ge.key = gkey;
-            ge.views = std::move(gviews);
-            ge.exec = exec;
-            h->graphs.insert(h->graphs.begin(), std::move(ge));
-            h->graph_captures++;
-            }
-        }
-        HIPCHK(hipGetLastError());
-        if (int rc = read_heads(h)) return rc;
-        trials += (long)(ncalls - next);
-        // After a pass over calls next .. ncalls-1 every window whose counter is below ncalls is stalled AT that call.
-        // Every stalled call is finished with the ordinary LM loop -- each one, not only the earliest: a window left at a
-        // later call would otherwise run that call again from its start when the chain is re-issued.
-        std::vector<int> stalled, stall_at((size_t)h->W);
-        for (int w = 0; w < h->W; ++w) {
-            const int c = (int)head(h, w)->call_idx;
-            stall_at[w] = c;        // a window that the loop below moves on INTO a later stalled call has not run that call's front: it waits for the re-issue
-            if (c < ncalls && std::find(stalled.begin(), stalled.end(), c) == stalled.end()) stalled.push_back(c);
-        }
-        if (prof_pass && guard == 0 && stalled.empty()) {       // every call ran once, in order: its three intervals count
-            for (int c = 0; c < ncalls; ++c) {
-                const hipEvent_t* pe = h->cprof.ev.data() + (size_t)4 * c;
-                for (int k = 0; k < 3; ++k) {
-                    float ms = 0.f;
-                    if (k == 1 && inits[c]) continue;       // landmark-only call: the step is formed in front of or inside the trial kernel, no solve launch
-                    if (hipEventElapsedTime(&ms, pe[k], pe[k + 1]) == hipSuccess) {
-                        h->cprof.ms[k] += ms;
-                        h->cprof.launches[k]++;
-                    }
-                }
-            }
-        }
-        if (stalled.empty()) { complete = true; break; }
-        std::sort(stalled.begin(), stalled.end());
-        static const bool trace = std::getenv("VBA_TRACE") != nullptr;
-        if (trace) {
-            std::fprintf(stderr, "[vba] pass from call %d:", next);
-            for (int w = 0; w < h->W && w < 8; ++w)
-                std::fprintf(stderr, " w%d(call %d done %d flags %u ntr %d)", w, head(h, w)->call_idx, head(h, w)->done, head(h, w)->flags, head(h, w)->n_trials);
-            std::fprintf(stderr, "\n");
-        }
-        for (int sc_call : stalled) {
-            if (int rc = finish_stalled_call(h, spec(sc_call, false), stall_at, trials)) return rc;
-        }
-        next = stalled.front() + 1;
-        if (next >= ncalls) { complete = true; break; }
-    }
-    if (!complete) {
-        complete = true;
-        for (int w = 0; w < h->W; ++w) complete = complete && head(h, w)->call_idx >= ncalls;
-        if (!complete) return fail(VBA_ESTATE, "chained schedule did not complete (a window never reached its last call)");
-    }
-    abandon.armed = false;
-    if (trials_total) *trials_total = (int)trials;
-    h->par = (par0 + ncalls) & 1;
-    h->carry_ok = emit_kind;
-    h->stepped = true;
-    h->last_pipelined = false;
-    h->last_iter = iters[ncalls - 1];
-    h->last_init = inits[ncalls - 1];
-    return VBA_OK;
-}
-
-static int vba_set_schedule_graph(vba_handle h, int on) {
-    if (!h) return fail(VBA_EINVAL, "null handle");
-    if (int rc = settle(h)) return rc;
-    h->graph_enabled = on != 0;
-    return VBA_OK;
-}
-
-int vba_schedule_graph_stats(vba_handle h, int* captures, int* replays) {
-    if (!h) return fail(VBA_EINVAL, "null handle");
-    if (captures) *captures = (int)h->graph_captures;
-    if (replays) *replays = (int)h->graph_replays;
-    return VBA_OK;
-}
-
-static int vba_set_chain_profile(vba_handle h, int on) {
-    if (!h) return fail(VBA_EINVAL, "null handle");
-    if (int rc = settle(h)) return rc;
-    h->cprof.on = on != 0;
-    return VBA_OK;
-}
 
 // the settings a caller of BA() never needs, behind one entry point (include/vinsat_ba.h: VBA_OPT_*)
 int vba_set_option(vba_handle h, int option, int value) {
@@ -1707,300 +896,6 @@ int vba_set_option(vba_handle h, int option, int value) {
         case VBA_OPT_CHAIN_PROFILE: return vba_set_chain_profile(h, value);
         default: return fail(VBA_EINVAL, "unknown option (VBA_OPT_*)");
     }
-}
-
-int vba_chain_profile(vba_handle h, double* ms, int64_t* launches, int reset) {
-    if (!h) return fail(VBA_EINVAL, "null handle");
-    for (int k = 0; k < 3; ++k) {
-        if (ms) ms[k] = h->cprof.ms[k];
-        if (launches) launches[k] = h->cprof.launches[k];
-        if (reset) { h->cprof.ms[k] = 0.0; h->cprof.launches[k] = 0; }
-    }
-    return VBA_OK;
-}
-
-int vba_step_profiled(vba_handle h, int iter, int initialize, float* ms) {
-    if (!ms) return fail(VBA_EINVAL, "null ms");
-    return step_impl(h, iter, initialize, ms);
-}
-
-static int take_back(vba_handle h, double* states_out, double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags) {
-    if (h->back_valid) {        // read back together with the step: no second wait
-        const WinScalars* sc = reinterpret_cast<const WinScalars*>(h->h_back + (size_t)h->n_max * 10);
-        if (states_out) std::memcpy(states_out, h->h_back, (size_t)h->n[0] * 80);
-        unpack_scalars(sc, h->par, lamda_out, last_hessian, n_trials, flags);
-        return VBA_OK;
-    }
-    return vba_get_states(h, 0, states_out, lamda_out, last_hessian, n_trials, flags);
-}
-
-int vba_iterate(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in, double* states_out,
-                double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags) {
-    if (int rc = vba_set_states(h, 0, states_in, lamda_in)) return rc;
-    // the next call of this kind replaces the states again: nothing to carry over
-    if (int rc = step_impl(h, iter, initialize, nullptr, false, 0)) return rc;
-    return take_back(h, states_out, lamda_out, last_hessian, n_trials, flags);
-}
-
-static bool can_pipeline(vba_handle h);
-static bool host_watch_changed(vba_handle h);
-static int iterate_pipelined(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out, double* last_hessian,
-                             int* n_trials, unsigned* flags);
-
-// vba_iterate as the FIRST call of a driver loop whose following calls will be vba_iterate_resident: the states go up, and the call
-// itself is served like a resident one -- returned as soon as its accept test is known, with the next call already enqueued behind
-// it (a caller that does not come back with a resident call pays for that speculation: use vba_iterate there).
-int vba_iterate_open(vba_handle h, int iter, int initialize, double lamda_in, const double* states_in, double* states_out,
-                     double* lamda_out, double* last_hessian, int* n_trials, unsigned* flags) {
-    if (int rc = vba_set_states(h, 0, states_in, lamda_in)) return rc;
-    if (can_pipeline(h)) return iterate_pipelined(h, iter, initialize, states_out, lamda_out, last_hessian, n_trials, flags);
-    const bool watch_changed = host_watch_changed(h);       // (like every resident call: the caller relies on it)
-    if (int rc = step_impl(h, iter, initialize, nullptr, false, 0)) return rc;
-    if (int rc = take_back(h, states_out, lamda_out, last_hessian, n_trials, flags)) return rc;
-    if (flags && watch_changed) *flags |= VBA_FLAG_HOST_CHANGED;
-    return VBA_OK;
-}
-
-// The driver loop `for iter in range(20): states, ... = BA(iter, states, ...)` (od_pipe.py:1036-1040) hands every call the
-// result of the one before, through the host.  Served call by call the device idles while the host unpacks one result and
-// enqueues the next call, and the host idles while the device works.  Here the two overlap: behind the call that is being
-// returned the NEXT call is enqueued speculatively (what follows iter k is learnt from the caller: k + 1 until told
-// otherwise), its first kernel evaluates the accept test of the call in front -- exactly the chained schedule of
-// vba_run_schedule, one link at a time -- and the host waits only for that kernel plus a 40 kB copy on a side stream,
-// while the rest of the speculated call runs under the caller's feet.  When the caller comes back with the predicted
-// arguments the call is already on its way.  A wrong guess costs one call's worth of device time and the carried keys
-// (settle); a first trial that is not cleanly accepted sends this call through the ordinary LM loop.  Same bits as
-// vba_step: the kernels, their order inside a call and the accept test are those of the chained schedule.
-static bool host_watch_changed(vba_handle h) {
-    for (const auto& w : h->watch)
-        if (w.live && std::memcmp(w.live, w.copy, w.bytes) != 0) return true;
-    return false;
-}
-// ... the same on the handle's helper thread: begin before the enqueues, end once the device has answered.  Small watch lists
-// (under 64 kB) are compared in place by watch_end: waking a thread costs more than that.
-static size_t host_watch_bytes(vba_handle h) {
-    size_t b = 0;
-    for (const auto& w : h->watch) if (w.live) b += w.bytes;
-    return b;
-}
-static bool watch_begin(vba_handle h) {
-    if (host_watch_bytes(h) < 65536) return false;
-    auto& W = h->ww;
-    if (W.started && W.owner != getpid()) return false;     // forked child: no helper here, the caller compares in place
-    if (!W.started) {
-        W.started = true;
-        W.owner = getpid();
-        W.th = std::thread([h]() {
-            auto& Q = h->ww;
-            unsigned long long taken = 0;
-            for (;;) {
-                {
-                    std::unique_lock<std::mutex> lk(Q.m);
-                    Q.cv.wait(lk, [&] { return Q.quit || Q.seq != taken; });
-                    if (Q.quit) return;
-                    taken = Q.seq;
-                }
-                Q.changed = host_watch_changed(h);
-                Q.done_seq.store(taken, std::memory_order_release);
-            }
-        });
-    }
-    {
-        std::lock_guard<std::mutex> lk(W.m);
-        ++W.seq;
-    }
-    W.cv.notify_one();
-    return true;
-}
-static bool watch_end(vba_handle h, bool begun) {
-    if (!begun) return host_watch_changed(h);
-    auto& W = h->ww;
-    // (bounded: a helper that does not answer within 20 ms -- a forked child has none, a starved host may park it -- is not waited
-    // for; the comparison is then made here, beside it if it still runs: both only read)
-    const auto t0 = std::chrono::steady_clock::now();
-    const unsigned long long mine = W.seq;      // (written by this thread only)
-    for (unsigned spins = 0; W.done_seq.load(std::memory_order_acquire) != mine; ++spins) {
-        __builtin_ia32_pause();
-        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return host_watch_changed(h);
-    }
-    return W.changed;
-}
-// the helper has answered every request (a wait that gave up after 20 ms may have left it comparing): before the watch list changes
-static void watch_quiesce(vba_handle h) {
-    auto& W = h->ww;
-    if (!W.started || W.owner != getpid()) return;          // (a forked child has no helper to wait for)
-    while (W.done_seq.load(std::memory_order_acquire) != W.seq) std::this_thread::yield();
-}
-static void watch_stop(vba_handle h) {
-    auto& W = h->ww;
-    if (!W.started) return;
-    if (W.owner != getpid()) {      // forked child: the thread object refers to a thread of the parent -- let go of it, never join
-        W.th.detach();
-        W.started = false;
-        return;
-    }
-    {
-        std::lock_guard<std::mutex> lk(W.m);
-        W.quit = true;
-    }
-    W.cv.notify_one();
-    W.th.join();
-    W.started = false;
-}
-
-static bool can_pipeline(vba_handle h) {
-    // (whichever kernel forms the trial states of an unpivoted call -- the trial kernel, or with fusion bit 0 off the fused landmark-only
-    // assembly / the recovery of the partitioned solve -- also writes them to mapped host memory)
-    return h->pipeline && h->W == 1 && h->h_states_map && h->carry_enabled && h->warm_enabled >= 1 && h->fold_enabled && h->inline_select &&
-           h->V.wbucket != nullptr && h->pivot_mode == 0 && h->V.chunk > 0 && h->V.lat;
-}
-
-static int iterate_pipelined(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out, double* last_hessian,
-                             int* n_trials, unsigned* flags) {
-    if (int rc = ready(h)) return rc;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    constexpr int emit_kind = 2;
-    initialize = initialize ? 1 : 0;
-    // what the caller did after the previous resident call: remember it
-    if (h->prev_res_iter >= 0) {
-        h->pred_iter[h->prev_res_iter & 63] = iter;
-        h->pred_init[h->prev_res_iter & 63] = initialize;
-    }
-    bool consumed = false;
-    if (h->spec.valid) {
-        if (h->spec.iter == iter && h->spec.init == initialize && h->spec.reg == h->reg) {
-            consumed = true;
-            h->spec_hits++;
-        } else if (int rc = settle(h)) {
-            return rc;
-        }
-    }
-    struct Abandon {
-        vba_handle h; bool armed = true;
-        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = 0; h->spec.valid = false; h->prev_res_iter = -1; } }
-    } abandon{h};
-    auto call_spec = [&](int c, int it, int in, int carry, bool fold) {
-        CallSpec q;
-        q.iter = it; q.initialize = in; q.call = c; q.par = (h->chain_par0 + c) & 1;
-        q.carry = carry; q.emit = emit_kind; q.fold = fold;
-        q.host_out = true;
-        return q;
-    };
-    bool watch_changed = false;
-    int c;                      // index of THIS call in the open chain
-    if (consumed) {
-        c = h->spec.c;
-        h->spec.valid = false;
-    } else {                    // open a chain with this call as its call 0
-        const int carry0 = h->carry_ok;
-        h->carry_ok = 0;
-        h->shc.carried = false;
-        h->chain_par0 = h->par;
-        c = 0;
-        const CallSpec q = call_spec(0, iter, initialize, carry0, false);
-        CallCtx C;
-        view_for_call(h, C.V, q);
-        if (h->need_hist_reset) {
-            DevView Q = C.V;
-            for (int p = 0; p < 2; ++p) { Q.par = p; launch_clear_hist(Q, 1, s); }
-            h->need_hist_reset = false;
-            h->hist_dirty = false;
-        }
-        if (!carry0 && h->hist_dirty) launch_clear_hist(C.V, 0, s);
-        launch_reset_calls(C.V, s);
-        h->h_head[0].call_idx = 0; h->h_head[0].done = 0; h->h_head[0].flags = 0;
-        if (int rc = enqueue_front(h, C, q, false, nullptr)) return rc;
-        enqueue_trial(h, C, q, true);
-    }
-    h->hist_dirty = true;
-    // the call behind it, speculatively: its first kernel decides this one
-    int ni = h->pred_iter[iter & 63], nin = h->pred_init[iter & 63];
-    if (ni == -1) { ni = iter + 1; nin = initialize; }
-    const bool speculate = ni >= 0;
-    const CallSpec qc = call_spec(c, iter, initialize, emit_kind, false);       // (this call, as the stalled path needs it)
-    const int par_c = qc.par;
-    const bool watching = watch_begin(h);
-    struct WatchJoin {          // (an early return must not leave the helper comparing buffers the caller may free)
-        vba_handle h; bool begun; bool joined = false;
-        bool end() { joined = true; return watch_end(h, begun); }
-        ~WatchJoin() { if (begun && !joined) (void)watch_end(h, true); }
-    } wj{h, watching};
-    if (speculate) {
-        const CallSpec qn = call_spec(c + 1, ni, nin, emit_kind, true);
-        CallCtx C;
-        view_for_call(h, C.V, qn);
-        fill_params(C.V.prev, iter, initialize);
-        C.after_first = h->ev_first;
-        if (int rc = enqueue_front(h, C, qn, false, nullptr)) return rc;
-        enqueue_trial(h, C, qn, true);
-        // the first kernel of the speculated call has decided this one; the trial states and the outcome are in mapped host
-        // memory by then (k_trial, fold_commit): no copy, the rest of the speculated call runs on under the caller's feet
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventSynchronize(h->ev_first));
-        watch_changed = wj.end();       // (compared while the device worked)
-    } else {                    // nothing resident is expected behind this call: decide it with a launch of its own
-        CallCtx C;
-        view_for_call(h, C.V, qc);
-        launch_decide(C.V, nullptr, 0, s);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
-        watch_changed = wj.end();
-    }
-    h->stepped = true;
-    h->last_pipelined = true;
-    h->last_iter = iter;
-    h->last_init = initialize;
-    h->back_valid = false;
-    const bool clean = (int)head(h, 0)->call_idx >= c + 1;
-    if (clean) {
-        h->par = par_c ^ 1;             // the trial buffer of this call is the next call's input
-        const volatile WinHead* hd = head(h, 0);
-        if (states_out) std::memcpy(states_out, h->h_states_map + (size_t)par_c * h->n_max * 10, (size_t)h->n[0] * 80);
-        if (lamda_out) *lamda_out = hd->lamda;
-        if (last_hessian) for (int k = 0; k < 81; ++k) last_hessian[k] = hd->last_hessian[k];
-        if (n_trials) *n_trials = 1;    // (a clean first trial)
-        if (flags) *flags = (hd->flags & 7u) | (watch_changed ? VBA_FLAG_HOST_CHANGED : 0u);
-        if (speculate) {
-            h->spec.valid = true; h->spec.iter = ni; h->spec.init = nin; h->spec.reg = h->reg; h->spec.c = c + 1;
-            h->carry_ok = 0;            // (the keys of the result belong to the speculated call now; settle() keeps the books)
-        } else {
-            h->carry_ok = emit_kind;
-        }
-        h->prev_res_iter = iter;
-        abandon.armed = false;
-        return VBA_OK;
-    }
-    // Not a clean first trial (rejected, pivot check failed, warm select missed): the speculated call has skipped itself
-    // (the window never moved on to it); finish this call the ordinary way.
-    HIPCHK(hipStreamSynchronize(s));
-    {
-        std::vector<int> stall_at(1, c);
-        long trials = 0;
-        if ((int)head(h, 0)->call_idx != c) return fail(VBA_ESTATE, "pipelined call: the window is at call " + std::to_string(head(h, 0)->call_idx) + ", expected " + std::to_string(c));
-        if (int rc = finish_stalled_call(h, qc, stall_at, trials)) return rc;
-    }
-    h->par = par_c ^ 1;
-    h->carry_ok = emit_kind;            // the accepted (or last) trial left the next call's keys behind
-    h->prev_res_iter = iter;
-    abandon.armed = false;
-    if (int rc = vba_get_states(h, 0, states_out, lamda_out, last_hessian, n_trials, flags)) return rc;
-    if (flags && watch_changed) *flags |= VBA_FLAG_HOST_CHANGED;
-    return VBA_OK;
-}
-
-// The next call of a driver loop that hands BA() the states it got back from the previous call: nothing to upload, the
-// device already holds them (and the carried keys of the last accepted trial stay usable).
-int vba_iterate_resident(vba_handle h, int iter, int initialize, double* states_out, double* lamda_out, double* last_hessian,
-                         int* n_trials, unsigned* flags) {
-    if (!h) return fail(VBA_EINVAL, "null handle");
-    if (!h->stepped) return fail(VBA_ESTATE, "vba_iterate_resident follows a call that left its result on the device");
-    if (can_pipeline(h)) return iterate_pipelined(h, iter, initialize, states_out, lamda_out, last_hessian, n_trials, flags);
-    const bool watch_changed = host_watch_changed(h);
-    if (int rc = step_impl(h, iter, initialize, nullptr, true, 0)) return rc;
-    if (int rc = take_back(h, states_out, lamda_out, last_hessian, n_trials, flags)) return rc;
-    if (flags && watch_changed) *flags |= VBA_FLAG_HOST_CHANGED;
-    return VBA_OK;
 }
 
 int vba_last_step_ms(vba_handle h, float* ms) {
@@ -2163,544 +1058,3 @@ int vba_debug_fetch(vba_handle h, int window, int what, double* out, int64_t cap
     }
 }
 
-// ------------------------------------------------------------------------------------------------ sharded mode
-int64_t vba_sh_partial_count(int n) { return 27 * (int64_t)n + 2; }
-
-// the device view of the sharded call in flight: classic kernels throughout (the bands go through memory, the trial reads
-// the trial states the recovery wrote, every accept test is its own launch)
-static void sharded_view(vba_handle h, DevView& V) {
-    CallSpec c;
-    c.iter = h->last_iter; c.initialize = h->last_init; c.call = -1; c.par = h->par;
-    view_for_call(h, V, c);
-    // Since round 3 the pose-chain part of a sharded call uses the latency-mode kernels of the handle (one window): the
-    // dynamics factor rides in the accumulation's grid, the chunk elimination forms its own blocks, the trial kernel forms
-    // the step (no assembly / recovery launches; the landmark-only phase has no solve launch at all).  What stays classic
-    // is everything keyed to the exchanges: keys recomputed per call, exact select over the gathered keys, every accept
-    // test a launch of its own on the gathered sums.
-    V.fuse_walk = 0;
-    V.m_total = h->V.m_total;
-}
-
-int vba_sh_stage1(vba_handle h, int iter, int initialize, int64_t m_total, double* d_abs_local) {
-    if (!h || !d_abs_local || m_total < 1) return fail(VBA_EINVAL, "bad argument");
-    if (int rc_settle = settle(h)) return rc_settle;
-    if (h->W != 1) return fail(VBA_EINVAL, "sharded mode uses a single window per handle");
-    if (h->reg) return fail(VBA_EINVAL, "sharded mode does not take a prior (vba_set_prior)");
-    if (int rc = ready(h)) return rc;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    h->V.m_total = m_total;
-    h->last_iter = iter;
-    h->last_init = initialize;
-    h->carry_ok = false;
-    h->shc.carried = false;
-    DevView V;
-    sharded_view(h, V);
-    if (h->hist_dirty || h->need_hist_reset) {
-        DevView Q = V;
-        for (int p = 0; p < 2; ++p) { Q.par = p; launch_clear_hist(Q, 1, s); }
-        h->hist_dirty = h->need_hist_reset = false;
-    }
-    launch_obs_residual(V, d_abs_local, s);
-    HIPCHK(hipGetLastError());
-    return VBA_OK;
-}
-
-int vba_sh_stage2(vba_handle h, const double* d_abs_all, int64_t count_all, double* d_partial_local) {
-    if (!h || !d_abs_all || !d_partial_local || count_all < 1) return fail(VBA_EINVAL, "bad argument");
-    if (h->V.m_total < 1 || count_all < 2 * h->V.m_total) return fail(VBA_ESTATE, "stage1 has not run or count_all < 2*m_total");
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    DevView V;
-    sharded_view(h, V);
-    V.abs_all = d_abs_all;
-    V.abs_all_count = count_all;
-    launch_select(V, true, s);          // digit 0 over the gathered keys as well
-    // the dynamics factor is a function of the states only: its blocks ride in this grid
-    h->sh_rode = !h->last_init && V.lat;
-    V.dyn_in_acc = h->sh_rode ? 1 : 0;
-    launch_obs_accumulate(V, s);
-    launch_shard_pack(V, d_partial_local, s);
-    HIPCHK(hipGetLastError());
-    return VBA_OK;
-}
-
-int vba_sh_stage3(vba_handle h, const double* d_partial_all, int ranks, double* d_trial_local) {
-    if (!h || !d_trial_local) return fail(VBA_EINVAL, "bad argument");
-    if (h->V.m_total < 1) return fail(VBA_ESTATE, "stage1 has not run");
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    CallSpec c;
-    c.iter = h->last_iter; c.initialize = h->last_init; c.call = -1; c.par = h->par;
-    CallCtx C;
-    sharded_view(h, C.V);
-    DevView& V = C.V;
-    const bool init = h->last_init != 0;
-    if (d_partial_all) {    // first trial of this call; NULL = another LM trial on the same system
-        if (ranks < 1) return fail(VBA_EINVAL, "ranks must be >= 1");
-        launch_shard_reduce(V, d_partial_all, ranks, s);
-        if (!init && !h->sh_rode) launch_dynamics(V, s);
-        // who reads the bands from memory?  Nobody when the trial kernel solves the 6x6 systems itself (landmark-only) or
-        // the chunk elimination forms its own blocks (full phase)
-        const bool need_bands = init ? V.fused_trial != 1 : !solve_forms_blocks(V);
-        if (need_bands) launch_assemble(V, 0, s);
-        h->sh_bands_ready = need_bands;
-        // every rank holds bit-identical systems (rank-ordered reductions), so the checked unpivoted path and its
-        // fallback are taken by all ranks alike: stage4 reports the failed check and the caller's loop repeats stage3
-        h->sh_pivot = h->pivot_mode;
-    }
-    V.pivot = h->sh_pivot;
-    C.fuse_assemble = false;
-    C.assembled = C.bands_ready = h->sh_bands_ready;
-    enqueue_trial(h, C, c, d_partial_all != nullptr);
-    h->sh_bands_ready = C.bands_ready;      // (a pivoted repeat of a landmark-only trial assembles the blocks it reads)
-    launch_shard_trial_sum(V, d_trial_local, s);
-    HIPCHK(hipGetLastError());
-    return VBA_OK;
-}
-
-int vba_sh_stage4(vba_handle h, const double* d_trial_all, int ranks, int* done) {
-    if (!h || !d_trial_all || !done || ranks < 1) return fail(VBA_EINVAL, "bad argument");
-    HIPCHK(hipSetDevice(h->device));
-    DevView V;
-    sharded_view(h, V);
-    launch_decide(V, d_trial_all, ranks, h->stream);
-    HIPCHK(hipGetLastError());
-    if (int rc = read_heads(h)) return rc;
-    *done = head(h, 0)->done;
-    if (!*done && (head(h, 0)->flags & 8u) && h->sh_pivot == 0) {   // pivot check failed: next stage3 uses the pivoted kernels
-        h->sh_pivot = 2;
-        h->fallbacks++;
-    }
-    if (*done) {
-        h->stepped = true;
-        h->V.m_total = 0;
-        h->par ^= 1;            // the trial buffer is the next call's input
-    }
-    return VBA_OK;
-}
-
-// ---- the same protocol with the exchanges issued by the library: RCCL all-gathers on the handle's stream between the stage
-// kernels, one host call and (per LM trial) one synchronisation per BA() call.  RCCL is resolved at run time from the path the
-// caller names -- the copy the process has loaded already when it also uses torch.distributed -- so the library itself
-// carries no link-time dependency on it.
-namespace {
-void* open_rccl(const char* path) {
-    void* dl = dlopen(path, RTLD_NOW | RTLD_NOLOAD);        // the instance the process has loaded already, if any
-    if (!dl) dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
-    return dl;
-}
-}  // namespace
-
-int vba_sh_unique_id(const char* rccl_path, void* id128) {
-    if (!rccl_path || !id128) return fail(VBA_EINVAL, "null argument");
-    void* dl = open_rccl(rccl_path);
-    if (!dl) return fail(VBA_EINVAL, std::string("cannot open ") + rccl_path + ": " + dlerror());
-    auto get_id = reinterpret_cast<ncclResult_t (*)(ncclUniqueId*)>(dlsym(dl, "ncclGetUniqueId"));
-    if (!get_id) { dlclose(dl); return fail(VBA_EINVAL, "ncclGetUniqueId not found in the named library"); }
-    ncclUniqueId id;
-    const ncclResult_t rc = get_id(&id);
-    dlclose(dl);
-    if (rc != ncclSuccess) return fail(VBA_EHIP, "ncclGetUniqueId failed (" + std::to_string((int)rc) + ")");
-    static_assert(sizeof(id) == 128, "unique id size");
-    std::memcpy(id128, &id, sizeof(id));
-    return VBA_OK;
-}
-
-int vba_sh_comm_init(vba_handle h, const char* rccl_path, const void* id128, int nranks, int rank) {
-    if (!h || !rccl_path || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(VBA_EINVAL, "bad argument");
-    if (int rc_settle = settle(h)) return rc_settle;
-    if (h->W != 1) return fail(VBA_EINVAL, "sharded mode uses a single window per handle");
-    if (h->shc.comm) return fail(VBA_ESTATE, "the handle has a communicator already");
-    HIPCHK(hipSetDevice(h->device));
-    auto& S = h->shc;
-    S.dl = open_rccl(rccl_path);
-    if (!S.dl) return fail(VBA_EINVAL, std::string("cannot open ") + rccl_path + ": " + dlerror());
-    auto init_rank = reinterpret_cast<ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>(dlsym(S.dl, "ncclCommInitRank"));
-    S.all_gather = reinterpret_cast<decltype(S.all_gather)>(dlsym(S.dl, "ncclAllGather"));
-    S.comm_destroy = reinterpret_cast<decltype(S.comm_destroy)>(dlsym(S.dl, "ncclCommDestroy"));
-    S.error_string = reinterpret_cast<decltype(S.error_string)>(dlsym(S.dl, "ncclGetErrorString"));
-    if (!init_rank || !S.all_gather || !S.comm_destroy || !S.error_string) {
-        dlclose(S.dl);
-        S = {};
-        return fail(VBA_EINVAL, "the named library does not export the RCCL entry points");
-    }
-    ncclUniqueId id;
-    std::memcpy(&id, id128, sizeof(id));
-    const ncclResult_t rc = init_rank(&S.comm, nranks, id, rank);       // collective: returns when every rank has joined
-    if (rc != ncclSuccess) {
-        const std::string why = S.error_string(rc);
-        dlclose(S.dl);
-        S = {};
-        return fail(VBA_EHIP, "ncclCommInitRank failed: " + why);
-    }
-    S.nranks = nranks;
-    S.rank = rank;
-    return VBA_OK;
-}
-
-int vba_sh_comm_destroy(vba_handle h) {
-    if (!h) return VBA_OK;
-    auto& S = h->shc;
-    if (!S.comm && !S.buf) return VBA_OK;
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
-    if (S.comm) S.comm_destroy(S.comm);
-    if (S.buf) hipFree(S.buf);
-    if (S.buf2) hipFree(S.buf2);
-    if (S.dl) dlclose(S.dl);
-    S = {};
-    return VBA_OK;
-}
-
-namespace {
-
-// exchange buffers of a sharded window (both protocols); m_total rows over all ranks
-int sh_ensure_buffers(vba_handle h, int64_t m_total) {
-    auto& S = h->shc;
-    const int n = h->n[0];
-    const int64_t m_pad = (m_total + S.nranks - 1) / S.nranks;     // equal all-gather slots
-    if (h->m[0] > m_pad) return fail(VBA_EINVAL, "this rank holds more rows than ceil(m_total / ranks)");
-    const int64_t pc = vba_sh_partial_count(n);
-    const int64_t R = S.nranks;
-    if (S.m_total != m_total || S.n != n) {       // (re)size the exchange buffers; the padding of a slot sorts above every |r|
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (S.buf) { HIPCHK(hipFree(S.buf)); S.buf = nullptr; }
-        const int64_t total = 2 * m_pad * (1 + R) + pc * (1 + R) + 2 * (1 + R) + 64;
-        HIPCHK(hipMalloc((void**)&S.buf, (size_t)total * 8));
-        S.abs_local = S.buf;
-        S.abs_all = S.abs_local + 2 * m_pad;
-        S.partial_local = S.abs_all + 2 * m_pad * R;
-        S.partial_all = S.partial_local + pc;
-        S.trial_local = S.partial_all + pc * R;
-        S.trial_all = S.trial_local + 2;
-        S.m_total = m_total; S.m_pad = m_pad; S.n = n;
-        S.m_local = -1;
-        S.carried = false;
-    }
-    if (S.m_local != h->m[0]) {     // stage 1 writes 2 * m_local keys: everything behind them must sort above every |r| -- also after
-                                    // a re-upload with FEWER rows of this rank than before (the old shard's keys would enter the median)
-        HIPCHK(hipStreamSynchronize(h->stream));
-        std::vector<double> inf((size_t)(2 * m_pad), INFINITY);
-        HIPCHK(hipMemcpy(S.abs_local, inf.data(), inf.size() * 8, hipMemcpyHostToDevice));
-        S.m_local = h->m[0];
-        S.carried = false;
-    }
-    // The warm bins must keep the bin of the GLOBAL median short (the gathered buckets of that bin are ranked as one list of at
-    // most 1024 keys): their width follows the key count over all ranks, not this rank's share -- 1/256 binade up to 300 000
-    // keys, 1/512 up to 600 000, 1/1024 beyond (range [c/2, 2c): a median that moves further between two calls is a miss and
-    // takes the exact select, as everywhere).
-    if (S.protocol == 1) {
-        const int64_t keys = 2 * m_total;
-        const int shift = keys <= 300000 ? 44 : (keys <= 600000 ? 43 : 42);
-        if (h->V.warm_shift != shift) {
-            h->V.warm_shift = shift;
-            h->carry_ok = 0;
-            S.carried = false;
-        }
-    }
-    // carried-keys protocol: [hist 1024 | part_next nblk_obs | part_trial trial_stride] per call parity, the gathered copy, the
-    // bucket slots [count | keys bucket_cap]
-    const int nbo = h->V.nblk_obs, cap = h->V.bucket_cap;
-    const int lenA = (1024 + nbo + h->V.trial_stride + 3) & ~3, lenB = (cap + 1 + 3) & ~3;      // (16-byte aligned slots)
-    if (S.protocol == 1 && cap > 0 && (S.lenA != lenA || S.lenB != lenB || !S.buf2)) {
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (S.buf2) { HIPCHK(hipFree(S.buf2)); S.buf2 = nullptr; }
-        const size_t total = (size_t)lenA * (2 + R) + (size_t)lenB * (1 + R) + 64;
-        HIPCHK(hipMalloc((void**)&S.buf2, total * 8));
-        HIPCHK(hipMemset(S.buf2, 0, total * 8));
-        HIPCHK(hipStreamSynchronize(nullptr));      // (the fill runs on the null stream, the exchanges on the handle's non-blocking one)
-        S.sendA[0] = S.buf2;
-        S.sendA[1] = S.sendA[0] + lenA;
-        S.recvA = S.sendA[1] + lenA;
-        S.sendB = S.recvA + (size_t)lenA * R;
-        S.recvB = S.sendB + lenB;
-        S.lenA = lenA; S.lenB = lenB;
-        S.carried = false;
-    }
-    return VBA_OK;
-}
-
-int sh_gather(vba_handle h, const double* src, double* dst, int64_t count) {
-    auto& S = h->shc;
-    const ncclResult_t rc = S.all_gather(src, dst, (size_t)count, ncclDouble, S.comm, h->stream);
-    if (rc != ncclSuccess) return fail(VBA_EHIP, std::string("ncclAllGather failed: ") + S.error_string(rc));
-    return VBA_OK;
-}
-
-// ---- round-3 protocol: every call gathers all |r| keys (kept for comparison, vba_sh_set_protocol(h, 0))
-int sh_call_classic(vba_handle h, int iter, int initialize, int64_t m_total, int* n_trials) {
-    auto& S = h->shc;
-    const int n = h->n[0];
-    const int64_t pc = vba_sh_partial_count(n);
-    if (int rc = vba_sh_stage1(h, iter, initialize, m_total, S.abs_local)) return rc;
-    if (int rc = sh_gather(h, S.abs_local, S.abs_all, 2 * S.m_pad)) return rc;
-    if (int rc = vba_sh_stage2(h, S.abs_all, 2 * S.m_pad * S.nranks, S.partial_local)) return rc;
-    if (int rc = sh_gather(h, S.partial_local, S.partial_all, pc)) return rc;
-    int trials = 0;
-    for (bool first = true;; first = false) {
-        if (int rc = vba_sh_stage3(h, first ? S.partial_all : nullptr, S.nranks, S.trial_local)) return rc;
-        if (int rc = sh_gather(h, S.trial_local, S.trial_all, 2)) return rc;
-        int done = 0;
-        if (int rc = vba_sh_stage4(h, S.trial_all, S.nranks, &done)) return rc;
-        ++trials;
-        if (done) break;
-        // lamda runs out after 9 trials (+ one repeat for a pivoted fallback): the device never reported an outcome
-        if (trials >= 24) return fail(VBA_ESTATE, "sharded BA call: the LM loop did not terminate within 24 trials");
-    }
-    if (n_trials) *n_trials = trials;
-    return VBA_OK;
-}
-
-// ---- carried-keys protocol.  One BA() call of a rank, first trial (everything asynchronous on the handle's stream):
-//   front, carried   k_sh_front   [accept test of the call in front on the gathered block sums] + the R warm histograms added up,
-//                                 the bin of the global median resolved, this rank's bucket of it -> sendB
-//                    all-gather B buckets of that bin (<= 8 kB per rank)
-//                    k_obs_accumulate  ranks the gathered buckets in its prologue (exact median), weights, local per-pose sums
-//                                 straight into the exchange buffer; the dynamics factor rides in its grid
-//   front, classic   (first call on new states; a call whose carried select missed)  residual pass -> all-gather of all keys
-//                                 -> exact select -> accumulation -> pack
-//                    all-gather C per-pose normal equations (27 n + 2 doubles) [-> rank-ordered reduce; one rank: used in place]
-//   solve            the handle's latency-mode kernels (every rank redundantly: bit-identical systems)
-//   trial            k_trial: trial residuals of the local rows + next call's keys in bin buckets, warm histogram and block sums,
-//                                 the latter two written straight into sendA
-//                    all-gather A [histogram | block sums] (~12 kB per rank) -- decided by the NEXT call's k_sh_front
-// Every rank enqueues the same collectives whether its window runs a call or skips it (a window that stalls at a call --
-// trial not cleanly accepted, select missed -- leaves the rest of the chain untouched on EVERY rank alike, the decisions being
-// taken on gathered data), and the host synchronises once per schedule.
-struct Sh2 {
-    vba_handle h;
-    int R;
-    const int *iters, *inits;
-    int ncalls, par0;
-
-    CallSpec spec(int c, bool carried, bool fold) const {
-        CallSpec q;
-        q.iter = iters[c]; q.initialize = inits[c]; q.call = c; q.par = (par0 + c) & 1;
-        q.carry = carried ? 2 : 0;
-        q.emit = 2;
-        q.fold = fold;
-        return q;
-    }
-    // the view of call q: exchange buffers where the kernels write anyway
-    void view(DevView& V, const CallSpec& q) const {
-        auto& S = h->shc;
-        view_for_call(h, V, q);
-        V.fuse_walk = 0;
-        V.m_total = S.m_total;
-        V.hist0_ext[0] = reinterpret_cast<unsigned*>(S.sendA[0]);
-        V.hist0_ext[1] = reinterpret_cast<unsigned*>(S.sendA[1]);
-        V.part_next = S.sendA[q.par ^ 1] + 1024;                     // the trial of this call writes the next call's slot
-        V.part_trial = V.part_next + V.nblk_obs;
-        V.sel_inline = 0;
-        V.pivot = h->sh_pivot;
-    }
-
-    int enqueue_call(int c, bool carried, bool fold) {
-        auto& S = h->shc;
-        hipStream_t s = h->stream;
-        const CallSpec q = spec(c, carried, fold);
-        const int n = h->n[0];
-        const int64_t pc = vba_sh_partial_count(n);
-        const bool init = q.initialize != 0;
-        CallCtx C;
-        view(C.V, q);
-        DevView& V = C.V;
-        h->sh_pivot = h->pivot_mode;
-        V.pivot = h->sh_pivot;
-        V.dyn_in_acc = (!init && V.lat) ? 1 : 0;
-        if (carried) {
-            if (fold) fill_params(V.prev, iters[c - 1], inits[c - 1]);
-            if (R > 1) V.wmax_ext = reinterpret_cast<unsigned long long*>(S.partial_local + (size_t)27 * n);     // (the front clears it)
-            launch_sh_front(V, S.recvA, R, S.lenA, S.sendB, fold ? 1 : 0, 1, s);
-            if (int rc = sh_gather(h, S.sendB, S.recvB, S.lenB)) return rc;
-            DevView Va = V;             // the accumulation: gathered buckets in, sums straight into the exchange buffer
-            Va.sel_slots = S.recvB; Va.sel_nslots = R; Va.sel_slot_stride = S.lenB;
-            Va.Hraw = S.partial_local; Va.braw = S.partial_local + (size_t)21 * n;
-            launch_obs_accumulate(Va, s);
-            if (int rc = sh_gather(h, S.partial_local, S.partial_all, pc)) return rc;
-            if (R > 1) launch_shard_reduce(V, S.partial_all, R, s, 0);
-            else { V.Hraw = S.partial_all; V.braw = S.partial_all + (size_t)21 * n; }      // one rank: the gathered copy IS the sum
-        } else {
-            // no carried keys: residual pass, all keys gathered, exact select
-            DevView Q = V;
-            for (int p = 0; p < 2; ++p) { Q.par = p; launch_clear_hist(Q, 1, s); }
-            V.redo = 2;                 // (a window repeating a call whose carried select missed takes part)
-            launch_sh_clear_miss(V, s);
-            launch_obs_residual(V, S.abs_local, s);
-            if (int rc = sh_gather(h, S.abs_local, S.abs_all, 2 * S.m_pad)) return rc;
-            DevView Vs = V;
-            Vs.abs_all = S.abs_all; Vs.abs_all_count = 2 * S.m_pad * R;
-            launch_select(Vs, true, s);
-            launch_obs_accumulate(Vs, s);
-            launch_shard_pack(V, S.partial_local, s);
-            if (int rc = sh_gather(h, S.partial_local, S.partial_all, pc)) return rc;
-            launch_shard_reduce(V, S.partial_all, R, s, 1);
-        }
-        if (!init && !V.dyn_in_acc) launch_dynamics(V, s);
-        const bool need_bands = init ? V.fused_trial != 1 : !solve_forms_blocks(V);
-        if (need_bands) launch_assemble(V, 0, s);
-        C.fuse_assemble = false;
-        C.assembled = C.bands_ready = need_bands;
-        enqueue_trial(h, C, q, true);
-        if (int rc = sh_gather(h, S.sendA[q.par ^ 1], S.recvA, S.lenA)) return rc;
-        return VBA_OK;
-    }
-
-    // call c stalled at its first trial (rejected, pivot check failed): the ordinary LM loop, the trial sums gathered per round
-    int finish_stalled(int c, bool carried, long& trials) {
-        auto& S = h->shc;
-        hipStream_t s = h->stream;
-        const CallSpec q = spec(c, carried, false);
-        CallCtx C;
-        view(C.V, q);
-        DevView& V = C.V;
-        const int n = h->n[0];
-        if (R == 1 && carried) { V.Hraw = S.partial_all; V.braw = S.partial_all + (size_t)21 * n; }    // (where the call's sums live, see enqueue_call)
-        V.redo = 2;
-        const bool init = q.initialize != 0;
-        C.fuse_assemble = false;
-        C.assembled = C.bands_ready = init ? V.fused_trial != 1 : !solve_forms_blocks(V);
-        for (int round = 0; round <= 24; ++round) {
-            launch_shard_trial_sum(V, S.trial_local, s);
-            if (int rc = sh_gather(h, S.trial_local, S.trial_all, 2)) return rc;
-            launch_decide(V, S.trial_all, R, s);
-            HIPCHK(hipGetLastError());
-            if (int rc = read_heads(h)) return rc;
-            if (head(h, 0)->done) {
-                // the last trial left the next call's keys, histogram and block sums: exchange them as every trial's are
-                if (int rc = sh_gather(h, S.sendA[q.par ^ 1], S.recvA, S.lenA)) return rc;
-                S.fallbacks_lm++;
-                return VBA_OK;
-            }
-            if (round == 24) break;
-            if ((head(h, 0)->flags & 8u) && h->sh_pivot == 0) { h->sh_pivot = 2; h->fallbacks++; }
-            V.pivot = h->sh_pivot;
-            enqueue_trial(h, C, q, false);
-            ++trials;
-        }
-        return fail(VBA_ESTATE, "sharded BA call: the LM loop did not terminate within 24 rounds");
-    }
-};
-
-}  // namespace
-
-int vba_sh_set_protocol(vba_handle h, int carried_keys) {
-    if (!h) return fail(VBA_EINVAL, "null handle");
-    if (int rc = settle(h)) return rc;
-    h->shc.protocol = carried_keys ? 1 : 0;
-    h->shc.carried = false;
-    return VBA_OK;
-}
-
-int vba_sh_stats(vba_handle h, int64_t* bytes_first_exchange, int64_t* fallbacks_miss, int64_t* fallbacks_lm) {
-    if (!h) return fail(VBA_EINVAL, "null handle");
-    auto& S = h->shc;
-    if (bytes_first_exchange) *bytes_first_exchange = (S.protocol == 1 && S.lenA && h->m_max == S.m_pad) ? (int64_t)S.lenA * 8 : 16 * S.m_pad;
-    if (fallbacks_miss) *fallbacks_miss = S.fallbacks_miss;
-    if (fallbacks_lm) *fallbacks_lm = S.fallbacks_lm;
-    return VBA_OK;
-}
-
-int vba_sh_run_schedule(vba_handle h, int ncalls, const int* iters, const int* inits, int64_t m_total, int* trials_total) {
-    if (!h || !iters || !inits || ncalls < 1 || m_total < 1) return fail(VBA_EINVAL, "bad argument");
-    auto& S = h->shc;
-    if (!S.comm) return fail(VBA_ESTATE, "vba_sh_comm_init has not run");
-    if (int rc_settle = settle(h)) return rc_settle;
-    if (h->W != 1) return fail(VBA_EINVAL, "sharded mode uses a single window per handle");
-    if (h->reg) return fail(VBA_EINVAL, "sharded mode does not take a prior (vba_set_prior)");
-    if (int rc = ready(h)) return rc;
-    HIPCHK(hipSetDevice(h->device));
-    if (int rc = sh_ensure_buffers(h, m_total)) return rc;
-    // (the exchange buffers are laid out by the handle's geometry -- observation blocks, bucket capacity --, which must be the same on
-    // every rank: a handle created for exactly ceil(m_total / ranks) rows; any other takes the round-3 protocol, whose slots are sized
-    // by m_total alone)
-    // (the carried-keys protocol is written for the trial kernel that forms the step; a handle whose mask was chosen by the library --
-    // big single windows get 14 -- takes 15 here)
-    if (h->fusion_auto && S.protocol != 0 && !(h->fusion & 1)) h->fusion = 15;
-    if (S.protocol == 0 || !h->V.wbucket || !h->V.lat || !(h->fusion & 1) || h->V.chunk <= 0 || h->m_max != S.m_pad) {
-        // the round-3 protocol, call by call
-        long total = 0;
-        for (int c = 0; c < ncalls; ++c) {
-            int t = 0;
-            if (int rc = sh_call_classic(h, iters[c], inits[c], m_total, &t)) return rc;
-            total += t;
-        }
-        S.carried = false;
-        if (trials_total) *trials_total = (int)total;
-        return VBA_OK;
-    }
-    hipStream_t s = h->stream;
-    h->V.m_total = m_total;
-    Sh2 P{h, S.nranks, iters, inits, ncalls, h->par};
-    bool carried0 = S.carried && h->carry_ok == 2 && S.carried_par == h->par;
-    h->carry_ok = 0;
-    S.carried = false;
-    struct Abandon {
-        vba_handle h; bool armed = true;
-        ~Abandon() { if (armed) { h->need_hist_reset = true; h->have_state.assign(h->W, 0); h->carry_ok = 0; h->V.m_total = 0; } }
-    } abandon{h};
-    {
-        DevView V0;
-        P.view(V0, P.spec(0, false, false));
-        launch_reset_calls(V0, s);
-    }
-    h->h_head[0].call_idx = 0; h->h_head[0].done = 0; h->h_head[0].flags = 0;
-    long trials = 0;
-    int next = 0;
-    bool first_carried = carried0;
-    for (int guard = 0; guard <= 2 * ncalls + 2; ++guard) {
-        for (int c = next; c < ncalls; ++c) {
-            const bool carried = c == next ? first_carried : true;
-            const bool fold = carried && c > next;
-            if (int rc = P.enqueue_call(c, carried, fold)) return rc;
-            // a call without carried keys in front of it is decided by a launch of its own (nothing folds it) when the NEXT
-            // call's front does not: the next call is always carried, so only the last call of the schedule is left over
-        }
-        {   // the accept test of the last call: the front kernel with nothing to resolve
-            CallSpec q = P.spec(ncalls - 1, true, true);
-            q.call = ncalls; q.par = (P.par0 + ncalls) & 1;
-            DevView V;
-            P.view(V, q);
-            fill_params(V.prev, iters[ncalls - 1], inits[ncalls - 1]);
-            launch_sh_front(V, S.recvA, P.R, S.lenA, S.sendB, 1, 0, s);
-        }
-        HIPCHK(hipGetLastError());
-        if (int rc = read_heads(h)) return rc;
-        const int at = (int)head(h, 0)->call_idx;
-        if (at >= ncalls) { trials += (long)(ncalls - next); break; }
-        if (head(h, 0)->flags & 32u) {          // the carried select of call `at` missed: that call again, exact select over all keys
-            trials += (long)(at - next);
-            S.fallbacks_miss++;
-            h->warm_misses++;
-            h->h_head[0].flags = 0;
-            next = at;
-            first_carried = false;
-            continue;
-        }
-        trials += (long)(at - next + 1);        // (the stalled call's first trial has run)
-        if (int rc = P.finish_stalled(at, at == next ? first_carried : true, trials)) return rc;
-        next = at + 1;
-        first_carried = true;
-        if (next >= ncalls) break;
-    }
-    if ((int)head(h, 0)->call_idx < ncalls) return fail(VBA_ESTATE, "sharded schedule did not complete (the window never reached its last call)");
-    abandon.armed = false;
-    h->par = (P.par0 + ncalls) & 1;
-    h->carry_ok = 2;
-    S.carried = true;
-    S.carried_par = h->par;
-    h->V.m_total = 0;
-    h->stepped = true;
-    h->last_pipelined = false;
-    h->last_iter = iters[ncalls - 1];
-    h->last_init = inits[ncalls - 1];
-    if (trials_total) *trials_total = (int)trials;
-    return VBA_OK;
-}
-
-int vba_sh_call(vba_handle h, int iter, int initialize, int64_t m_total, int* n_trials) {
-    return vba_sh_run_schedule(h, 1, &iter, &initialize, m_total, n_trials);
-}
-
-}  // extern "C"
