@@ -211,3 +211,38 @@ def test_three_cyclic_reduction_levels_in_front_give_the_bits_of_two(chunk, monk
         a, b = outs
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[0][0], b[0][0]) and a[0][1] == b[0][1] and a[0][3] == b[0][3], (chunk, pivot)
         assert np.isfinite(a[1]).all() and np.abs(a[1]).max() > 0
+
+
+def test_resident_solve_run_twice_on_one_handle_is_never_replayed_as_a_graph():
+    """k_solve_resident takes the epoch of its launch as a kernel argument; a graph replay would freeze it and the consumers'
+    flags of the previous run would read as already set.  Handles with VBA_OPT_FUSION bits 5 / 6 therefore launch kernel by
+    kernel: the same schedule three times on ONE handle gives the bits of a default handle every time, and captures nothing."""
+    from vinsat_amd.engine import BAEngine
+    from vinsat_amd import od_pipe, synth
+    cfg = synth.WindowConfig("res2", 300, 20, 5)
+    win = od_pipe.prepare_window(*synth.make_sequence(cfg, seed=12))
+    n, m = win.time_idx.size, win.ii.size
+    st0 = od_pipe.initial_guess(win, seed=12)
+    iters, inits = [9, 10, 11, 12, 13], [True, False, False, False, False]
+
+    def run(mask):
+        e = BAEngine(n, m)
+        e.set_solver(8, -1)
+        e.set_fusion(mask)
+        e.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+        e.upload_window(win.intrinsics, win.cumrot_last, win.time_idx)
+        outs = []
+        for rep in range(3):
+            e.set_states(st0, 1e-4)
+            e.run_schedule(iters, inits)
+            outs.append(e.get_states())
+        stats = e.schedule_graph_stats()
+        e.close()
+        return outs, stats
+    ref, stats_ref = run(15)
+    assert stats_ref[0] >= 1 and sum(stats_ref) == 3       # (five calls: the state-buffer parity alternates between runs, two graphs)
+    for mask in (15 + 32, 15 + 64):
+        got, stats = run(mask)
+        assert stats == (0, 0), (mask, stats)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[3] == b[3], mask
