@@ -354,6 +354,19 @@ int vba_host_orbit_chain(const double* x0 /*[6]*/, int steps, double* out /*[ste
 int vba_host_quat_chain(const double* q0 /*[4] or NULL*/, const double* r /*[K,4]*/, int K, double* out /*[K,4]*/);
 int vba_host_gap_rotations(const double* r /*[N,4]*/, int64_t N, const int64_t* time_idx /*[T]*/, int T, double* cum /*[T,4]*/);
 
+/* ---- the per-row part of the driver's data preparation ON THE DEVICE (no handle; synchronous; a process-wide workspace).
+ * For every detection row det[k] = [frame (s), lon (deg), lat (deg), u, v, confidence] (sim/nadir_sim.py:236, 256) with pose index
+ * ii[k] into the T ground-truth poses (pos_gt [T,3] ECI km, rot_gt [T,9] row-major camera->inertial rotation):
+ *   xyz[k]  = the landmark in ECI km at the frame's second (latlon_to_eci, BA_utils.py:1238-1251 with the ellipsoid of :1221-1236 and the
+ *             Greenwich angle of :1172-1218),
+ *   proj[k] = its reprojection at that ground-truth pose (landmark_project, BA_utils.py:30-43; depth clamped at 0.1 km, :13),
+ *   mask[k] = the driver's outlier test (od_pipe.py:930): 0 < proj < (4700, 2600), |proj - uv| < 1000 px, confidence > 0.8.
+ * Agrees with the host path (vinsat_amd/od_pipe.py without a device, which is bit-identical to the reference's arrays) to rounding:
+ * the device library's sin / cos are not the host's. */
+int vba_prepare_rows(int device, int64_t M, const double* det /*[M,6]*/, const int64_t* ii /*[M]*/, int T, const double* pos_gt /*[T,3]*/,
+                     const double* rot_gt /*[T,9]*/, const double* intrinsics /*[4] fx fy cx cy*/, double* xyz /*[M,3]*/, double* proj /*[M,2]*/,
+                     unsigned char* mask /*[M]*/);
+
 /* ---- free-landmark Schur-complement BA: ADD-ON, PARITY UNPINNED ------------------------------------------
  * The reference keeps its landmarks fixed (BA_filtering.py:32-37) and has nothing to marginalise; this mode is the
  * variant BASELINE.json's north_star describes on top of it and has NO counterpart in the reference.  Unknowns: 6 per

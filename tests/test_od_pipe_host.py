@@ -27,6 +27,34 @@ def test_prepare_window_matches_reference_inputs(name):
     assert rel_err(od_pipe.initial_guess(win), g["states0"][0]) < 1e-15
 
 
+def test_poses_that_lose_all_their_rows_are_renumbered_away():
+    """remove_elems (od_pipe.py:253-288): a pose whose rows are all masked out disappears (unless it is a 1000 s knot) and the pose
+    indices of the remaining rows are renumbered -- the vectorised preparation against the rule spelt out row by row."""
+    det, orb = synth.make_sequence("C2")
+    det = det.copy()
+    frames_ = np.unique(det[:, 0])
+    for fr in frames_[[3, 4, 50]]:
+        det[det[:, 0] == fr, 5] = 0.1                    # confidence below 0.8: every row of three frames goes
+    det[np.flatnonzero(det[:, 0] == frames_[70])[::2], 5] = 0.1      # half the rows of another frame: that pose stays
+    win = od_pipe.prepare_window(det.copy(), orb.copy())
+    full = od_pipe.prepare_window(synth.make_sequence("C2")[0], orb.copy())
+    assert win.time_idx.size == full.time_idx.size - 3 and not np.isin(frames_[[3, 4, 50]], win.time_idx).any()
+    kept_frames = det[win.mask, 0].astype(np.int64)
+    assert np.array_equal(win.time_idx[win.ii], kept_frames)                      # every row still points at its own frame
+    assert np.array_equal(np.unique(win.ii), np.arange(win.time_idx.size))       # no empty pose, no gap in the numbering
+    assert win.landmarks_uv.shape[0] == win.ii.size == int(win.mask.sum())
+
+
+def test_unsorted_detection_rows_take_the_sorting_path():
+    """read_detections on rows that are not in frame order (np.unique) gives the frames and counts of the sorted input."""
+    det, orb = synth.make_sequence("C1")
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(det.shape[0])
+    a = od_pipe.read_detections(det.copy(), orb.copy())
+    b = od_pipe.read_detections(det[perm].copy(), orb.copy())
+    assert np.array_equal(a[3], b[3]) and np.array_equal(np.bincount(a[4]), np.bincount(b[4]))
+
+
 def _oracle_ba(iter, states, velocities, imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences, Sigma, V,
                lamda_init, poses_gt_eci, initialize=False):
     st, lam, hess, _ = O.ba_iteration(iter, states[0].numpy(), imu_meas[0, :, -1, 6:10].numpy(), landmarks[0].numpy(),

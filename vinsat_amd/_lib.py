@@ -70,6 +70,7 @@ SIGNATURES = {
     "vba_host_orbit_chain": (c_int, [PD, c_int, PD]),
     "vba_host_quat_chain": (c_int, [PD, PD, c_int, PD]),
     "vba_host_gap_rotations": (c_int, [PD, c_int64, PI64, c_int, PD]),
+    "vba_prepare_rows": (c_int, [c_int, c_int64, PD, PI64, c_int, PD, PD, PD, PD, PD, c_void_p]),
     # free-landmark Schur add-on (parity unpinned: no counterpart in the reference)
     "vba_schur_last_error": (c_char_p, []),
     "vba_schur_create": (c_int, [c_int, c_int, c_int64, c_int, c_int, c_int64, POINTER(c_void_p)]),

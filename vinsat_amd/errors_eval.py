@@ -62,7 +62,7 @@ def _run_share(pairs, ba, batched, timing=None):
         # what the consumer still waited for)
         import time
         results = []
-        it = prepared_runs(list(pairs))
+        it = prepared_runs(list(pairs), device=0 if ba is None else None)      # (the HIP BA in use: per-row preparation on its device)
         while True:
             t0 = time.perf_counter()
             run = next(it, None)

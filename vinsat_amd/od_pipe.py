@@ -61,13 +61,18 @@ def read_detections(detections, orbit, intrinsics=None):
     """
     det = np.asarray(detections)
     fields = dict(frame=det[:, 0], uv=det[:, 3:5], lonlat=det[:, 1:3], confidence=det[:, 5])
-    uniq, counts = np.unique(det[:, 0], return_counts=True)
+    frame = det[:, 0]
+    if frame.size > 1 and np.all(frame[1:] >= frame[:-1]):     # rows in frame order (as the simulator writes them): no sort needed
+        first = np.flatnonzero(np.concatenate([[True], frame[1:] != frame[:-1]]))
+        uniq, counts = frame[first], np.diff(np.concatenate([first, [frame.size]]))
+    else:
+        uniq, counts = np.unique(frame, return_counts=True)
     uniq = uniq.astype(np.int64)
     filler = uniq.min() // KNOT_PERIOD + 1
     offset = 0
     time_new = []
-    ii = []
-    for i, (t, c) in enumerate(zip(uniq, counts)):
+    pose_of_frame = np.empty(uniq.size, dtype=np.int64)
+    for i, t in enumerate(uniq.tolist()):
         if t == filler * KNOT_PERIOD:
             filler += 1
         while t > filler * KNOT_PERIOD:
@@ -75,7 +80,8 @@ def read_detections(detections, orbit, intrinsics=None):
             filler += 1
             offset += 1
         time_new.append(t)
-        ii.append(np.full(c, i + offset, dtype=np.int64))
+        pose_of_frame[i] = i + offset
+    ii = [np.repeat(pose_of_frame, counts)]
     n_sec = orbit.shape[0]
     orbit[:, 0], orbit[:, 1], orbit[:, 2] = frames.ecef_to_eci(
         orbit[:, 0] / 1000, orbit[:, 1] / 1000, orbit[:, 2] / 1000, times=np.arange(n_sec))
@@ -88,37 +94,65 @@ def read_detections(detections, orbit, intrinsics=None):
     return orbit, fields, np.asarray(intrinsics, dtype=np.float64), np.array(time_new, dtype=np.int64), np.concatenate(ii)
 
 
-def prepare_window(detections, orbit_np, intrinsics=None, dt=1.0) -> Window:
-    """Reference od_pipe.py:924-961 (read, ground truth, outlier mask, renumber, IMU)."""
+def rows_on_device(detections, ii, pos_gt, rot_gt, intr, device):
+    """The per-row part of the preparation on GPU ``device`` (``vba_prepare_rows``): landmark positions ``xyz [M,3]``, their
+    reprojection at the ground-truth poses ``proj [M,2]`` and the outlier mask ``[M]`` (reference od_pipe.py:924-930)."""
+    _lib, lib = _lib_host()
+    det = np.ascontiguousarray(detections, dtype=np.float64)
+    ii = np.ascontiguousarray(ii, dtype=np.int64)
+    pos = np.ascontiguousarray(pos_gt, dtype=np.float64)
+    rot = np.ascontiguousarray(rot_gt, dtype=np.float64).reshape(-1, 9)
+    k4 = np.ascontiguousarray(intr, dtype=np.float64)
+    M = det.shape[0]
+    xyz, proj, mask = np.empty((M, 3)), np.empty((M, 2)), np.empty(M, dtype=np.uint8)
+    _lib.check(lib.vba_prepare_rows(int(device), M, _lib.as_pd(det), _lib.as_pi64(ii), pos.shape[0], _lib.as_pd(pos), _lib.as_pd(rot),
+                                    _lib.as_pd(k4), _lib.as_pd(xyz), _lib.as_pd(proj), mask.ctypes.data), lib)
+    return xyz, proj, mask.view(np.bool_)
+
+
+def prepare_window(detections, orbit_np, intrinsics=None, dt=1.0, device=None) -> Window:
+    """Reference od_pipe.py:924-961 (read, ground truth, outlier mask, renumber, IMU).
+
+    ``device``: None = everything on the host in NumPy, bit-identical to the arrays the reference's own preparation produces
+    (``tests/test_od_pipe_host.py``); a GPU index = the per-row part (lat / lon -> ECI, reprojection at ground truth, outlier
+    mask: most of the time of a 50 000-row sequence) by one kernel of the library, equal to rounding."""
     orbit, f, intr, time_idx, ii = read_detections(detections, np.array(orbit_np, dtype=np.float64), intrinsics)
     # process_ground_truths (od_pipe.py:94-123)
     pos_full = orbit[:, :3]
     pos_gt = pos_full[time_idx]
     vel_full = frames.finite_difference(pos_full, dt)
-    quat_gt = frames.nadir_quaternion(pos_gt)
     quat_full = frames.nadir_quaternion(pos_full)
-    xyz = frames.latlon_to_eci(f["lonlat"][:, 1], f["lonlat"][:, 0], f["frame"])
+    quat_gt = quat_full[time_idx]           # (the attitude of a position is a function of that row alone: the rows of one evaluation)
     uv = np.asarray(f["uv"], dtype=np.float64)
     conf = np.asarray(f["confidence"], dtype=np.float64)
     intr_rows = np.repeat(intr[None], len(pos_gt), axis=0)
     # outlier mask from the reprojection at ground truth (od_pipe.py:928-930): the rotation of a pose is formed once per pose and
     # gathered per row (the same operations per element as forming it per row -- ~100 rows share a pose)
     R = quat_to_matrix(quat_gt / np.linalg.norm(quat_gt, axis=-1, keepdims=True))
-    pc = np.einsum("kji,kj->ki", R[ii], xyz - pos_gt[ii])
-    z = np.maximum(pc[:, 2], 0.1)
-    proj = np.empty((len(ii), 2))
-    proj[:, 0] = intr[0] * pc[:, 0] / z + intr[2]
-    proj[:, 1] = intr[1] * pc[:, 1] / z + intr[3]
-    mask = ((proj[:, 0] > 0) & (proj[:, 1] > 0) & (proj[:, 0] < 4700) & (proj[:, 1] < 2600)
-            & (np.linalg.norm(proj - uv, axis=-1) < 1000) & (conf > 0.8))
+    if device is not None:
+        xyz, proj, mask = rows_on_device(detections, ii, pos_gt, R, intr, device)
+    else:
+        xyz = frames.latlon_to_eci(f["lonlat"][:, 1], f["lonlat"][:, 0], f["frame"])
+        pc = np.einsum("kji,kj->ki", R[ii], xyz - pos_gt[ii])
+        z = np.maximum(pc[:, 2], 0.1)
+        proj = np.empty((len(ii), 2))
+        proj[:, 0] = intr[0] * pc[:, 0] / z + intr[2]
+        proj[:, 1] = intr[1] * pc[:, 1] / z + intr[3]
+        mask = ((proj[:, 0] > 0) & (proj[:, 1] > 0) & (proj[:, 0] < 4700) & (proj[:, 1] < 2600)
+                & (np.linalg.norm(proj - uv, axis=-1) < 1000) & (conf > 0.8))
     # remove_elems (od_pipe.py:253-288): keep poses that still own an observation, and knots
+    all_kept = bool(mask.all())
+    ii_kept = ii if all_kept else ii[mask]
     keep = np.zeros(time_idx.shape[0], dtype=bool)
-    keep[np.unique(ii[mask])] = True
+    keep[ii_kept] = True                    # (every pose that still owns a row)
     keep |= (time_idx % KNOT_PERIOD == 0)
-    new_index = np.cumsum(keep) - 1
-    ii_new = new_index[ii[mask]]
-    time_idx = time_idx[keep]
-    pos_gt, quat_gt = pos_gt[keep], quat_gt[keep]
+    if keep.all():
+        ii_new = ii_kept
+    else:
+        new_index = np.cumsum(keep) - 1
+        ii_new = new_index[ii_kept]
+        time_idx = time_idx[keep]
+        pos_gt, quat_gt = pos_gt[keep], quat_gt[keep]
     # IMU pre-integration (od_pipe.py:945-961): only the rotation accumulated over each gap is
     # consumed downstream (BA_utils.py:295), zero-rate padding being the identity.
     T = len(pos_gt)
@@ -129,10 +163,11 @@ def prepare_window(detections, orbit_np, intrinsics=None, dt=1.0) -> Window:
     # rounded as the array expression rounds it -- the bits of the reference's cum_rots[:, :, -1]).
     omega = quat.omega_from_quats(quat_full, dt)
     cum = gap_rotations(quat.qexp(dt * omega), time_idx)
-    return Window(time_idx=time_idx, ii=ii_new, landmarks_uv=uv[mask], landmarks_xyz=xyz[mask],
-                  confidences=conf[mask], intrinsics=intr_rows, poses_gt=np.concatenate([pos_gt, quat_gt], 1),
+    sel = (lambda a: np.ascontiguousarray(a)) if all_kept else (lambda a: a[mask])
+    return Window(time_idx=time_idx, ii=ii_new, landmarks_uv=sel(uv), landmarks_xyz=sel(xyz),
+                  confidences=sel(conf), intrinsics=intr_rows, poses_gt=np.concatenate([pos_gt, quat_gt], 1),
                   vel_gt_full=vel_full, quat_gt_full=quat_full, omega_gt=omega, cumrot_last=cum,
-                  max_gap=max_gap, mask=mask, extras=dict(proj_gt=proj[mask]))
+                  max_gap=max_gap, mask=mask, extras=dict(proj_gt=sel(proj)))
 
 
 def _lib_host():
@@ -229,9 +264,9 @@ class SequenceRun:
     bookkeeping) and returns their arguments, ``finish_patch`` takes their result.  The sequential driver and the batched
     one (:func:`streaming_batched`: the patches of many sequences as windows of ONE handle) share this code."""
 
-    def __init__(self, detections, orbit_np):
+    def __init__(self, detections, orbit_np, device=None):
         import torch
-        win = self.win = prepare_window(detections, orbit_np)
+        win = self.win = prepare_window(detections, orbit_np, device=device)
         states = initial_guess(win, seed=0)
         self.time_idx, self.ii = win.time_idx, win.ii
         T = self.T = len(self.time_idx)
@@ -304,7 +339,7 @@ class SequenceRun:
         return torch.cat(self.errors), self.first_detection, self.times
 
 
-def prepared_runs(sources, threads=None, ahead=None):
+def prepared_runs(sources, threads=None, ahead=None, device=None):
     """``SequenceRun`` objects for ``sources`` -- ``(detections, orbit_np)`` array pairs or ``(detections_file, orbit_file)`` path
     pairs -- in order, prepared on ``threads`` host threads (default: three) up to ``ahead`` sequences in
     front of the consumer.  Data preparation is ~9 ms of NumPy per 50 000-row sequence against ~1 ms of BA calls: the array
@@ -322,7 +357,7 @@ def prepared_runs(sources, threads=None, ahead=None):
         det, orb = src
         if isinstance(det, (str, bytes, os.PathLike)):
             det, orb = np.load(det, allow_pickle=True), np.load(orb, allow_pickle=True)
-        return SequenceRun(det, orb)
+        return SequenceRun(det, orb, device=device)
 
     if threads <= 1 or len(sources) <= 1:
         for src in sources:
@@ -366,17 +401,20 @@ class _Clock:
 
 
 def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, detections_file_name=None,
-                      ba=None, num_iters=NUM_ITERS, record=None, timing=None, run=None):
+                      ba=None, num_iters=NUM_ITERS, record=None, timing=None, run=None, device=0):
     """Drop-in for the reference's ``streaming_version`` (od_pipe.py:911-1062).
 
     ``ba`` defaults to the HIP-backed :func:`vinsat_amd.ba.BA`; tests may inject another
     callable with the reference signature.  With the default ``ba`` and no ``record`` list the ``num_iters`` calls
     of a batch are issued as one chained device call (:func:`vinsat_amd.ba.BA_window`, same bits).
     ``timing`` (a dict) receives the wall time by phase (:class:`_Clock`).  ``run``: a :class:`SequenceRun` prepared elsewhere
-    (:func:`prepared_runs`) instead of the input arrays / files.
+    (:func:`prepared_runs`) instead of the input arrays / files.  With the default ``ba`` the per-row part of the data preparation
+    runs on GPU ``device`` as well (:func:`prepare_window`); an injected ``ba`` keeps the preparation on the host.
     """
     ba_window = None
+    rows_device = None
     if ba is None:
+        rows_device = device
         from .ba import BA as ba
         if record is None:
             from .ba import BA_window as ba_window
@@ -384,7 +422,7 @@ def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, dete
     t0 = clk.now()
     if run is None:
         np.random.seed(0)           # (as the reference's driver does, od_pipe.py:913; nothing here draws from it)
-        run = SequenceRun(*_load_sequence(detections, orbit_np, orbit_file_name, detections_file_name))
+        run = SequenceRun(*_load_sequence(detections, orbit_np, orbit_file_name, detections_file_name), device=rows_device)
     t0 = clk("prep", t0)
     while True:
         p = run.next_patch()
@@ -409,7 +447,7 @@ def streaming_version(detections=None, orbit_np=None, orbit_file_name=None, dete
     return out
 
 
-def streaming_batched(sequences, num_iters=NUM_ITERS, ba_window=None, record=None, timing=None, threads=None):
+def streaming_batched(sequences, num_iters=NUM_ITERS, ba_window=None, record=None, timing=None, threads=None, device=0):
     """Many sequences at once -- the reference's outer loop over sequence files (od_pipe.py:1069-1077) turned into the batch
     dimension of ``BA``: round r runs batch r of EVERY sequence that still has one as the windows of ONE ragged handle
     (:func:`vinsat_amd.ba.BA_window` on lists: every kernel launch covers all of them), sequences that have ended drop out.
@@ -419,11 +457,13 @@ def streaming_batched(sequences, num_iters=NUM_ITERS, ba_window=None, record=Non
     ``record`` (a list) receives ``dict(round, sequence, states, lamda)`` after every round; ``timing`` (a dict) the wall time
     by phase (:class:`_Clock`).
     """
+    rows_device = None
     if ba_window is None:
+        rows_device = device            # (the HIP BA is in use: the per-row preparation runs on its device as well)
         from .ba import BA_window as ba_window
     clk = _Clock(timing)
     t0 = clk.now()
-    runs = list(prepared_runs(sequences, threads=threads, ahead=len(sequences)))     # (on several host threads)
+    runs = list(prepared_runs(sequences, threads=threads, ahead=len(sequences), device=rows_device))     # (on several host threads)
     t0 = clk("prep", t0)
     rnd = 0
     while True:
