@@ -272,9 +272,11 @@ def driver_series(od_pipe, synth, errors_eval, device):
         out["folder"] = folder
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    out["note"] = ("wall = one call of the driver with its inputs in memory (sequences) / on disk (folder); prep is NumPy on one host "
-                   "core plus the library's host helpers for the serial chains (vba_host_*); replicas over GPUs and several workers "
-                   "per GPU (errors_eval.run_folder(gpus=N, workers_per_gpu=K)) run the prep of different sequences in parallel")
+    out["note"] = ("wall = one call of the driver with its inputs in memory (sequences) / on disk (folder); prep = the per-row part on the device "
+                   "(vba_prepare_rows: lat / lon -> ECI, reprojection at ground truth, outlier mask) + NumPy for the per-pose part + the library's "
+                   "host helpers for the serial chains (vba_host_*); the sequential folder run prepares the next sequences on host threads "
+                   "beside the BA calls; replicas over GPUs and several workers per GPU (errors_eval.run_folder(gpus=N, workers_per_gpu=K)) "
+                   "run the preparation of different sequences in parallel")
     return out
 
 
