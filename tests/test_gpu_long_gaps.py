@@ -256,3 +256,37 @@ def test_library_issued_sharded_protocols_across_long_gaps(tmp_path):
     port = 29300 + (os.getpid() % 200)
     mp.spawn(_worker_native_long, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     assert os.path.exists(tmp_path / "ok.npy")
+
+
+def test_BA_reg_across_long_gaps_against_the_oracle():
+    """``BA_reg`` (BA_filtering.py:100-210: the per-pose prior, its constant rotation residual, the trial's attitude residual scaled as
+    the reference passes its coefficients) on a window with long gaps: the long edges' orbit residual comes from kernels of their
+    own, everything else from the ordinary lanes -- whole calls against the oracle."""
+    from vinsat_amd.engine import BAEngine
+    win = _window(7, rows_per_pose=10, seed=9)
+    steps = np.array([5, 400, 5, 5, 150, 5], dtype=np.int64)
+    t = np.concatenate([[10], 10 + np.cumsum(steps)]).astype(np.int64)
+    n = t.size
+    rng = np.random.default_rng(6)
+    sp = win.states_gt.copy()
+    sp[:, :3] += rng.normal(0, 0.5, (n, 3))
+    Hs = np.stack([np.eye(6) * s for s in rng.uniform(0.5, 3.0, n)])
+    for i in range(n):
+        B = rng.normal(0, 0.1, (6, 6))
+        Hs[i] += B @ B.T
+    eng = BAEngine(n, win.ii.size)
+    eng.upload_observations(win.landmarks_xyz, win.landmarks_uv, win.confidences, win.ii, n)
+    eng.upload_window(win.intrinsics, win.cumrot_last, t)
+    eng.upload_prior(sp, Hs)
+    eng.set_prior(True)
+    st = win.states_gt.copy()
+    st[:, :3] += rng.normal(0, 2.0, (n, 3))
+    lam = 1e-4
+    for it in (10, 11, 12):
+        out, lam_g, hess, ntr, flags = eng.iterate(it, False, lam, st)
+        ref, lam_o, hess_o, ntr_o = O.ba_iteration(it, st, win.cumrot_last, win.landmarks_uv, win.landmarks_xyz, win.ii, t, win.intrinsics,
+                                                   win.confidences, lam, initialize=False, prior=(sp, Hs))
+        assert ntr == ntr_o and lam_g == lam_o, it
+        assert rel_err(out, ref) < 1e-7, it
+        st, lam = out, lam_g
+    eng.close()
