@@ -1,52 +1,82 @@
 #!/usr/bin/env python3
 """NumPy prototype of the parallel-in-time propagation of a long gap (vinsat_amd/csrc/vba_long.hip): convergence table of the
-parareal iteration (fine = the reference's chain of 1 s RK4 steps, coarse = one RK4 step per chunk) against the serial walk."""
-import numpy as np, math
-MU=398600.4418; J2C=1.75553e10
-def accel(p):
-    px2,py2,pz2=p[0]*p[0],p[1]*p[1],p[2]*p[2]
-    r2=px2+py2+pz2; r=math.sqrt(r2); r3=r*r*r; r7=r3*r3*r
-    k3=MU/r3; k7=J2C/r7
-    u0=6*px2-1.5*py2-1.5*pz2; u2=3*px2-4.5*py2-4.5*pz2
-    return np.array([-k3*p[0]+k7*u0*p[0], -k3*p[1]+k7*u0*p[1], -k3*p[2]+k7*u2*p[2]])
-def f(x): return np.concatenate([x[3:],accel(x[:3])])
-def rk4(x,h):
-    k1=f(x);k2=f(x+0.5*h*k1);k3=f(x+0.5*h*k2);k4=f(x+h*k3)
-    return x+(h/6)*(k1+2*k2+2*k3+k4)
-def fine(x,n):
-    for _ in range(n): x=rk4(x,1.0)
+iteration against the serial walk.  Fine propagator = the reference's chain of 1 s RK4 steps (BA_utils.py:73-87), coarse propagator
+= one RK4 step per chunk; the correction sweep linearised around the current chain (c_{j+1} = (F_j(U_j) - U_{j+1}) + A_j c_j with
+A_j the Jacobian of the coarse step), convergence by the chain's defect.  Same partition rule, tolerances and stopping rule as the
+kernel; prints, per gap length, the defect after every fine pass and the error of the end state against the serial chain.
+
+    python tools/parareal_prototype.py [gap seconds ...]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ba_oracle as O     # noqa: E402  (the oracle's RK4 and its sensitivity: tools are not the product)
+
+TIGHT, LOOSE = 2.0 ** -48, 2.0 ** -45
+
+
+def plan(s):
+    """vba_math.h:long_plan."""
+    L = 1
+    while 45 * L * L < 34 * s:
+        L += 1
+    if 64 * L < s:
+        L = (s + 63) // 64
+    P = (s + L - 1) // L
+    return L, P
+
+
+def fine(x, n):
+    for _ in range(n):
+        x = O.rk4_step(x)
     return x
-def parareal(x0,s,tol=2.0**-40,verbose=False):
-    L=math.ceil(math.sqrt(s)) if s<=1024 else math.ceil(s/32); P=math.ceil(s/L)
-    lens=[L]*(P-1)+[s-(P-1)*L]
-    U=[x0]; Gold=[]
-    for j in range(P):
-        g=rk4(U[j],float(lens[j])); Gold.append(g); U.append(g)
-    for k in range(1,P+1):
-        F=[fine(U[j],lens[j]) for j in range(P)]
-        Un=[x0]; d=0.0
-        for j in range(P):
-            gn=rk4(Un[j],float(lens[j]))
-            un=F[j]+(gn-Gold[j]); Gold[j]=gn
-            sc=np.array([np.abs(un[:3]).max()]*3+[np.abs(un[3:]).max()]*3)
-            d=max(d,(np.abs(un-U[j+1])/sc).max())
-            Un.append(un)
-        U=Un
-        if verbose: print(' iter',k,'delta',d)
-        if d<=tol: break
-    return U[-1],k,P,L
-a=6978.0
-x0=np.array([-a*0.6, 100.0, a*0.8, 0.5, -7.5, 0.3]); 
-v=math.sqrt(MU/a); 
-# polar-ish orbit
-p=np.array([-a*0.6,0.0,a*0.8]); vd=np.array([0.8,0.0,0.6])*v*1.001
-x0=np.concatenate([p,vd])
-for s in (65,100,300,945,1000,3000,6000):
-    ref=fine(x0,s)
-    xp,k,P,L=parareal(x0,s,verbose=(s in(945,6000)))
-    print(s,'P',P,'L',L,'iters',k,'rel err pos',np.abs(xp[:3]-ref[:3]).max()/np.abs(ref[:3]).max(),'vel',np.abs(xp[3:]-ref[3:]).max()/np.abs(ref[3:]).max())
-# perturbed (bad initial guess, 100 km off, 10% v)
-x1=x0.copy(); x1[:3]+=np.array([60,-50,40.0]); x1[3:]*=1.1
-for s in (945,):
-    ref=fine(x1,s); xp,k,P,L=parareal(x1,s,verbose=True)
-    print(s,'iters',k,'rel err',np.abs(xp[:3]-ref[:3]).max()/np.abs(ref[:3]).max(),np.abs(xp[3:]-ref[3:]).max()/np.abs(ref[3:]).max())
+
+
+def rel_defect(F, N):
+    return max(np.abs(F[:3] - N[:3]).max() / np.abs(N[:3]).max(), np.abs(F[3:] - N[3:]).max() / np.abs(N[3:]).max())
+
+
+def parallel_in_time(x0, s, verbose=False):
+    L, P = plan(s)
+    lens = [L] * (P - 1) + [s - (P - 1) * L]
+    U = [x0]
+    for j in range(P):                                  # the coarse chain
+        U.append(O.rk4_step(U[j], float(lens[j])))
+    prev = 1.0
+    for it in range(P + 1):
+        F = [fine(U[j], lens[j]) for j in range(P)]     # in parallel on the device: a lane per chunk
+        if it > 0:
+            worst = max(rel_defect(F[j], U[j + 1]) for j in range(P))
+            if verbose:
+                print(f"   fine pass {it + 1}: defect {worst:.2e}")
+            if worst <= TIGHT or (it >= 2 and worst <= LOOSE and worst > 0.25 * prev):
+                break
+            prev = worst
+        A = [O.rk4_step_stm(U[j], np.eye(6), float(lens[j]))[1] for j in range(P)]     # in parallel: Jacobian of each coarse step
+        c = np.zeros(6)
+        for j in range(P):                              # the serial part: a matrix-vector product per chunk
+            c = (F[j] - U[j + 1]) + A[j] @ c
+            U[j + 1] = U[j + 1] + c
+    return U[-1], it, P, L
+
+
+def main():
+    gaps = [int(a) for a in sys.argv[1:]] or [65, 100, 300, 510, 935, 1000, 3000, 6000]
+    a = 6978.0
+    v = np.sqrt(O.MU / a)
+    x0 = np.concatenate([np.array([-a * 0.6, 0.0, a * 0.8]), np.array([0.8, 0.0, 0.6]) * v * 1.001])
+    for s in gaps:
+        ref = fine(x0, s)
+        print(f"gap {s} s")
+        xp, it, P, L = parallel_in_time(x0, s, verbose=True)
+        ep = np.abs(xp[:3] - ref[:3]).max() / np.abs(ref[:3]).max()
+        ev = np.abs(xp[3:] - ref[3:]).max() / np.abs(ref[3:]).max()
+        print(f"   {P} chunks of {L} steps, {it} sweep(s); end state against the serial chain: position {ep:.1e}, velocity {ev:.1e} (relative)")
+
+
+if __name__ == "__main__":
+    main()

@@ -10,14 +10,14 @@
 // steps and whose coarse propagator G is ONE RK4 step over the chunk:
 //     U_0 = x0,  U_{j+1} <- F_j(U_j) + (G_j(U_j') - G_j(U_j))        (U' = the new iterate, swept left to right)
 // The fixed point is U_{j+1} = F_j(U_j), the serial chain itself (after k iterations the first k chunks are the serial chain
-// bit for bit).  The coarse step over ~35 s is wrong by ~5e-10 relative, so an iteration contracts the error by ~1e-8: the
+// bit for bit).  The coarse step over ~27 s is wrong by ~1e-10 relative, so an iteration contracts the error by ~1e-8: the
 // first one leaves ~1e-15 relative, and the fine pass of the second finds every chunk landing on the next chunk's start state
-// to 2^-45 relative -- the chain's defect -- and stops there (one sweep and two fine passes up to ~1000 s, three or four
-// sweeps at 6000 s; prototype with convergence table: tools/parareal_prototype.py).  What comes out differs from the serial
+// to 2^-48 relative -- the chain's defect -- and stops there (one sweep and two fine passes up to ~1000 s, two or three
+// sweeps at 3000 - 6000 s; prototype with convergence table: tools/parareal_prototype.py).  What comes out differs from the serial
 // walk by rounding (<= 1e-15 relative measured, the size of the difference between this library's rsq-based acceleration and
 // the reference's sqrt / division), is a function of the states and the step count only, and is the same in every kernel set
 // -- both kernels below call the same long_states().
-// Cost of a 935 s edge: 2 P + 2 L = 2 * 26 + 2 * 37 step times instead of 935.
+// Cost of a 935 s edge: 35 coarse steps + 2 * 27 fine steps + a 35-step matrix-vector recurrence instead of 935 fine steps.
 //
 // The transition matrix of a long edge is the ORDERED PRODUCT of the transition matrices of G <= 128 sub-chunks of ~10 steps (each
 // from its start state on the converged chain, six tangent lanes per sub-chunk as in dynamics_block), multiplied pairwise in a
@@ -62,15 +62,24 @@ __device__ __forceinline__ void rk4_coarse(const double* x, double h, double hh,
     }
 }
 
-constexpr double kLongTol = 0x1p-45;    // a chunk's fine end state and the next chunk's start state agree to this, relative: converged
+// The chain is converged when every chunk's fine end state and the next chunk's start state agree to kLongTight, relative (the
+// defects of up to 64 chunks add up along the gap: 2^-48 each keeps the end state within ~1e-13) -- or, a few units of rounding above
+// that, when another sweep no longer reduces the defect (a chunk of ~50 fine steps carries ~1e-15 of rounding of its own).
+constexpr double kLongTight = 0x1p-48, kLongLoose = 0x1p-45;
 
 // One wavefront.  x0: the state at the start of the gap (the same in every lane), s: its steps.  Lane j < P ends up with the
 // converged chunk-start state U_j in `U`; xh (every lane) = U_P, the state at the end of the gap.  Everything lives in registers:
-// the sweep is computed by all lanes alike from values fetched with v_readlane, a lane keeps what concerns its chunk (its start
-// state U, its end state N = the next chunk's start, its coarse value G).
+// a lane keeps what concerns its chunk (its start state U, its end state N = the next chunk's start).
+// The correction sweep is LINEARISED: with A_j the Jacobian of the coarse step at U_j (every lane forms its own, six tangents
+// through one RK4 step) the parareal update G_j(U_j') - G_j(U_j) becomes A_j c_j and the sweep the affine recurrence
+//     c_0 = 0,  c_{j+1} = (F_j(U_j) - U_{j+1}) + A_j c_j,   U_j' = U_j + c_j
+// -- a matrix-vector product and six v_readlane per chunk instead of a nonlinear RK4 step (66 instead of 250 instructions on the
+// serial path).  What the linearisation drops is second order in c (~1e-8 relative after the coarse chain: 1e-16), and the first
+// k chunks are still the serial chain bit for bit after k sweeps (c_1 = F_0 - U_1 exactly, and so on).
 // The iteration ends when the DEFECT of the chain is below tolerance: every chunk's fine propagation from its start state
 // lands on the next chunk's start state, i.e. the U_j are the serial chain up to that tolerance -- checked right behind the
-// fine pass, so a converged iterate costs no sweep of its own (one sweep, two fine passes for gaps up to ~1000 s).
+// fine pass, so a converged iterate costs no sweep of its own (one sweep, two fine passes for gaps up to ~1000 s).  Whatever the
+// sweep does, that check is what the result answers to.
 // subs: receives the states at the sub-chunk starts of the LAST fine pass -- subs[g * 6 .. ], g in chain order.
 __device__ __forceinline__ void long_states(const double* x0, int s, const LongPlan pl, int lane, double* U /*[6]*/, double* xh /*[6]*/,
                                             double* subs) {
@@ -79,17 +88,18 @@ __device__ __forceinline__ void long_states(const double* x0, int s, const LongP
     const int my_len = lane < P - 1 ? pl.L : (lane == P - 1 ? last_len : 0);
     const double hL = (double)pl.L, hhL = 0.5 * hL, h6L = hL / 6.0;
     const double hT = (double)last_len, hhT = 0.5 * hT, h6T = hT / 6.0;
-    double G[6], F[6], N[6], u[6];
+    double F[6], N[6], u[6];
+    double worst_prev = 1.0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) { u[c] = x0[c]; U[c] = x0[c]; G[c] = 0.0; N[c] = x0[c]; }
-    // the coarse chain
+    for (int c = 0; c < 6; ++c) { u[c] = x0[c]; U[c] = x0[c]; N[c] = x0[c]; }
+    // the coarse chain (serial, the same in every lane)
     for (int j = 0; j < P; ++j) {
         const bool tail = j == P - 1;
         double g[6];
         rk4_coarse(u, tail ? hT : hL, tail ? hhT : hhL, tail ? h6T : h6L, g);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            if (lane == j) { G[c] = g[c]; N[c] = g[c]; }
+            if (lane == j) N[c] = g[c];
             if (lane == j + 1) U[c] = g[c];
             u[c] = g[c];
         }
@@ -112,27 +122,54 @@ __device__ __forceinline__ void long_states(const double* x0, int s, const LongP
             }
         }
         if (it > 0) {       // (the coarse chain alone is never close enough)
-            const double np = fmax(fmax(fabs(N[0]), fabs(N[1])), fabs(N[2])) * kLongTol;
-            const double nv = fmax(fmax(fabs(N[3]), fabs(N[4])), fabs(N[5])) * kLongTol;
-            bool off = false;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) off = off || !(fabs(F[c] - N[c]) <= (c < 3 ? np : nv));     // (a NaN never converges: P + 1 iterations)
-            if (!__any(off && lane < P)) break;
+            const double np = fmax(fmax(fabs(N[0]), fabs(N[1])), fabs(N[2])), nv = fmax(fmax(fabs(N[3]), fabs(N[4])), fabs(N[5]));
+            const double dp = fmax(fmax(fabs(F[0] - N[0]), fabs(F[1] - N[1])), fabs(F[2] - N[2]));
+            const double dv = fmax(fmax(fabs(F[3] - N[3]), fabs(F[4] - N[4])), fabs(F[5] - N[5]));
+            const double rel = lane < P ? fmax(dp / np, dv / nv) : 0.0;
+            if (__any(rel != rel)) break;               // non-finite states: nothing to converge to (the residual carries the NaN on)
+            const double worst = wave_max(rel);
+            if (worst <= kLongTight || (it >= 2 && worst <= kLongLoose && worst > 0.25 * worst_prev)) break;
+            worst_prev = worst;
         }
-        // sweep (serial over the chunks, the same in every lane)
+        // the Jacobian of this lane's coarse step at its start state: A[r][k] = T[k][r] (two passes of three tangents: the registers)
+        double T[6][6];
+        {
+            const double h = lane == P - 1 ? hT : hL;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) u[c] = x0[c];
+            for (int half = 0; half < 2; ++half) {
+                double xs[6], t3[3][6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) xs[c] = U[c];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) t3[k][c] = (c == 3 * half + k) ? 1.0 : 0.0;
+                rk4_step_multi<3>(xs, t3, h);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) T[3 * half + k][c] = t3[k][c];
+            }
+        }
+        double d[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d[c] = F[c] - N[c];
+        // sweep: c_{j+1} = d_j + A_j c_j; every lane evaluates it with its own A and d, lane j's value is the one that counts
+        double cc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int j = 0; j < P; ++j) {
-            const bool tail = j == P - 1;
-            double g[6], un[6];
-            rk4_coarse(u, tail ? hT : hL, tail ? hhT : hhL, tail ? h6T : h6L, g);
+            double cn[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) un[c] = readlane_f64(F[c], j) + (g[c] - readlane_f64(G[c], j));
+            for (int r = 0; r < 6; ++r) {
+                double a = d[r];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) a = fma(T[k][r], cc[k], a);
+                cn[r] = readlane_f64(a, j);
+            }
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                if (lane == j) { G[c] = g[c]; N[c] = un[c]; }
-                if (lane == j + 1) U[c] = un[c];
-                u[c] = un[c];
+                if (lane == j) N[c] += cn[c];
+                if (lane == j + 1) U[c] += cn[c];
+                cc[c] = cn[c];
             }
         }
     }

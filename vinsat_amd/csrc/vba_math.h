@@ -289,19 +289,22 @@ VBA_HD void propagate_gap_multi(double* x, double (*t)[6], int steps, int hop) {
 
 // How a LONG gap of s one-second steps is cut for the parallel-in-time propagation (vba_long.hip) -- a function of s alone, so
 // that the host (which sizes the carried chunk states) and every kernel cut an edge alike.  P chunks of L steps (the last one
-// shorter): a sweep step of the iteration costs ~1.7 fine steps and there are two fine passes per sweep, L ~ sqrt(1.4 s) balances
-// them; at most 32 chunks.  Each chunk is cut again into sub-chunks of `sub` steps (at most four per chunk) whose start states
-// the last fine pass leaves behind: the transition matrix of the edge is the ordered product of the G <= 128 sub-chunk matrices.
+// shorter), a lane of one wavefront each: the serial part costs ~272 instructions per chunk (coarse chain + linearised sweep), the
+// two fine passes 360 per step, L ~ sqrt(0.76 s) balances them; at most 64 chunks.  Each chunk is cut again into sub-chunks of
+// `sub` steps whose start states the last fine pass leaves behind: the transition matrix of the edge is the ordered product of
+// the G <= 128 sub-chunk matrices.
 struct LongPlan { int L, P, sub, nsubL, G; };
 VBA_HD LongPlan long_plan(int s) {
     LongPlan p;
     int L = 1;
-    while (5 * L * L < 7 * s) ++L;
-    if (32 * L < s) L = (s + 31) / 32;
+    while (45 * L * L < 34 * s) ++L;
+    if (64 * L < s) L = (s + 63) / 64;
     p.L = L;
-    p.P = (s + L - 1) / L;             // <= 32
-    p.sub = (L + 3) / 4 > 8 ? (L + 3) / 4 : 8;
-    p.nsubL = (L + p.sub - 1) / p.sub; // <= 4
+    p.P = (s + L - 1) / L;             // <= 64
+    const int per_chunk = 128 / p.P < 4 ? 128 / p.P : 4;      // sub-chunks a chunk may have (2 .. 4)
+    const int even = (L + per_chunk - 1) / per_chunk;
+    p.sub = even > 8 ? even : 8;
+    p.nsubL = (L + p.sub - 1) / p.sub; // <= per_chunk
     const int last = s - (p.P - 1) * L;
     p.G = (p.P - 1) * p.nsubL + (last + p.sub - 1) / p.sub;
     return p;
