@@ -202,6 +202,29 @@ def config_series(BAEngine, od_pipe, synth, device, sync):
         e.close()
         gap["hop (predict_gpu, the reference's GPU default)" if hop else "rk4 (predict, the parity target)"] = {"value": 1e3 / ms, "ms_per_step": ms}
     out["GAP"] = gap
+    # the window of a sequence's LAST batch after six passes: 127 poses / 6 000 rows, ten gaps of 395 .. 1000 s (a knot every 1000 s)
+    win = od_pipe.prepare_window(*synth.make_multi_pass_sequence())
+    mp_states = od_pipe.initial_guess(win)
+    n, m = win.time_idx.size, win.ii.size
+    gaps = np.diff(win.time_idx)
+    mp = {"poses": int(n), "observations": int(m), "long_gaps": int((gaps > 64).sum()), "longest_gap_s": int(gaps.max())}
+    for hop in (False, True):
+        e = BAEngine(n, m, device=device)
+        e.set_integrator(hop)
+        load_windows(e, win, n, 1)
+        iters, inits = list(range(20)), [False] * 20
+        e.set_states(mp_states, 1e-4)
+        e.run_schedule(iters, inits)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            e.set_states(mp_states, 1e-4)
+            e.run_schedule(iters, inits)
+        sync()
+        ms = 1e3 * (time.perf_counter() - t0) / 60
+        e.close()
+        mp["hop (predict_gpu, the reference's GPU default)" if hop else "rk4 (predict, the parity target)"] = {"value": 1e3 / ms, "ms_per_step": ms}
+    out["SIXTH_PASS"] = mp
     return out
 
 
@@ -228,8 +251,9 @@ def driver_series(od_pipe, synth, errors_eval, device):
     import shutil
     import tempfile
     out = {"unit": "ms", "sequences": {}}
-    for name, fixture in (("C2", "c2"), ("C3", "c3"), ("two-pass", "gap")):
-        det, orb = synth.make_two_pass_sequence() if name == "two-pass" else synth.make_sequence(name)
+    for name, fixture in (("C2", "c2"), ("C3", "c3"), ("two-pass", "gap"), ("six-pass", None)):
+        det, orb = (synth.make_two_pass_sequence() if name == "two-pass" else synth.make_multi_pass_sequence() if name == "six-pass"
+                    else synth.make_sequence(name))
         od_pipe.streaming_version(detections=det.copy(), orbit_np=orb.copy())          # engines created, kernels loaded
         best = None
         for _ in range(3):
@@ -242,7 +266,7 @@ def driver_series(od_pipe, synth, errors_eval, device):
         wall, t = best
         e = {"wall": 1e3 * wall, "prep": 1e3 * t["prep"], "ba": 1e3 * t["ba"], "bookkeeping": 1e3 * t["bookkeeping"],
              "ba_calls": int(t["ba_calls"]), "rows": int(det.shape[0]), "host_over_ba": (t["prep"] + t["bookkeeping"]) / t["ba"]}
-        gpath = os.path.join(ROOT, "tests", "golden", fixture + ".npz")
+        gpath = os.path.join(ROOT, "tests", "golden", (fixture or "none") + ".npz")
         if os.path.exists(gpath):
             g = np.load(gpath)
             if "ref_wall_seconds" in g:

@@ -290,3 +290,25 @@ def test_BA_reg_across_long_gaps_against_the_oracle():
         assert rel_err(out, ref) < 1e-7, it
         st, lam = out, lam_g
     eng.close()
+
+
+def test_window_of_a_sixth_pass_with_ten_long_gaps_against_the_oracle():
+    """What the window of a sequence's last batch looks like after six passes: 127 poses, ten gaps of 395 .. 1000 s (a knot every
+    1000 s, od_pipe.py:213-221).  The factor and whole calls against the oracle's serial chain; the driver end to end against
+    the same driver with the oracle standing in for the GPU BA."""
+    from test_gpu_parity import _oracle_vs_gpu
+    from vinsat_amd import od_pipe, synth
+    det, orb = synth.make_multi_pass_sequence()
+    win = od_pipe.prepare_window(det.copy(), orb.copy())
+    gaps = np.diff(win.time_idx)
+    assert win.time_idx.size == 127 and (gaps > 64).sum() == 10 and gaps.max() == 1000
+    eng = _engine(win, win.time_idx)
+    rng = np.random.default_rng(1)
+    st = win.states_gt.copy()
+    st[:, :3] += rng.normal(0, 5.0, st[:, :3].shape)
+    _check_factor(eng, st, win.time_idx, win.cumrot_last)
+    args = (win.cumrot_last, win.landmarks_uv, win.landmarks_xyz, win.ii, win.time_idx, win.intrinsics, win.confidences)
+    lam = 1e-4
+    for it in (10, 11, 12):
+        st, lam, ntr, flags = _oracle_vs_gpu(eng, args, it, False, lam, st, tol=1e-7)
+    eng.close()

@@ -251,3 +251,36 @@ def make_two_pass_sequence(n_poses=12, obs_per_pose=6, stride=5, gap=1500, seed=
     uv = project(p, q, xyz, INTRINSICS) + rng.normal(0.0, pixel_noise, size=(m, 2))
     det = np.stack([frame_col.astype(np.float64), lon, lat, uv[:, 0], uv[:, 1], np.full(m, conf)], -1)
     return det, orbit_np
+
+
+def make_multi_pass_sequence(passes=6, n_poses=20, obs_per_pose=50, stride=5, gap=1500, seed=5, pixel_noise=1.0, conf=0.95, tail=140):
+    """``passes`` passes of ``n_poses`` frames, ``gap`` seconds apart -- what a sequence looks like after several passes: the window
+    of its last batch holds every earlier pass, a knot pose every 1000 s and therefore one or two gaps of hundreds of seconds per
+    pass (``od_pipe.py:213-221``).  Same construction as :func:`make_two_pass_sequence` (which stays as it is: fixtures were made
+    from it).  Returns ``(detections [M,6], orbit_np [N,12])``."""
+    t0 = 10
+    n_sec = t0 + (passes - 1) * gap + n_poses * stride + tail
+    traj = integrate_orbit(n_sec)
+    times = np.arange(n_sec)
+    ecef_km = frames.eci_to_ecef(traj[:, :3], times)
+    orbit_np = np.zeros((n_sec, 12))
+    orbit_np[:, :3] = ecef_km * 1000.0
+    xe, ye, ze = frames.ecef_to_eci(orbit_np[:, 0] / 1000, orbit_np[:, 1] / 1000, orbit_np[:, 2] / 1000, times)
+    pos_eci = np.stack([xe, ye, ze], -1)
+    rng = np.random.default_rng(seed)
+    first = t0 + stride * np.arange(n_poses)
+    frames_t = np.concatenate([first + p * gap for p in range(passes)])
+    k = obs_per_pose
+    frame_col = np.repeat(frames_t, k)
+    sub = ecef_km[frames_t]
+    sub_lat = np.rad2deg(np.arcsin(sub[:, 2] / np.linalg.norm(sub, axis=-1)))
+    sub_lon = np.rad2deg(np.arctan2(sub[:, 1], sub[:, 0]))
+    m = frame_col.size
+    lat = np.repeat(sub_lat, k) + rng.uniform(-1.2, 1.2, size=m)
+    lon = np.repeat(sub_lon, k) + rng.uniform(-2.0, 2.0, size=m)
+    xyz = frames.latlon_to_eci(lat, lon, frame_col)
+    p = np.repeat(pos_eci[frames_t], k, axis=0)
+    q = np.repeat(frames.nadir_quaternion(pos_eci[frames_t]), k, axis=0)
+    uv = project(p, q, xyz, INTRINSICS) + rng.normal(0.0, pixel_noise, size=(m, 2))
+    det = np.stack([frame_col.astype(np.float64), lon, lat, uv[:, 0], uv[:, 1], np.full(m, conf)], -1)
+    return det, orbit_np
