@@ -759,14 +759,20 @@ def test_run_schedule_equals_step_by_step(c2):
     e.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_windows_with_long_gaps_vs_oracle(seed):
+    """The same with up to four gaps of 65 .. 1300 s among the random ones: the long edges go parallel in time."""
+    test_randomised_windows_vs_oracle(seed, long_gaps=True)
+
+
 @pytest.mark.parametrize("seed", range(8))
-def test_randomised_windows_vs_oracle(seed):
+def test_randomised_windows_vs_oracle(seed, long_gaps=False):
     """Random window shapes (2..70 poses, 0..60 rows per pose, gaps 1..60 s, confidences 0.3..1.2, shuffled rows),
     random solver settings and a random call schedule, against the oracle."""
     from vinsat_amd.engine import BAEngine
     from vinsat_amd import od_pipe
     import random_windows
-    win, xyz, uv, ii, conf, t, _ = random_windows.make(seed)
+    win, xyz, uv, ii, conf, t, _ = random_windows.make(seed, long_gaps=long_gaps)
     n = win.time_idx.size
     eng = BAEngine(n, ii.size)
     mode = seed % 4

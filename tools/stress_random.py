@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off stress: the randomised GPU parity test (tests/test_gpu_parity.py::test_randomised_windows_vs_oracle) over a
-range of seeds.  usage: tools/stress_random.py first last"""
+range of seeds.  usage: tools/stress_random.py first last   (STRESS_LONG=1: with long gaps among the random ones)"""
 import os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,7 +9,7 @@ a, b = int(sys.argv[1]), int(sys.argv[2])
 bad = []
 for seed in range(a, b):
     try:
-        T.test_randomised_windows_vs_oracle.__wrapped__(seed) if hasattr(T.test_randomised_windows_vs_oracle, "__wrapped__") else T.test_randomised_windows_vs_oracle(seed)
+        T.test_randomised_windows_vs_oracle(seed, long_gaps=bool(os.environ.get("STRESS_LONG")))
     except Exception as ex:
         bad.append(seed)
         print(f"seed {seed}: {type(ex).__name__}: {str(ex)[:200]}", flush=True)
