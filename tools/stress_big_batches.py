@@ -16,7 +16,7 @@ bad = []
 for seed in range(a, b):
     rng = np.random.default_rng(9000 + seed)
     W = int(rng.integers(300, 1401))
-    wins = [make(100 * seed + k) for k in range(24)]
+    wins = [make(100 * seed + k, long_gaps=bool(os.environ.get("STRESS_LONG"))) for k in range(24)]
     n_max = max(w[5].size for w in wins); m_max = max(w[3].size for w in wins)
     single = []
     for (win, xyz, uv, ii, conf, t, st0) in wins:

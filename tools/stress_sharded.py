@@ -16,7 +16,7 @@ a, b = int(sys.argv[1]), int(sys.argv[2])
 bad = []
 iters, inits = [s[0] for s in SCHEDULE], [s[1] for s in SCHEDULE]
 for seed in range(a, b):
-    win, xyz, uv, ii, conf, t, st0 = make(seed)
+    win, xyz, uv, ii, conf, t, st0 = make(seed, long_gaps=bool(os.environ.get("STRESS_LONG")))
     n, m = t.size, ii.size
     try:
         def engine():
