@@ -102,7 +102,12 @@ def _run_replicas(pairs, devices, ba, batched, configure, timeout):
     import sys
     import tempfile
     import time
-    sizes = [int(np.load(det, mmap_mode="r", allow_pickle=False).shape[0]) for det, _ in pairs]
+    def rows(path):
+        try:
+            return int(np.load(path, mmap_mode="r", allow_pickle=False).shape[0])       # (the header only)
+        except ValueError:
+            return int(np.load(path, allow_pickle=True).shape[0])
+    sizes = [rows(det) for det, _ in pairs]
     share = split_longest_first(sizes, len(devices))
     visible = os.environ.get("HIP_VISIBLE_DEVICES")
     visible = [v for v in visible.split(",") if v] if visible else None
@@ -121,22 +126,29 @@ def _run_replicas(pairs, devices, ba, batched, configure, timeout):
                        PYTHONPATH=os.pathsep.join([root] + [q for q in os.environ.get("PYTHONPATH", "").split(os.pathsep) if q]))
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
+            # (stderr into a file: a pipe nobody reads while another worker is waited for would fill up and block its writer)
             procs.append(subprocess.Popen([sys.executable, "-m", "vinsat_amd.errors_eval", "--worker", os.path.join(tmp, f"w{w}.json")],
-                                          env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+                                          env=env, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, f"w{w}.err"), "w")))
         deadline = time.monotonic() + timeout
         failed = []
         for w, p in enumerate(procs):
             if p is None:
                 continue
+
+            def tail():
+                try:
+                    return open(os.path.join(tmp, f"w{w}.err")).read()[-400:]
+                except OSError:
+                    return ""
             try:
-                _, err = p.communicate(timeout=max(1.0, deadline - time.monotonic()))
+                p.wait(timeout=max(1.0, deadline - time.monotonic()))
             except subprocess.TimeoutExpired:
                 p.kill()
-                _, err = p.communicate()
-                failed.append((w, "timed out", err))
+                p.wait()
+                failed.append((w, "timed out", tail()))
                 continue
             if p.returncode != 0:
-                failed.append((w, f"exit code {p.returncode}", err))
+                failed.append((w, f"exit code {p.returncode}", tail()))
         if failed:
             raise RuntimeError("replica worker(s) failed: " + "; ".join(f"worker {w} on device {devices[w]}: {why}: {(err or '')[-400:]}"
                                                                           for w, why, err in failed))
