@@ -55,6 +55,37 @@ def test_unsorted_detection_rows_take_the_sorting_path():
     assert np.array_equal(a[3], b[3]) and np.array_equal(np.bincount(a[4]), np.bincount(b[4]))
 
 
+def test_host_helpers_of_the_library_against_the_interpreted_loops():
+    """vba_host_orbit_chain / vba_host_quat_chain / vba_host_gap_rotations (host code of the library, no device): the dead reckoning
+    across a gap against the interpreted loop it replaced (reference propagate_dynamics_init, BA_utils.py:114-129) -- the orbit to
+    rounding (the library's RK4 spells the acceleration differently), the attitude chain bit for bit -- and the gap rotations against
+    the array loop of the reference's driver (od_pipe.py:945-961) bit for bit."""
+    from vinsat_amd import quat
+    from vinsat_amd.synth import rk4_step
+    det, orb = synth.make_two_pass_sequence()
+    win = od_pipe.prepare_window(det, orb)
+    rng = np.random.default_rng(3)
+    state = win.states_gt[5].copy()
+    vel = state[7:] * (1 + 1e-3 * rng.normal(size=3))
+    omega = rng.normal(0, 1e-3, (400, 3))
+    for tdiff, duration in ((1, 0), (7, 30), (250, 149)):
+        slow = od_pipe.propagate_between_batches(state, vel, omega, tdiff, duration, rk4_step)
+        fast = od_pipe.propagate_between_batches(state, vel, omega, tdiff, duration)
+        assert fast.shape == slow.shape == (duration + 1, 10)
+        assert np.array_equal(fast[:, 3:7], slow[:, 3:7])                                  # quaternion chain: the same roundings
+        assert np.abs(fast[:, :3] - slow[:, :3]).max() < 1e-8 and np.abs(fast[:, 7:] - slow[:, 7:]).max() < 1e-11
+    # gap rotations: the loop of the reference's driver, spelt out
+    rot = quat.qexp(1.0 * win.omega_gt)
+    gaps = np.diff(win.time_idx)
+    cum = np.zeros((win.time_idx.size, 4))
+    cum[:, 3] = 1.0
+    for j in range(int(gaps.max())):
+        act = np.nonzero(gaps > j)[0]
+        step = rot[win.time_idx[act] + j]
+        cum[act] = step if j == 0 else quat.qmul(cum[act], step)
+    assert np.array_equal(od_pipe.gap_rotations(rot, win.time_idx), cum) and np.array_equal(win.cumrot_last, cum)
+
+
 def _oracle_ba(iter, states, velocities, imu_meas, landmarks, landmarks_xyz, ii, time_idx, intrinsics, confidences, Sigma, V,
                lamda_init, poses_gt_eci, initialize=False):
     st, lam, hess, _ = O.ba_iteration(iter, states[0].numpy(), imu_meas[0, :, -1, 6:10].numpy(), landmarks[0].numpy(),
