@@ -120,7 +120,11 @@ int vba_set_solver(vba_handle h, int chunk);
 int vba_set_solver2(vba_handle h, int chunk, int chunk2);
 
 /* Orbit integrator of the dynamics factor.  0 (default): one-second RK4 steps, the reference's CPU branch `predict`
- * (BA_utils.py:73-87) -- the parity target.  1: the coarse schedule of `propagate_orbit_dynamics_skip`
+ * (BA_utils.py:73-87) -- the parity target.  A gap of more than 64 s between two poses (time_idx of vba_upload_window; a knot
+ * every 1000 s makes every later-pass window hold such gaps, od_pipe.py:213-221) is propagated PARALLEL IN TIME: the same
+ * one-second steps in ~sqrt(gap) chunks side by side, their start states found by a parareal iteration whose fixed point is the
+ * serial chain (stopped when every chunk's end state meets the next chunk's start state to 2^-48 relative), the transition matrix
+ * as the ordered product of the chunks' matrices -- equal to the serial chain to rounding (csrc/vba_long.hip).  1: the coarse schedule of `propagate_orbit_dynamics_skip`
  * (BA_utils.py:52-71: steps of 100 s plus one remainder step) that the reference itself switches to when it sees a
  * GPU (`predict_gpu`, BA_filtering.py:16-17); results differ from mode 0 by the integration error. */
 int vba_set_integrator(vba_handle h, int hop100);
