@@ -33,7 +33,7 @@ def test_a_slow_barrier_is_not_charged_to_the_timed_region():
         p = _run("--gpus", world, "--dry-run", VBA_BENCH_BARRIER_SLEEP_MS="60")
         assert p.returncode == 0, p.stderr[-2000:]
         ms = json.loads(p.stdout.strip())["timed_region_ms"]
-        assert 19.0 <= ms < 45.0, ms
+        assert 19.0 <= ms < 70.0, ms          # (charged, the trailing barrier alone would add 60)
 
 
 def test_single_rank_needs_no_process_group():
