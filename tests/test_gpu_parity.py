@@ -307,6 +307,15 @@ def test_argument_errors_are_reported():
         eng.upload_window(np.ones((8, 4)), np.ones((8, 4)), np.array([0, 1, 2, 2, 3, 4, 5, 6]))              # repeated time
     with pytest.raises(VbaError):
         eng.upload_observations(np.zeros((100, 3)), np.zeros((100, 2)), np.ones(100), np.zeros(100, dtype=np.int64), 8)  # m > m_max
+    # vba_set_option: an option that does not exist, values an option does not take
+    from vinsat_amd import _lib
+    lib = _lib.load()
+    assert lib.vba_set_option(eng.h, 999, 0) != 0 and b"option" in lib.vba_last_error()
+    for name, value in (("trial_tiles", 3), ("accumulate_lanes", 5), ("chunk_waves", 7), ("warm_shift", 99)):
+        assert lib.vba_set_option(eng.h, _lib.OPT[name], value) != 0, name
+    assert lib.vba_set_option(eng.h, _lib.OPT["fusion"], 32) != 0          # (bits 4 .. 6: the comparison build only)
+    for name, value in (("trial_tiles", 2), ("accumulate_lanes", 16), ("chunk_waves", 1), ("pipeline", 0), ("schedule_graph", 0)):
+        assert lib.vba_set_option(eng.h, _lib.OPT[name], value) == 0, name
     eng.close()
 
 
